@@ -1,0 +1,187 @@
+/*
+ * arcle_hip.h — C ABI of the MI355X-native ARCLE hot path (libarcle_hip.so).
+ *
+ * This is the drop-in boundary for the reference's data-parallel hot path:
+ *   O2ARCv2Env.step()/transition()      /root/reference/arcle/envs/o2arcenv.py:130-151
+ *   ARCEnv.step()/transition()          /root/reference/arcle/envs/arcenv.py:155-176
+ *   RawARCEnv.step()                    /root/reference/arcle/envs/arcenv.py:60-76
+ *   AbstractARCEnv.submit()/init_state  /root/reference/arcle/envs/base.py:155-183
+ *   the op closures of arcle/actions    color.py:62-103, object.py:10-349, critical.py:8-66
+ *   BBoxWrapper/PointWrapper.action     /root/reference/arcle/wrappers/bbox.py:22-30,43-49
+ *
+ * The reference has no FFI of its own (it is pure Python); the functions below are what
+ * a ctypes binding inside the reference's `step()` would call.
+ *
+ * Conventions
+ *   - every pointer in `arcle_buffers` and every per-step array is a DEVICE pointer
+ *     (HBM of the GPU the handle was created on); plain C types only, no torch types.
+ *   - all functions return 0 on success or a negative arcle_status; they never throw.
+ *   - kernels are enqueued on the `hipStream_t` passed as `void* stream` (NULL = default
+ *     stream) and are asynchronous; outputs are valid after the stream is synchronised.
+ *   - a handle is not thread-safe; serialise calls on one handle (the reference env is
+ *     single-threaded as well).
+ *
+ * State layout in HBM (structure of arrays, all int8, one row per env):
+ *   plane[p]  : int8 [n_envs][H*W]   contiguous, row-major (env, row, col); p in arcle_plane
+ *   rec       : int8 [n_envs][16]    packed per-env scalars, byte offsets ARCLE_REC_*
+ *   cnt       : int32[n_envs][2]     {action_steps, submit_count}
+ */
+#ifndef ARCLE_HIP_H
+#define ARCLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARCLE_ABI_VERSION 1
+#define ARCLE_MAX_OPS 64
+#define ARCLE_MAX_CELLS 1024 /* H*W <= 1024 (one 64-lane wavefront x 16 cells) */
+
+/* ---- planes: keys of the reference state dict (o2arcenv.py:16-34, base.py:155-166) ---- */
+enum arcle_plane {
+  ARCLE_PL_INPUT = 0,      /* state['input']                                        */
+  ARCLE_PL_GRID = 1,       /* state['grid']                                         */
+  ARCLE_PL_SELECTED = 2,   /* state['selected']                    (O2ARCv2Env)     */
+  ARCLE_PL_CLIP = 3,       /* state['clip']                        (O2ARCv2Env/ARCEnv) */
+  ARCLE_PL_OBJECT = 4,     /* state['object_states']['object']     (O2ARCv2Env)     */
+  ARCLE_PL_OBJECT_SEL = 5, /* state['object_states']['object_sel'] (O2ARCv2Env)     */
+  ARCLE_PL_BACKGROUND = 6, /* state['object_states']['background'] (O2ARCv2Env)     */
+  ARCLE_PL_ANSWER = 7,     /* env.answer zero-padded to HxW (info['answer'], base.py:150) */
+  ARCLE_N_PLANES = 8
+};
+
+/* ---- per-env scalar record, byte offsets into rec[env][16] (all int8) ---- */
+#define ARCLE_REC_INPUT_DIM 0   /* [2] state['input_dim']                     */
+#define ARCLE_REC_GRID_DIM 2    /* [2] state['grid_dim']                      */
+#define ARCLE_REC_CLIP_DIM 4    /* [2] state['clip_dim']                      */
+#define ARCLE_REC_OBJECT_DIM 6  /* [2] object_states['object_dim']            */
+#define ARCLE_REC_OBJECT_POS 8  /* [2] object_states['object_pos'] (signed)   */
+#define ARCLE_REC_TRIALS 10     /* [1] state['trials_remain']                 */
+#define ARCLE_REC_TERMINATED 11 /* [1] state['terminated']                    */
+#define ARCLE_REC_ACTIVE 12     /* [1] object_states['active']                */
+#define ARCLE_REC_PARITY 13     /* [1] object_states['rotation_parity']       */
+#define ARCLE_REC_ANSWER_DIM 14 /* [2] env.answer.shape                       */
+#define ARCLE_REC_BYTES 16
+
+#define ARCLE_CNT_STEPS 0  /* env.action_steps == info['steps']          */
+#define ARCLE_CNT_SUBMIT 1 /* env.submit_count == info['submit_count']   */
+
+/* ---- op descriptors: one uint32 per slot of the env's operation table ----
+ * desc = kind | (arg << 8) | (flags << 16).  The table is what
+ * AbstractARCEnv.create_operations() returns (base.py:140-142); slot index == the
+ * integer `action['operation']`. */
+enum arcle_op_kind {
+  ARCLE_OP_NONE = 0,             /* empty slot (never valid to execute)                     */
+  ARCLE_OP_COLOR = 1,            /* gen_color(arg)        color.py:62-77                    */
+  ARCLE_OP_FLOODFILL = 2,        /* gen_flood_fill(arg)   color.py:79-103 (+dfs :8-30)      */
+  ARCLE_OP_MOVE = 3,             /* gen_move(arg) 0=U 1=D 2=R 3=L    object.py:218-243      */
+  ARCLE_OP_ROTATE = 4,           /* gen_rotate(arg) k=1,2,3 (CCW)    object.py:167-216      */
+  ARCLE_OP_FLIP = 5,             /* gen_flip(axis) 0=H 1=V 2=D0 3=D1 object.py:245-279      */
+  ARCLE_OP_COPY = 6,             /* gen_copy(src) 0="I" 1="O"        object.py:281-314      */
+  ARCLE_OP_PASTE = 7,            /* gen_paste(paste_blank=arg)       object.py:316-349      */
+  ARCLE_OP_COPY_FROM_INPUT = 8,  /* copy_from_input       critical.py:19-29                 */
+  ARCLE_OP_RESET_GRID = 9,       /* reset_grid            critical.py:8-17                  */
+  ARCLE_OP_RESIZE_GRID = 10,     /* resize_grid           critical.py:31-46                 */
+  ARCLE_OP_CROP_GRID = 11,       /* crop_grid             critical.py:48-66                 */
+  ARCLE_OP_RESIZE_TO_ANSWER = 12,/* RawARCEnv resize_to_answer  arcenv.py:31-35             */
+  ARCLE_OP_SUBMIT = 13,          /* AbstractARCEnv.submit base.py:172-183                   */
+  ARCLE_N_OP_KINDS = 14
+};
+#define ARCLE_OPF_RESET_SEL 1u /* wrapped by reset_sel  object.py:10-26 */
+#define ARCLE_OPF_KEEP_SEL 2u  /* wrapped by keep_sel   object.py:28-41 */
+#define ARCLE_OP_DESC(kind, arg, flags) \
+  ((uint32_t)(kind) | ((uint32_t)(arg) << 8) | ((uint32_t)(flags) << 16))
+#define ARCLE_OP_KIND(d) ((d) & 0xffu)
+#define ARCLE_OP_ARG(d) (((d) >> 8) & 0xffu)
+#define ARCLE_OP_FLAGS(d) (((d) >> 16) & 0xffu)
+
+/* ---- step flags ---- */
+/* Envs whose `terminated` is already 1 when the step starts are re-initialised from their
+ * task (init_state, base.py:155-166 + o2arcenv.py:16-34) instead of executing the action;
+ * reward 0, terminated 0 for that step (Gymnasium "next-step" autoreset; not in the
+ * reference, which keeps mutating a terminated env — that is the default here too). */
+#define ARCLE_STEP_AUTORESET 1u
+
+/* ---- sticky device status bits (arcle_get_status) ---- */
+#define ARCLE_ST_BAD_OP 1u       /* operation index out of range / empty slot: step skipped
+                                    (reference: IndexError / TypeError)                   */
+#define ARCLE_ST_ROTATE_DOMAIN 2u /* Rotate produced a position outside int8 or a tile that
+                                    does not fit HxW (reference: ValueError/garbage,
+                                    SURVEY.md A.6-2, A.6-6): step skipped                  */
+
+enum arcle_status {
+  ARCLE_OK = 0,
+  ARCLE_ERR_ARG = -1,     /* NULL / out-of-range argument                                */
+  ARCLE_ERR_CONFIG = -2,  /* unsupported H, W, n_ops or op table needing absent planes   */
+  ARCLE_ERR_HIP = -3,     /* a HIP runtime call failed; see arcle_last_error()           */
+  ARCLE_ERR_NO_DEVICE = -4
+};
+
+typedef struct arcle_config {
+  int32_t n_envs;    /* envs owned by this handle (this GPU's shard)                     */
+  int32_t H, W;      /* max_grid_size (base.py:49); H*W <= ARCLE_MAX_CELLS               */
+  int32_t max_trial; /* base.py:51; stored as int8 in trials_remain                      */
+  int32_t device;    /* HIP device ordinal, -1 = current device                          */
+} arcle_config;
+
+typedef struct arcle_buffers {
+  int8_t* plane[ARCLE_N_PLANES]; /* NULL for planes the env kind does not have           */
+  int8_t* rec;                   /* [n_envs][16]                                         */
+  int32_t* cnt;                  /* [n_envs][2]                                          */
+} arcle_buffers;
+
+typedef struct arcle_env arcle_env; /* opaque handle */
+
+/* Creates a handle. `bufs` are caller-owned device buffers (e.g. torch tensors' data_ptr);
+ * if bufs == NULL the library allocates all planes itself (hipMalloc) and frees them in
+ * arcle_destroy. Replaces AbstractARCEnv.__init__ state allocation (base.py:37-66). */
+int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, arcle_env** out);
+int arcle_destroy(arcle_env* env);
+/* Fills `out` with the device pointers the handle uses. */
+int arcle_get_buffers(const arcle_env* env, arcle_buffers* out);
+
+/* Installs the operation table (host array of descriptors). Replaces the list returned by
+ * create_operations() (o2arcenv.py:76-113, arcenv.py:26-41,110-138). */
+int arcle_set_op_table(arcle_env* env, const uint32_t* descs, int32_t n_ops);
+
+/* Re-initialises envs from PL_INPUT / REC_INPUT_DIM (init_state: base.py:155-166,
+ * o2arcenv.py:16-34; counters as in reset base.py:73-79). `mask` is a device uint8[n_envs]
+ * (non-zero = reset) or NULL for all envs. The task (input, answer, dims) must have been
+ * written into PL_INPUT, PL_ANSWER, REC_INPUT_DIM, REC_ANSWER_DIM by the host layer. */
+int arcle_reset(arcle_env* env, const uint8_t* mask, void* stream);
+
+/* One step() of every env. Replaces O2ARCv2Env.step (o2arcenv.py:130-147).
+ *   op      device int32[n_envs]       action['operation']
+ *   reward  device int32[n_envs] out   0/1 (o2arcenv.py:121-128)
+ *   term    device uint8[n_envs] out   bool(state['terminated'][0])
+ * selection ingress, three forms:
+ *   _mask : sel  device int8 [n_envs][H*W]   action['selection'] as given
+ *   _bbox : bbox device int32[n_envs][4]     (x1,y1,x2,y2) as BBoxWrapper.action (bbox.py:22-30)
+ *   _point: xy   device int32[n_envs][2]     (x,y)         as PointWrapper.action (bbox.py:43-49)
+ */
+int arcle_step_mask(arcle_env* env, const int8_t* sel, const int32_t* op, int32_t* reward,
+                    uint8_t* term, uint32_t flags, void* stream);
+int arcle_step_bbox(arcle_env* env, const int32_t* bbox, const int32_t* op, int32_t* reward,
+                    uint8_t* term, uint32_t flags, void* stream);
+int arcle_step_point(arcle_env* env, const int32_t* xy, const int32_t* op, int32_t* reward,
+                     uint8_t* term, uint32_t flags, void* stream);
+
+/* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*). Synchronises
+ * the stream. */
+int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);
+
+/* Algorithmic HBM bytes (SURVEY.md §8d accounting) moved by all step launches since the
+ * last call with clear != 0; accumulated on device by the step kernel only when the handle
+ * was created with accounting enabled via arcle_enable_accounting(env, 1). */
+int arcle_enable_accounting(arcle_env* env, int on);
+int arcle_get_accounting(arcle_env* env, uint64_t* bytes, uint64_t* steps, int clear, void* stream);
+
+const char* arcle_last_error(const arcle_env* env);
+int arcle_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCLE_HIP_H */
