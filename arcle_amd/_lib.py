@@ -1,0 +1,83 @@
+"""ctypes binding of libarcle_hip.so — the C ABI declared in include/arcle_hip.h.
+
+The HIP library is THE product path: there is no CPU fallback.  If the shared object is missing
+or the machine has no HIP device, creating an env raises `ArcleHipError` loudly.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libarcle_hip.so")
+SOURCES = [os.path.join(_CSRC, "arcle_hip.hip"), os.path.join(_CSRC, "arcle_wave.h"),
+           os.path.join(_CSRC, "..", "..", "include", "arcle_hip.h")]
+
+ABI_VERSION = 1
+N_PLANES = 8
+MAX_OPS = 64
+EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buffers", "arcle_set_op_table",
+           "arcle_reset", "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_get_status",
+           "arcle_enable_accounting", "arcle_get_accounting", "arcle_last_error"]
+
+
+class ArcleHipError(RuntimeError):
+    pass
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("max_trial", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+class Buffers(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_void_p * N_PLANES), ("rec", ctypes.c_void_p), ("cnt", ctypes.c_void_p)]
+
+
+def build(force=False, verbose=False):
+    """Compiles csrc/arcle_hip.hip for gfx950 into csrc/libarcle_hip.so (in-tree)."""
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in SOURCES):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise ArcleHipError("hipcc not found: cannot build libarcle_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library (does not need a GPU; creating a handle does)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ArcleHipError(
+            f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  arcle_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32
+    L.arcle_abi_version.restype = ctypes.c_int
+    L.arcle_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(Buffers), ctypes.POINTER(vp)]
+    L.arcle_destroy.argtypes = [vp]
+    L.arcle_get_buffers.argtypes = [vp, ctypes.POINTER(Buffers)]
+    L.arcle_set_op_table.argtypes = [vp, ctypes.POINTER(u32), i32]
+    L.arcle_reset.argtypes = [vp, vp, vp]
+    for name in ("arcle_step_mask", "arcle_step_bbox", "arcle_step_point"):
+        getattr(L, name).argtypes = [vp, vp, vp, vp, vp, u32, vp]
+    L.arcle_get_status.argtypes = [vp, ctypes.POINTER(u32), ctypes.c_int, vp]
+    L.arcle_enable_accounting.argtypes = [vp, ctypes.c_int]
+    L.arcle_get_accounting.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.c_int, vp]
+    L.arcle_last_error.argtypes = [vp]
+    L.arcle_last_error.restype = ctypes.c_char_p
+    if L.arcle_abi_version() != ABI_VERSION:
+        raise ArcleHipError("libarcle_hip.so ABI version mismatch — rebuild")
+    _lib = L
+    return L

@@ -1,0 +1,312 @@
+// arcle_hip.hip — gfx950 kernels + the C ABI of include/arcle_hip.h  (libarcle_hip.so)
+//
+// Kernels
+//   arcle_step_kernel   one wavefront per env, 4 envs per 256-thread workgroup; body in arcle_wave.h
+//   arcle_reset_kernel  init_state for (masked) envs
+// Launch geometry: grid = ceil(N/4) workgroups rounded up to a multiple of 8.  Workgroup b is observed
+// to run on XCD b%8 (MI355X_MICROARCH.md §Workgroup dispatch); the block->env map below gives each XCD
+// one contiguous range of envs, so the 128 B lines shared by neighbouring envs' planes stay in one
+// XCD's L2.  That is an affinity choice only — correctness never depends on placement (envs share no
+// data and no workgroup communicates with another).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#define ARCLE_DEV __device__ __forceinline__
+
+namespace xl {  // cross-lane primitives of one 64-lane wavefront
+ARCLE_DEV uint32_t shfl(uint32_t v, int src_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+ARCLE_DEV unsigned long long ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+ARCLE_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+ARCLE_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// orders this wave's LDS traffic (each wave owns a private LDS tile: no workgroup barrier needed)
+ARCLE_DEV void lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+}  // namespace xl
+
+#include "arcle_wave.h"
+
+using arcle::StepParams;
+using arcle::WaveLDS;
+
+static constexpr int WAVES_PER_WG = 4;
+
+__device__ __forceinline__ int env_of_wave(const StepParams& p) {
+  const uint32_t nb = gridDim.x, b = blockIdx.x;          // nb is a multiple of 8
+  const uint32_t vb = (b & 7u) * (nb >> 3) + (b >> 3);    // XCD-contiguous env ranges
+  const int env = (int)(vb * WAVES_PER_WG + (threadIdx.x >> 6));
+  return __builtin_amdgcn_readfirstlane(env);
+}
+
+__global__ __launch_bounds__(256) void arcle_step_kernel(const StepParams p) {
+  __shared__ WaveLDS lds[WAVES_PER_WG];
+  const int env = env_of_wave(p);
+  if (env >= p.n_envs) return;
+  arcle::wave_step(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+}
+
+__global__ __launch_bounds__(256) void arcle_reset_kernel(const StepParams p) {
+  __shared__ WaveLDS lds[WAVES_PER_WG];
+  const int env = env_of_wave(p);
+  if (env >= p.n_envs) return;
+  arcle::wave_reset(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: the C ABI
+// ------------------------------------------------------------------------------------------------
+struct arcle_env {
+  arcle_config cfg;
+  arcle_buffers bufs;
+  bool owns_bufs;
+  StepParams base;
+  uint32_t* d_status;
+  uint32_t* d_acct;
+  uint64_t acct_steps;
+  int device;
+  char err[256];
+};
+
+#define HIP_TRY(env, call)                                                                        \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      snprintf((env)->err, sizeof((env)->err), "%s failed: %s", #call, hipGetErrorString(e_));    \
+      return ARCLE_ERR_HIP;                                                                       \
+    }                                                                                             \
+  } while (0)
+
+static int fail(arcle_env* e, int code, const char* msg) {
+  if (e) snprintf(e->err, sizeof(e->err), "%s", msg);
+  return code;
+}
+
+extern "C" int arcle_abi_version(void) { return ARCLE_ABI_VERSION; }
+
+extern "C" const char* arcle_last_error(const arcle_env* env) { return env ? env->err : "null handle"; }
+
+extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, arcle_env** out) {
+  if (!cfg || !out) return ARCLE_ERR_ARG;
+  *out = nullptr;
+  if (cfg->n_envs <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->H > 127 || cfg->W > 127 ||
+      cfg->H * cfg->W > ARCLE_MAX_CELLS || cfg->max_trial < -128 || cfg->max_trial > 127)
+    return ARCLE_ERR_CONFIG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ARCLE_ERR_NO_DEVICE;
+  arcle_env* e = new (std::nothrow) arcle_env();
+  if (!e) return ARCLE_ERR_ARG;
+  memset(e, 0, sizeof(*e));
+  e->cfg = *cfg;
+  if (cfg->device >= 0) {
+    if (cfg->device >= ndev || hipSetDevice(cfg->device) != hipSuccess) {
+      delete e;
+      return ARCLE_ERR_NO_DEVICE;
+    }
+  }
+  hipGetDevice(&e->device);
+  StepParams& b = e->base;
+  b.n_envs = cfg->n_envs;
+  b.H = cfg->H;
+  b.W = cfg->W;
+  b.P = cfg->H * cfg->W;
+  b.PS = (b.P + 15) & ~15;
+  b.max_trial = cfg->max_trial;
+  b.div_magic = 65536u / (uint32_t)cfg->W + 1u;
+  for (uint32_t n = 0; n < 2048; n++)
+    if (((n * b.div_magic) >> 16) != n / (uint32_t)cfg->W) {
+      delete e;
+      return ARCLE_ERR_CONFIG;
+    }
+  b.nseg = (cfg->W >= 16) ? 2 : 1 + (15 + cfg->W - 1) / cfg->W;
+  const size_t plane_bytes = (size_t)cfg->n_envs * b.PS;
+  if (bufs) {
+    e->bufs = *bufs;
+    e->owns_bufs = false;
+    if (!bufs->plane[ARCLE_PL_INPUT] || !bufs->plane[ARCLE_PL_GRID] || !bufs->plane[ARCLE_PL_ANSWER] || !bufs->rec ||
+        !bufs->cnt) {
+      delete e;
+      return ARCLE_ERR_ARG;
+    }
+    for (int i = 0; i < ARCLE_N_PLANES; i++)
+      if ((reinterpret_cast<uintptr_t>(bufs->plane[i]) & 15) != 0) {
+        delete e;
+        return ARCLE_ERR_ARG;  // planes must be 16-byte aligned
+      }
+    if ((reinterpret_cast<uintptr_t>(bufs->rec) & 15) != 0) {
+      delete e;
+      return ARCLE_ERR_ARG;
+    }
+  } else {
+    e->owns_bufs = true;
+    for (int i = 0; i < ARCLE_N_PLANES; i++) {
+      if (hipMalloc((void**)&e->bufs.plane[i], plane_bytes) != hipSuccess ||
+          hipMemset(e->bufs.plane[i], 0, plane_bytes) != hipSuccess) {
+        arcle_destroy(e);
+        return ARCLE_ERR_HIP;
+      }
+    }
+    if (hipMalloc((void**)&e->bufs.rec, (size_t)cfg->n_envs * ARCLE_REC_BYTES) != hipSuccess ||
+        hipMemset(e->bufs.rec, 0, (size_t)cfg->n_envs * ARCLE_REC_BYTES) != hipSuccess ||
+        hipMalloc((void**)&e->bufs.cnt, (size_t)cfg->n_envs * 8) != hipSuccess ||
+        hipMemset(e->bufs.cnt, 0, (size_t)cfg->n_envs * 8) != hipSuccess) {
+      arcle_destroy(e);
+      return ARCLE_ERR_HIP;
+    }
+  }
+  if (hipMalloc((void**)&e->d_status, 4) != hipSuccess || hipMemset(e->d_status, 0, 4) != hipSuccess) {
+    arcle_destroy(e);
+    return ARCLE_ERR_HIP;
+  }
+  for (int i = 0; i < ARCLE_N_PLANES; i++) b.plane[i] = e->bufs.plane[i];
+  b.rec = e->bufs.rec;
+  b.cnt = e->bufs.cnt;
+  b.status = e->d_status;
+  b.n_ops = 0;
+  *out = e;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_destroy(arcle_env* e) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (e->owns_bufs) {
+    for (int i = 0; i < ARCLE_N_PLANES; i++)
+      if (e->bufs.plane[i]) (void)hipFree(e->bufs.plane[i]);
+    if (e->bufs.rec) (void)hipFree(e->bufs.rec);
+    if (e->bufs.cnt) (void)hipFree(e->bufs.cnt);
+  }
+  if (e->d_status) (void)hipFree(e->d_status);
+  if (e->d_acct) (void)hipFree(e->d_acct);
+  delete e;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_get_buffers(const arcle_env* e, arcle_buffers* out) {
+  if (!e || !out) return ARCLE_ERR_ARG;
+  *out = e->bufs;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n_ops) {
+  if (!e || !descs) return ARCLE_ERR_ARG;
+  if (n_ops <= 0 || n_ops > ARCLE_MAX_OPS) return fail(e, ARCLE_ERR_CONFIG, "n_ops out of range");
+  for (int i = 0; i < n_ops; i++) {
+    const uint32_t k = ARCLE_OP_KIND(descs[i]), f = ARCLE_OP_FLAGS(descs[i]), a = ARCLE_OP_ARG(descs[i]);
+    if (k >= ARCLE_N_OP_KINDS) return fail(e, ARCLE_ERR_CONFIG, "unknown op kind");
+    const bool need_sel = (f & (ARCLE_OPF_RESET_SEL | ARCLE_OPF_KEEP_SEL)) != 0;
+    const bool need_obj = (k == ARCLE_OP_MOVE || k == ARCLE_OP_ROTATE || k == ARCLE_OP_FLIP);
+    const bool need_clip = (k == ARCLE_OP_COPY || k == ARCLE_OP_PASTE);
+    if ((need_sel || need_obj) && !e->bufs.plane[ARCLE_PL_SELECTED])
+      return fail(e, ARCLE_ERR_CONFIG, "op table needs the `selected` plane");
+    if (need_obj && !(e->bufs.plane[ARCLE_PL_OBJECT] && e->bufs.plane[ARCLE_PL_OBJECT_SEL] &&
+                      e->bufs.plane[ARCLE_PL_BACKGROUND]))
+      return fail(e, ARCLE_ERR_CONFIG, "op table needs the object planes");
+    if (need_clip && !e->bufs.plane[ARCLE_PL_CLIP]) return fail(e, ARCLE_ERR_CONFIG, "op table needs the `clip` plane");
+    if ((k == ARCLE_OP_MOVE && a > 3) || (k == ARCLE_OP_ROTATE && (a < 1 || a > 3)) || (k == ARCLE_OP_FLIP && a > 3) ||
+        (k == ARCLE_OP_COPY && a > 1) || (k == ARCLE_OP_PASTE && a > 1))
+      return fail(e, ARCLE_ERR_CONFIG, "op argument out of range");
+  }
+  memset(e->base.ops, 0, sizeof(e->base.ops));
+  memcpy(e->base.ops, descs, sizeof(uint32_t) * (size_t)n_ops);
+  e->base.n_ops = n_ops;
+  return ARCLE_OK;
+}
+
+static dim3 grid_for(int n_envs) {
+  unsigned nb = (unsigned)((n_envs + WAVES_PER_WG - 1) / WAVES_PER_WG);
+  nb = (nb + 7u) & ~7u;
+  return dim3(nb);
+}
+
+extern "C" int arcle_reset(arcle_env* e, const uint8_t* mask, void* stream) {
+  if (!e) return ARCLE_ERR_ARG;
+  StepParams p = e->base;
+  p.rmask = mask;
+  hipLaunchKernelGGL(arcle_reset_kernel, grid_for(p.n_envs), dim3(256), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t* op, int32_t* reward, uint8_t* term,
+                       uint32_t flags, void* stream) {
+  if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
+  if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
+  StepParams p = e->base;
+  p.ingress = ingress;
+  p.sel = sel;
+  p.op = op;
+  p.reward = reward;
+  p.term = term;
+  p.flags = flags;
+  p.acct = e->d_acct;
+  p.rmask = nullptr;
+  hipLaunchKernelGGL(arcle_step_kernel, grid_for(p.n_envs), dim3(256), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
+  if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_step_mask(arcle_env* e, const int8_t* sel, const int32_t* op, int32_t* reward, uint8_t* term,
+                               uint32_t flags, void* stream) {
+  return launch_step(e, arcle::INGRESS_MASK, sel, op, reward, term, flags, stream);
+}
+extern "C" int arcle_step_bbox(arcle_env* e, const int32_t* bbox, const int32_t* op, int32_t* reward, uint8_t* term,
+                               uint32_t flags, void* stream) {
+  return launch_step(e, arcle::INGRESS_BBOX, bbox, op, reward, term, flags, stream);
+}
+extern "C" int arcle_step_point(arcle_env* e, const int32_t* xy, const int32_t* op, int32_t* reward, uint8_t* term,
+                                uint32_t flags, void* stream) {
+  return launch_step(e, arcle::INGRESS_POINT, xy, op, reward, term, flags, stream);
+}
+
+extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void* stream) {
+  if (!e || !status) return ARCLE_ERR_ARG;
+  HIP_TRY(e, hipMemcpyAsync(status, e->d_status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (clear) HIP_TRY(e, hipMemsetAsync(e->d_status, 0, 4, (hipStream_t)stream));
+  HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (on && !e->d_acct) {
+    HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 4));
+    HIP_TRY(e, hipMemset(e->d_acct, 0, (size_t)e->cfg.n_envs * 4));
+    e->acct_steps = 0;
+  } else if (!on && e->d_acct) {
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipFree(e->d_acct));
+    e->d_acct = nullptr;
+  }
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_get_accounting(arcle_env* e, uint64_t* bytes, uint64_t* steps, int clear, void* stream) {
+  if (!e || !bytes || !steps) return ARCLE_ERR_ARG;
+  if (!e->d_acct) return fail(e, ARCLE_ERR_CONFIG, "accounting is not enabled");
+  const size_t n = (size_t)e->cfg.n_envs;
+  uint32_t* h = (uint32_t*)malloc(n * 4);
+  if (!h) return ARCLE_ERR_ARG;
+  hipError_t err = hipMemcpyAsync(h, e->d_acct, n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (err == hipSuccess && clear) err = hipMemsetAsync(e->d_acct, 0, n * 4, (hipStream_t)stream);
+  if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+  if (err != hipSuccess) {
+    free(h);
+    snprintf(e->err, sizeof(e->err), "accounting copy failed: %s", hipGetErrorString(err));
+    return ARCLE_ERR_HIP;
+  }
+  uint64_t tot = 0;
+  for (size_t i = 0; i < n; i++) tot += h[i];
+  free(h);
+  *bytes = tot;
+  *steps = e->acct_steps;
+  if (clear) e->acct_steps = 0;
+  return ARCLE_OK;
+}

@@ -1,0 +1,181 @@
+"""Device-resident state of a batch of ARCLE envs + the calls into libarcle_hip.so.
+
+`EnvBatch` owns the HBM buffers (torch tensors: plumbing for device memory and streams only) in the
+layout include/arcle_hip.h declares and hands their raw pointers to the C ABI.  All stepping happens
+in the HIP kernels; this file contains no grid arithmetic.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ArcleHipError
+
+PLANES = ["input", "grid", "selected", "clip", "object", "object_sel", "background", "answer"]
+PLANE_ID = {k: i for i, k in enumerate(PLANES)}
+REC_FIELDS = {  # name -> (byte offset, length) inside the 16-byte per-env record
+    "input_dim": (0, 2), "grid_dim": (2, 2), "clip_dim": (4, 2), "object_dim": (6, 2), "object_pos": (8, 2),
+    "trials_remain": (10, 1), "terminated": (11, 1), "active": (12, 1), "rotation_parity": (13, 1),
+    "answer_dim": (14, 2),
+}
+KIND_PLANES = {  # which planes each env kind's state dict holds (o2arcenv.py:16-34, arcenv.py:81-89)
+    "o2arc": PLANES,
+    "arc": ["input", "grid", "clip", "answer"],
+    "raw": ["input", "grid", "answer"],
+}
+STEP_AUTORESET = 1
+ST_BAD_OP, ST_ROTATE_DOMAIN = 1, 2
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+class EnvBatch:
+    """n_envs envs of one kind on one GPU."""
+
+    def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None):
+        if not torch.cuda.is_available():
+            raise ArcleHipError("no HIP device visible (torch.cuda.is_available() is False); "
+                                "arcle_amd has no CPU fallback")
+        self.L = _lib.lib()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.N, self.H, self.W, self.P = int(n_envs), int(H), int(W), int(H) * int(W)
+        self.PS = (self.P + 15) & ~15  # plane stride: one aligned dwordx4 per lane
+        self.max_trial, self.kind = int(max_trial), kind
+        # 16 B alignment of every plane/record row comes from torch's >=256 B allocation alignment
+        self.planes = {k: torch.zeros((self.N, self.PS), dtype=torch.int8, device=self.device)
+                       for k in KIND_PLANES[kind]}
+        self.rec = torch.zeros((self.N, 16), dtype=torch.int8, device=self.device)
+        self.cnt = torch.zeros((self.N, 2), dtype=torch.int32, device=self.device)
+        self.reward = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+        self.term = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+        cfg = _lib.Config(self.N, self.H, self.W, self.max_trial, self.device.index or 0)
+        bufs = _lib.Buffers()
+        for k, i in PLANE_ID.items():
+            bufs.plane[i] = self.planes[k].data_ptr() if k in self.planes else None
+        bufs.rec = self.rec.data_ptr()
+        bufs.cnt = self.cnt.data_ptr()
+        h = ctypes.c_void_p()
+        rc = self.L.arcle_create(ctypes.byref(cfg), ctypes.byref(bufs), ctypes.byref(h))
+        if rc != 0:
+            raise ArcleHipError(f"arcle_create failed with status {rc}")
+        self._h = h
+        self.n_ops = 0
+        self._reward_ptr, self._term_ptr = self.reward.data_ptr(), self.term.data_ptr()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.L.arcle_destroy(h)
+            self._h = None
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.L.arcle_last_error(self._h)
+            raise ArcleHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def plane(self, name):
+        """Zero-copy [N,H,W] int8 view of a state plane (row stride PS)."""
+        return self.planes[name][:, :self.P].view(self.N, self.H, self.W)
+
+    def field(self, name):
+        """Zero-copy [N,len] int8 view of a scalar field of the per-env record."""
+        off, n = REC_FIELDS[name]
+        return self.rec[:, off:off + n]
+
+    # ---- configuration ------------------------------------------------------------------------
+    def set_op_table(self, descs):
+        arr = (ctypes.c_uint32 * len(descs))(*[int(d) for d in descs])
+        self._check(self.L.arcle_set_op_table(self._h, arr, len(descs)), "arcle_set_op_table")
+        self.n_ops = len(descs)
+
+    def set_tasks(self, inputs, answers, env_ids=None):
+        """Uploads tasks.  inputs/answers: sequences of un-padded 2-D int8 arrays (what Loader.pick yields)."""
+        ids = range(self.N) if env_ids is None else list(env_ids)
+        n = len(ids)
+        pin = np.zeros((n, self.PS), np.int8)
+        pan = np.zeros((n, self.PS), np.int8)
+        dims = np.zeros((n, 4), np.int8)
+        for j, (a, b) in enumerate(zip(inputs, answers)):
+            a = np.asarray(a, np.int8)
+            b = np.asarray(b, np.int8)
+            if a.shape[0] > self.H or a.shape[1] > self.W or b.shape[0] > self.H or b.shape[1] > self.W:
+                raise ValueError("task grid larger than max_grid_size")
+            pin[j, :self.P].reshape(self.H, self.W)[:a.shape[0], :a.shape[1]] = a
+            pan[j, :self.P].reshape(self.H, self.W)[:b.shape[0], :b.shape[1]] = b
+            dims[j] = (a.shape[0], a.shape[1], b.shape[0], b.shape[1])
+        idx = torch.as_tensor(list(ids), device=self.device, dtype=torch.long)
+        self.planes["input"][idx] = torch.from_numpy(pin).to(self.device)
+        self.planes["answer"][idx] = torch.from_numpy(pan).to(self.device)
+        d = torch.from_numpy(dims).to(self.device)
+        self.rec[idx, 0:2] = d[:, 0:2]
+        self.rec[idx, 14:16] = d[:, 2:4]
+
+    def set_tasks_padded(self, inp, input_dim, ans, answer_dim):
+        """Uploads already padded [N,H,W] int8 arrays + [N,2] dims (numpy or torch)."""
+        t = lambda x: (x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))).to(self.device, torch.int8)  # noqa: E731
+        self.plane("input").copy_(t(inp))
+        self.plane("answer").copy_(t(ans))
+        self.field("input_dim").copy_(t(input_dim))
+        self.field("answer_dim").copy_(t(answer_dim))
+
+    # ---- the hot path -------------------------------------------------------------------------
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        self._check(self.L.arcle_reset(self._h, _ptr(m), self._stream()), "arcle_reset")
+
+    def _step(self, fn, payload, op, flags):
+        if op.dtype != torch.int32 or not op.is_contiguous() or op.device != self.device:
+            op = op.to(device=self.device, dtype=torch.int32).contiguous()
+        self._check(fn(self._h, _ptr(payload), _ptr(op), _ptr(self.reward), _ptr(self.term), int(flags), self._stream()),
+                    "arcle_step")
+        return self.reward, self.term
+
+    def step_bbox(self, bbox, op, flags=0):
+        """bbox int32 [N,4] = (x1,y1,x2,y2) as BBoxWrapper.action (bbox.py:22-30); op int32 [N]."""
+        if bbox.dtype != torch.int32 or not bbox.is_contiguous() or bbox.device != self.device:
+            bbox = bbox.to(device=self.device, dtype=torch.int32).contiguous()
+        return self._step(self.L.arcle_step_bbox, bbox, op, flags)
+
+    def step_point(self, xy, op, flags=0):
+        if xy.dtype != torch.int32 or not xy.is_contiguous() or xy.device != self.device:
+            xy = xy.to(device=self.device, dtype=torch.int32).contiguous()
+        return self._step(self.L.arcle_step_point, xy, op, flags)
+
+    def step_mask(self, sel, op, flags=0):
+        """sel [N,H,W] int8/bool selection masks (action['selection'])."""
+        if sel.dtype == torch.bool:
+            sel = sel.to(torch.int8)
+        if sel.dtype != torch.int8 or not sel.is_contiguous() or sel.device != self.device:
+            sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
+        return self._step(self.L.arcle_step_mask, sel, op, flags)
+
+    def step_bbox_ptr(self, bbox_ptr, op_ptr, flags=0, stream=0):
+        """Lowest-overhead launch for rollout loops: raw device addresses (ints) of an int32 [N,4] bbox array
+        and an int32 [N] op array, explicit stream handle.  Outputs land in self.reward / self.term."""
+        rc = self.L.arcle_step_bbox(self._h, bbox_ptr, op_ptr, self._reward_ptr, self._term_ptr, flags, stream)
+        if rc != 0:
+            self._check(rc, "arcle_step_bbox")
+
+    # ---- status / accounting ------------------------------------------------------------------
+    def status(self, clear=True):
+        s = ctypes.c_uint32(0)
+        self._check(self.L.arcle_get_status(self._h, ctypes.byref(s), int(clear), self._stream()), "arcle_get_status")
+        return s.value
+
+    def enable_accounting(self, on=True):
+        self._check(self.L.arcle_enable_accounting(self._h, int(on)), "arcle_enable_accounting")
+
+    def accounting(self, clear=True):
+        b, s = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.L.arcle_get_accounting(self._h, ctypes.byref(b), ctypes.byref(s), int(clear), self._stream()),
+                    "arcle_get_accounting")
+        return b.value, s.value

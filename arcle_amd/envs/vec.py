@@ -1,0 +1,126 @@
+"""ARCVecEnv — N independent ARCLE envs stepped by ONE kernel launch per step (the hot path the
+throughput numbers are quoted on).  Observations are zero-copy torch views of the device state (like the
+reference, `obs` IS the live state — o2arcenv.py:147), actions are device tensors:
+
+    venv = ARCVecEnv(O2ARCv2Env, num_envs=8192, data_loader=loader, max_grid_size=(30, 30))
+    obs, info = venv.reset()
+    obs, reward, terminated, truncated, info = venv.step_bbox(bbox_i32[N,4], op_i32[N])     # BBoxWrapper form
+    obs, reward, terminated, truncated, info = venv.step_point(xy_i32[N,2], op_i32[N])      # PointWrapper form
+    obs, reward, terminated, truncated, info = venv.step({"selection": m[N,H,W], "operation": op[N]})
+"""
+import numpy as np
+import torch
+
+from .. import actions
+from ..engine import EnvBatch, STEP_AUTORESET
+
+
+class ARCVecEnv:
+    def __init__(self, env_cls, num_envs, data_loader=None, max_grid_size=(30, 30), colors=10, max_trial=None,
+                 device=None, autoreset=False, operations=None, rng=None):
+        """env_cls: RawARCEnv / ARCEnv / O2ARCv2Env or a subclass (its `create_operations` / `default_operations`
+        and KIND define the op table and the state planes).  `operations` overrides the table.
+        autoreset=True gives Gymnasium next-step autoreset semantics on device (ARCLE_STEP_AUTORESET)."""
+        self.env_cls, self.N = env_cls, int(num_envs)
+        self.H, self.W = int(max_grid_size[0]), int(max_grid_size[1])
+        self.colors = colors
+        if max_trial is None:
+            max_trial = 3 if env_cls.KIND == "arc" else -1  # the classes' defaults (arcenv.py:79, o2arcenv.py:14)
+        self.max_trial = max_trial
+        self.loader = data_loader
+        self.operations = list(operations) if operations is not None else env_cls.default_operations()
+        self.op_names = ["".join(map(str.capitalize, op.__name__.split("_"))) for op in self.operations]
+        self.batch = EnvBatch(self.N, self.H, self.W, max_trial, env_cls.KIND, device)
+        self.batch.set_op_table(actions.table_descs(self.operations))
+        self.device = self.batch.device
+        self.flags = STEP_AUTORESET if autoreset else 0
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.task_index = np.zeros(self.N, np.int64)
+        self.subprob_index = np.zeros(self.N, np.int64)
+        self._truncated = torch.zeros(self.N, dtype=torch.bool, device=self.device)
+        self._obs = self._build_obs()
+
+    # ---- observation = live device state -------------------------------------------------------------
+    def _build_obs(self):
+        b = self.batch
+        obs = {"trials_remain": b.field("trials_remain"), "terminated": b.field("terminated"),
+               "input": b.plane("input"), "input_dim": b.field("input_dim"),
+               "grid": b.plane("grid"), "grid_dim": b.field("grid_dim")}
+        if "clip" in b.planes:
+            obs["clip"] = b.plane("clip")
+            obs["clip_dim"] = b.field("clip_dim")
+        if "selected" in b.planes:
+            obs["selected"] = b.plane("selected")
+            obs["object_states"] = {
+                "active": b.field("active"), "object": b.plane("object"), "object_sel": b.plane("object_sel"),
+                "object_dim": b.field("object_dim"), "object_pos": b.field("object_pos"),
+                "background": b.plane("background"), "rotation_parity": b.field("rotation_parity")}
+        return obs
+
+    def _info(self):
+        b = self.batch
+        return {"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
+                "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1],
+                "task_index": self.task_index, "subprob_index": self.subprob_index}
+
+    # ---- reset: Loader.pick per env on the host (plugin point), init_state on device -------------------
+    def reset(self, seed=None, options=None, env_mask=None):
+        """options as base.py:87-93 (prob_index / subprob_index may be ints or per-env sequences; adaptation).
+        env_mask (bool [N], host or device) restricts the reset to some envs (they get NEW tasks)."""
+        if seed is not None:
+            self.rng = np.random.default_rng(seed)
+        options = options or {}
+        if options.get("reset_on_submit"):
+            raise NotImplementedError("reset_on_submit=True is not supported on device (SURVEY.md A.6-7)")
+        adaptation = True if options.get("adaptation") is None else bool(options.get("adaptation"))
+        ids = np.arange(self.N)
+        if env_mask is not None:
+            m = env_mask.cpu().numpy() if torch.is_tensor(env_mask) else np.asarray(env_mask)
+            ids = ids[m.astype(bool)]
+        if self.loader is None:
+            raise ValueError("ARCVecEnv needs a data_loader (or write tasks with batch.set_tasks and call batch.reset)")
+        data = self.loader.data
+        pidx = options.get("prob_index")
+        sidx = options.get("subprob_index")
+        ins, outs = [], []
+        for j, n in enumerate(ids):
+            p = int(self.rng.integers(0, len(data))) if pidx is None else int(pidx if np.isscalar(pidx) else pidx[j])
+            ex_in, ex_out, tt_in, tt_out, _ = self.loader.pick(data_index=p)
+            src_in, src_out = (ex_in, ex_out) if adaptation else (tt_in, tt_out)
+            s = int(self.rng.integers(0, len(src_in))) if sidx is None else int(sidx if np.isscalar(sidx) else sidx[j])
+            ins.append(src_in[s])
+            outs.append(src_out[s])
+            self.task_index[n], self.subprob_index[n] = p, s
+        if len(ids):
+            self.batch.set_tasks(ins, outs, env_ids=ids)
+            mask = None
+            if env_mask is not None:
+                mask = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+                mask[torch.as_tensor(ids, device=self.device)] = 1
+            self.batch.reset(mask)
+        return self._obs, self._info()
+
+    # ---- step ------------------------------------------------------------------------------------------
+    def _ret(self, reward, term):
+        return self._obs, reward, term.bool(), self._truncated, self._info()
+
+    def step_bbox(self, bbox, operation):
+        return self._ret(*self.batch.step_bbox(bbox, operation, self.flags))
+
+    def step_point(self, xy, operation):
+        return self._ret(*self.batch.step_point(xy, operation, self.flags))
+
+    def step(self, action):
+        return self._ret(*self.batch.step_mask(action["selection"], action["operation"], self.flags))
+
+    def check_errors(self):
+        """Raises if any env saw an out-of-range op / out-of-domain Rotate since the last check
+        (the reference raises IndexError / ValueError at the offending step)."""
+        st = self.batch.status()
+        if st & 1:
+            raise IndexError("an env received an operation index outside its table")
+        if st & 2:
+            raise ValueError("Rotate/Flip outside its domain (object.py:45 / int8 overflow of object_pos)")
+
+    def close(self):
+        self.batch = None

@@ -1,0 +1,375 @@
+"""Test-side adapters giving the oracle, the wave emulator and the HIP library ONE interface, plus the
+golden-fixture replayer.  Test infrastructure only.
+
+Backend interface (all arrays NumPy on the host side of the interface):
+    N, H, W, fields                       configuration / list of state field names
+    set_tasks(input, input_dim, answer, answer_dim)   padded [N,H,W] + [N,2]
+    reset(mask=None)
+    step(ingress, payload, op, flags=0) -> (reward int32[N], term uint8[N])   ingress in {'bbox','point','mask'}
+    get(field) -> np.int8 array [N,...];  counters() -> int32 [N,2];  status(clear=True) -> int
+"""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+PLANES = O.PLANES
+REC = O.REC
+
+
+# ---- checksum used by the golden fixtures (tests/golden/make_golden.py) ----------------------------
+def _splitmix_weights(n, seed=0xC0FFEE):
+    out, s = [], seed
+    M = 0xFFFFFFFFFFFFFFFF
+    for _ in range(n):
+        s = (s + 0x9E3779B97F4A7C15) & M
+        z = s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        out.append((z ^ (z >> 31)) | 1)
+    return np.array(out, np.uint64)
+
+
+_W = _splitmix_weights(1024)
+
+
+def checksum(a):
+    a = np.ascontiguousarray(a)
+    flat = a.reshape(a.shape[0], -1).view(np.uint8).astype(np.uint64) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        return (flat * _W[: flat.shape[1]]).sum(axis=1, dtype=np.uint64)
+
+
+# ---- oracle ------------------------------------------------------------------------------------------
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self, N, H, W, max_trial, kind, ops):
+        self.N, self.H, self.W, self.kind = N, H, W, kind
+        self.env = O.OracleEnv(N, H, W, max_trial, kind, ops)
+
+    def set_tasks(self, inp, idim, ans, adim):
+        self.env.planes["input"][:] = inp
+        self.env.planes["answer"][:] = ans
+        self.env.field("input_dim")[:] = idim
+        self.env.field("answer_dim")[:] = adim
+
+    def reset(self, mask=None):
+        self.env.reset(mask)
+
+    def step(self, ingress, payload, op, flags=0):
+        fn = {"bbox": self.env.step_bbox, "point": self.env.step_point, "mask": self.env.step_mask}[ingress]
+        r, t = fn(payload, op, flags)
+        return r.copy(), t.copy()
+
+    def get(self, field):
+        return (self.env.planes[field] if field in self.env.planes else self.env.field(field)).copy()
+
+    def counters(self):
+        return self.env.cnt.copy()
+
+    def status(self, clear=True):
+        return self.env.status(clear)
+
+
+# ---- wave emulator (tests/emu/wave_emu.cpp: the kernel body of arcle_wave.h run lock-step on the CPU) ----
+class _StepParams(ctypes.Structure):
+    _fields_ = [("plane", ctypes.c_void_p * 8), ("rec", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
+                ("op", ctypes.c_void_p), ("sel", ctypes.c_void_p), ("reward", ctypes.c_void_p),
+                ("term", ctypes.c_void_p), ("status", ctypes.c_void_p), ("acct", ctypes.c_void_p),
+                ("rmask", ctypes.c_void_p),
+                ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32),
+                ("ingress", ctypes.c_int32), ("flags", ctypes.c_uint32), ("div_magic", ctypes.c_uint32),
+                ("nseg", ctypes.c_int32), ("ops", ctypes.c_uint32 * 64)]
+
+
+_emu = None
+
+
+def emu_lib():
+    global _emu
+    if _emu is None:
+        d = os.path.join(ROOT, "tests", "emu")
+        so, src = os.path.join(d, "libwave_emu.so"), os.path.join(d, "wave_emu.cpp")
+        hdr = os.path.join(ROOT, "arcle_amd", "csrc", "arcle_wave.h")
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
+        _emu = ctypes.CDLL(so)
+        _emu.emu_run.argtypes = [ctypes.c_int, ctypes.POINTER(_StepParams)]
+        assert _emu.emu_params_size() == ctypes.sizeof(_StepParams), "StepParams layout drifted"
+    return _emu
+
+
+class EmuBackend:
+    name = "emu"
+    INGRESS = {"mask": 0, "bbox": 1, "point": 2}
+
+    def __init__(self, N, H, W, max_trial, kind, ops):
+        self.N, self.H, self.W, self.kind = N, H, W, kind
+        self.P = H * W
+        self.PS = (self.P + 15) & ~15
+        self.max_trial = max_trial
+        self.buf = {k: np.zeros((N, self.PS), np.int8) for k in O.KIND_PLANES[kind]}
+        self.rec = np.zeros((N, 16), np.int8)
+        self.cnt = np.zeros((N, 2), np.int32)
+        self.reward = np.zeros(N, np.int32)
+        self.term = np.zeros(N, np.uint8)
+        self.stat = np.zeros(1, np.uint32)
+        self.acct = np.zeros(N, np.uint32)
+        self.ops = list(ops)
+
+    def _params(self):
+        p = _StepParams()
+        for i, k in enumerate(PLANES):
+            p.plane[i] = self.buf[k].ctypes.data if k in self.buf else None
+        p.rec, p.cnt = self.rec.ctypes.data, self.cnt.ctypes.data
+        p.reward, p.term = self.reward.ctypes.data, self.term.ctypes.data
+        p.status, p.acct = self.stat.ctypes.data, self.acct.ctypes.data
+        p.n_envs, p.H, p.W, p.max_trial, p.n_ops = self.N, self.H, self.W, self.max_trial, len(self.ops)
+        for i, d in enumerate(self.ops):
+            p.ops[i] = d
+        return p
+
+    def plane(self, k):
+        return self.buf[k][:, :self.P].reshape(self.N, self.H, self.W)
+
+    def set_tasks(self, inp, idim, ans, adim):
+        self.buf["input"][:, :self.P] = np.asarray(inp).reshape(self.N, self.P)
+        self.buf["answer"][:, :self.P] = np.asarray(ans).reshape(self.N, self.P)
+        self.rec[:, 0:2] = idim
+        self.rec[:, 14:16] = adim
+
+    def reset(self, mask=None):
+        p = self._params()
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rmask = None if m is None else m.ctypes.data
+        rc = emu_lib().emu_run(1, ctypes.byref(p))
+        assert rc == 0, f"wave emulator reported error {rc}"
+
+    def step(self, ingress, payload, op, flags=0):
+        p = self._params()
+        if ingress == "mask":
+            pay = np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(self.N, self.P)
+        else:
+            pay = np.ascontiguousarray(payload, np.int32)
+        opa = np.ascontiguousarray(op, np.int32)
+        p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
+        rc = emu_lib().emu_run(0, ctypes.byref(p))
+        assert rc == 0, f"wave emulator reported error {rc} (divergent cross-lane op / non-uniform value)"
+        return self.reward.copy(), self.term.copy()
+
+    def get(self, field):
+        if field in self.buf:
+            return self.plane(field).copy()
+        off, n = REC[field]
+        return self.rec[:, off:off + n].copy()
+
+    def padding_is_zero(self):
+        return all(not b[:, self.P:].any() for b in self.buf.values())
+
+    def counters(self):
+        return self.cnt.copy()
+
+    def status(self, clear=True):
+        s = int(self.stat[0])
+        if clear:
+            self.stat[0] = 0
+        return s
+
+
+# ---- HIP (the product, through arcle_amd.engine -> libarcle_hip.so C ABI) ------------------------------
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, N, H, W, max_trial, kind, ops):
+        import torch
+        from arcle_amd.engine import EnvBatch
+        self.torch = torch
+        self.N, self.H, self.W, self.kind = N, H, W, kind
+        self.b = EnvBatch(N, H, W, max_trial, kind)
+        self.b.set_op_table(ops)
+
+    def set_tasks(self, inp, idim, ans, adim):
+        self.b.set_tasks_padded(inp, idim, ans, adim)
+
+    def reset(self, mask=None):
+        self.b.reset(mask)
+
+    def step(self, ingress, payload, op, flags=0):
+        t = self.torch
+        dev = self.b.device
+        opt = t.as_tensor(np.ascontiguousarray(op, np.int32), device=dev)
+        if ingress == "mask":
+            pay = t.as_tensor(np.ascontiguousarray(np.asarray(payload).astype(np.int8)), device=dev).reshape(self.N, self.H, self.W)
+            r, tm = self.b.step_mask(pay, opt, flags)
+        else:
+            pay = t.as_tensor(np.ascontiguousarray(payload, np.int32), device=dev)
+            r, tm = (self.b.step_bbox if ingress == "bbox" else self.b.step_point)(pay, opt, flags)
+        return r.cpu().numpy().copy(), tm.cpu().numpy().copy()
+
+    def get(self, field):
+        if field in self.b.planes:
+            return self.b.plane(field).cpu().numpy().copy()
+        return self.b.field(field).cpu().numpy().copy()
+
+    def padding_is_zero(self):
+        return all(not bool(p[:, self.b.P:].any()) for p in self.b.planes.values())
+
+    def counters(self):
+        return self.b.cnt.cpu().numpy().copy()
+
+    def status(self, clear=True):
+        return self.b.status(clear)
+
+
+BACKENDS = {"oracle": OracleBackend, "emu": EmuBackend, "hip": HipBackend}
+
+
+# ---- golden fixtures ------------------------------------------------------------------------------------
+def fixture_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    fx = {k: z[k] for k in z.files}
+    fx["meta"] = json.loads(str(fx["meta"]))
+    fx["fields"] = json.loads(str(fx["fields"]))
+    return fx
+
+
+def replay_fixture(backend_cls, name, max_steps=None):
+    """Replays a golden trace set on a backend; returns a list of mismatch descriptions (empty = parity)."""
+    fx = load_fixture(name)
+    m = fx["meta"]
+    N, S = m["N"], m["S"] if max_steps is None else min(m["S"], max_steps)
+    be = backend_cls(N, m["H"], m["W"], m["max_trial"], m["kind"], m["ops"])
+    be.set_tasks(fx["input"], fx["input_dim"], fx["answer"], fx["answer_dim"])
+    be.reset()
+    mask_idx = {int(s): i for i, s in enumerate(fx["mask_steps"])}
+    full_idx = {int(s): i for i, s in enumerate(fx["full_steps"])}
+    errs = []
+    for s in range(S):
+        ing = int(fx["ingress"][s])
+        if ing == 0:
+            r, t = be.step("bbox", fx["bbox"][s], fx["op"][s])
+        elif ing == 1:
+            r, t = be.step("point", fx["xy"][s], fx["op"][s])
+        else:
+            r, t = be.step("mask", fx["masks"][mask_idx[s]], fx["op"][s])
+        if not np.array_equal(r, fx["reward"][s]):
+            errs.append(f"{name} step {s}: reward {r.tolist()} != {fx['reward'][s].tolist()}")
+        if not np.array_equal(t, fx["term"][s]):
+            errs.append(f"{name} step {s}: terminated {t.tolist()} != {fx['term'][s].tolist()}")
+        cnt = be.counters()
+        if not np.array_equal(cnt[:, 0], fx["steps"][s]):
+            errs.append(f"{name} step {s}: steps counter mismatch")
+        if m["kind"] != "raw" and not np.array_equal(cnt[:, 1], fx["submit_count"][s]):
+            errs.append(f"{name} step {s}: submit_count mismatch")
+        for fi, f in enumerate(fx["fields"]):
+            got = be.get(f)
+            h = checksum(got)
+            bad = np.nonzero(h != fx["hash"][s, :, fi])[0]
+            if bad.size:
+                errs.append(f"{name} step {s} field {f}: checksum mismatch for envs {bad.tolist()} "
+                            f"(ops {fx['op'][s][bad].tolist()}, ingress {ing})")
+            if s in full_idx and not np.array_equal(got, fx["full_" + f][full_idx[s]]):
+                errs.append(f"{name} step {s} field {f}: full state mismatch")
+        if be.status():
+            errs.append(f"{name} step {s}: unexpected device status flag")
+        if len(errs) > 20:
+            break
+    if hasattr(be, "padding_is_zero") and not be.padding_is_zero():
+        errs.append(f"{name}: plane padding bytes (cells >= H*W) are not zero")
+    return errs
+
+
+# ---- random differential traces (no reference needed: backend vs oracle) ---------------------------------
+def random_trace_compare(backend_cls, kind, ops, H, W, N, S, seed, max_trial=-1, flags=0, op_weights=None,
+                         bad_ops=False):
+    """Steps `backend_cls` and the oracle side by side on seeded random tasks/actions; returns mismatches."""
+    rng = np.random.default_rng(seed)
+    be = backend_cls(N, H, W, max_trial, kind, ops)
+    orc = OracleBackend(N, H, W, max_trial, kind, ops)
+    inp = np.zeros((N, H, W), np.int8)
+    ans = np.zeros((N, H, W), np.int8)
+    idim = np.zeros((N, 2), np.int8)
+    adim = np.zeros((N, 2), np.int8)
+    for n in range(N):
+        ih, iw = rng.integers(1, H + 1), rng.integers(1, W + 1)
+        ncol = [10, 10, 2, 3][rng.integers(0, 4)]
+        g = rng.integers(0, ncol, (ih, iw)).astype(np.int8) * (rng.random((ih, iw)) < [1.0, 0.5][rng.integers(0, 2)])
+        inp[n, :ih, :iw] = g
+        idim[n] = (ih, iw)
+        if rng.random() < 0.5:
+            ans[n, :ih, :iw] = g
+            adim[n] = (ih, iw)
+        else:
+            ah, aw = rng.integers(1, H + 1), rng.integers(1, W + 1)
+            ans[n, :ah, :aw] = rng.integers(0, 10, (ah, aw))
+            adim[n] = (ah, aw)
+    for b in (be, orc):
+        b.set_tasks(inp, idim, ans, adim)
+        b.reset()
+    n_ops = len(ops)
+    w = np.ones(n_ops) if op_weights is None else np.asarray(op_weights, float)
+    w = w / w.sum()
+    errs = []
+    fields = [f for f in PLANES[:-1] if f in O.KIND_PLANES[kind]] + [
+        f for f in REC if f != "answer_dim" and (kind == "o2arc" or f in ("input_dim", "grid_dim", "trials_remain", "terminated")
+                                                  or (kind == "arc" and f == "clip_dim"))]
+    for s in range(S):
+        op = rng.choice(n_ops, size=N, p=w).astype(np.int32)
+        if bad_ops and s % 7 == 3:
+            op[rng.integers(0, N)] = n_ops + rng.integers(0, 3)
+        ing = ["bbox", "bbox", "point", "mask"][rng.integers(0, 4)]
+        if ing == "bbox":
+            pay = np.stack([rng.integers(0, H, N), rng.integers(0, W, N), rng.integers(0, H, N), rng.integers(0, W, N)], 1)
+            small = rng.random(N) < 0.5
+            pay[small, 2] = np.minimum(H - 1, pay[small, 0] + rng.integers(0, 4, small.sum()))
+            pay[small, 3] = np.minimum(W - 1, pay[small, 1] + rng.integers(0, 4, small.sum()))
+        elif ing == "point":
+            pay = np.stack([rng.integers(0, H, N), rng.integers(0, W, N)], 1)
+        else:
+            pay = np.zeros((N, H, W), np.int8)
+            for n in range(N):
+                t = rng.integers(0, 4)
+                if t == 1:
+                    pay[n] = rng.random((H, W)) < rng.random() * 0.3
+                elif t == 2:
+                    x, y = rng.integers(0, H), rng.integers(0, W)
+                    pay[n, x, y] = 1
+                elif t == 3:
+                    x, y = rng.integers(0, H), rng.integers(0, W)
+                    pay[n, x:x + rng.integers(1, 5), y:y + rng.integers(1, 5)] = 1
+        r1, t1 = be.step(ing, pay, op, flags)
+        r2, t2 = orc.step(ing, pay, op, flags)
+        tag = f"{kind} {H}x{W} seed {seed} step {s} ingress {ing}"
+        if not np.array_equal(r1, r2):
+            errs.append(f"{tag}: reward mismatch envs {np.nonzero(r1 != r2)[0].tolist()}")
+        if not np.array_equal(t1, t2):
+            errs.append(f"{tag}: terminated mismatch envs {np.nonzero(t1 != t2)[0].tolist()}")
+        if not np.array_equal(be.counters(), orc.counters()):
+            errs.append(f"{tag}: counters mismatch")
+        s1, s2 = be.status(), orc.status()
+        if s1 != s2:
+            errs.append(f"{tag}: status {s1} vs oracle {s2}")
+        for f in fields:
+            a, b = be.get(f), orc.get(f)
+            if not np.array_equal(a, b):
+                bad = np.nonzero((a != b).reshape(N, -1).any(1))[0]
+                errs.append(f"{tag} field {f}: envs {bad.tolist()} ops {op[bad].tolist()}")
+        if len(errs) > 12:
+            break
+    return errs

@@ -1,0 +1,151 @@
+// wave_emu.cpp — lock-step CPU emulation of ONE 64-lane wavefront, used to run the kernel body of
+// arcle_amd/csrc/arcle_wave.h (the very same header hipcc compiles for gfx950) on the host.
+//
+// TEST INFRASTRUCTURE ONLY: it lets `pytest -m "not gpu"` check the kernel LOGIC against the oracle and
+// the golden vectors without a GPU.  It is not a backend: nothing under arcle_amd/ loads it, and the
+// product library fails loudly when the HIP device/extension is missing.
+//
+// Each lane is a ucontext fiber; every cross-lane primitive of namespace xl is a rendezvous of all 64
+// fibers.  The scheduler asserts that all lanes reach the same primitive in the same order — i.e. that
+// cross-lane traffic only happens in wave-uniform control flow (on the GPU a bpermute from an
+// exec-masked lane would silently read garbage) — and that values declared xl::uniform() really are.
+#include <ucontext.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define ARCLE_DEV inline
+
+namespace xl {
+static int cur_lane;
+static uint32_t exch[64];
+static int sync_tag[64];
+static long sync_seq[64];
+static bool finished[64];
+static ucontext_t sched_ctx, lane_ctx[64];
+static int error_flag;
+
+static void yield(int tag) {
+  int me = cur_lane;
+  sync_tag[me] = tag;
+  sync_seq[me]++;
+  swapcontext(&lane_ctx[me], &sched_ctx);
+  cur_lane = me;
+}
+ARCLE_DEV uint32_t shfl(uint32_t v, int src_lane) {
+  exch[cur_lane] = v;
+  yield(1);
+  uint32_t r = exch[src_lane & 63];
+  yield(2);
+  return r;
+}
+ARCLE_DEV unsigned long long ballot(bool b) {
+  exch[cur_lane] = b ? 1u : 0u;
+  yield(3);
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; i++) m |= (unsigned long long)(exch[i] & 1u) << i;
+  yield(4);
+  return m;
+}
+ARCLE_DEV uint32_t uniform(uint32_t v) {
+  exch[cur_lane] = v;
+  yield(5);
+  for (int i = 0; i < 64; i++)
+    if (exch[i] != v) {
+      if (!error_flag) fprintf(stderr, "wave_emu: xl::uniform() value differs across lanes (%u vs %u)\n", exch[i], v);
+      error_flag |= 2;
+    }
+  yield(6);
+  return v;
+}
+ARCLE_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3u)));
+}
+ARCLE_DEV void lds_fence() { yield(7); }
+ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+}  // namespace xl
+
+#include "../../arcle_amd/csrc/arcle_wave.h"
+
+namespace {
+const arcle::StepParams* g_p;
+arcle::WaveLDS g_lds;
+int g_env, g_kind;
+char* g_stacks;
+const size_t STACK = 256 * 1024;
+
+void lane_main(int lane) {
+  xl::cur_lane = lane;
+  if (g_kind == 0)
+    arcle::wave_step(*g_p, &g_lds, g_env, lane);
+  else
+    arcle::wave_reset(*g_p, &g_lds, g_env, lane);
+  xl::finished[lane] = true;
+  // returning resumes uc_link (the scheduler)
+}
+
+void run_wave() {
+  for (int l = 0; l < 64; l++) {
+    xl::finished[l] = false;
+    xl::sync_seq[l] = 0;
+    xl::sync_tag[l] = 0;
+    getcontext(&xl::lane_ctx[l]);
+    xl::lane_ctx[l].uc_stack.ss_sp = g_stacks + (size_t)l * STACK;
+    xl::lane_ctx[l].uc_stack.ss_size = STACK;
+    xl::lane_ctx[l].uc_link = &xl::sched_ctx;
+    makecontext(&xl::lane_ctx[l], (void (*)())lane_main, 1, l);
+  }
+  for (;;) {
+    int alive = 0;
+    for (int l = 0; l < 64; l++) {
+      if (xl::finished[l]) continue;
+      xl::cur_lane = l;
+      swapcontext(&xl::sched_ctx, &xl::lane_ctx[l]);
+      if (!xl::finished[l]) alive++;
+    }
+    if (!alive) break;
+    // all lanes that are still running must wait at the same primitive, and none may have finished
+    int tag = -1;
+    long seq = -1;
+    for (int l = 0; l < 64; l++) {
+      if (xl::finished[l]) {
+        if (!(xl::error_flag & 1)) fprintf(stderr, "wave_emu: lane %d returned while others wait at a cross-lane op (env %d)\n", l, g_env);
+        xl::error_flag |= 1;
+        continue;
+      }
+      if (tag < 0) {
+        tag = xl::sync_tag[l];
+        seq = xl::sync_seq[l];
+      } else if (tag != xl::sync_tag[l] || seq != xl::sync_seq[l]) {
+        if (!(xl::error_flag & 1)) fprintf(stderr, "wave_emu: divergent cross-lane op (lane %d tag %d vs %d, env %d)\n", l, xl::sync_tag[l], tag, g_env);
+        xl::error_flag |= 1;
+      }
+    }
+    if (xl::error_flag & 1) {  // cannot continue a diverged wave safely
+      return;
+    }
+  }
+}
+}  // namespace
+
+// kind: 0 = step, 1 = reset.  Fills derived fields (P, PS, div_magic, nseg) like arcle_create does.
+extern "C" int emu_run(int kind, arcle::StepParams* p) {
+  p->P = p->H * p->W;
+  p->PS = (p->P + 15) & ~15;
+  p->div_magic = 65536u / (uint32_t)p->W + 1u;
+  p->nseg = (p->W >= 16) ? 2 : 1 + (15 + p->W - 1) / p->W;
+  if (!g_stacks) g_stacks = (char*)malloc(64 * STACK);
+  g_p = p;
+  g_kind = kind;
+  xl::error_flag = 0;
+  for (int env = 0; env < p->n_envs; env++) {
+    g_env = env;
+    memset(&g_lds, 0xA5, sizeof g_lds);  // stale LDS must never matter
+    run_wave();
+    if (xl::error_flag & 1) return -100 - xl::error_flag;
+  }
+  return xl::error_flag ? -100 - xl::error_flag : 0;
+}
+extern "C" int emu_params_size() { return (int)sizeof(arcle::StepParams); }

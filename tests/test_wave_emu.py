@@ -1,0 +1,30 @@
+"""The kernel body (arcle_amd/csrc/arcle_wave.h — the same header hipcc compiles for gfx950) executed by the
+lock-step wavefront emulator of tests/emu, checked against the golden vectors and against the oracle.
+This validates the kernel LOGIC on the CPU (plus: cross-lane ops only in wave-uniform control flow, values
+declared uniform really are, stale LDS never matters).  The GPU parity tests proper are in test_hip_parity.py."""
+import pytest
+
+import backends as B
+from oracle import oracle as O
+
+OBJ_HEAVY = [1] * 10 + [2] * 10 + [4] * 8 + [2] * 3 + [1] * 4
+
+
+@pytest.mark.parametrize("name", B.fixture_names())
+def test_emulated_kernel_matches_golden(name):
+    errs = B.replay_fixture(B.EmuBackend, name, max_steps=96)
+    assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("H,W", [(30, 30), (10, 10), (5, 5), (3, 3), (7, 12), (12, 7), (32, 32), (1, 17), (20, 1), (16, 16)])
+def test_emulated_kernel_vs_oracle_o2arc(H, W):
+    for flags in (0, O.STEP_AUTORESET):
+        errs = B.random_trace_compare(B.EmuBackend, "o2arc", O.o2arc_ops(), H, W, N=6, S=40, seed=H * 100 + W + flags,
+                                      max_trial=3 if flags else -1, flags=flags, op_weights=OBJ_HEAVY, bad_ops=True)
+        assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("kind,ops", [("arc", O.arc_ops()), ("raw", O.raw_ops())])
+def test_emulated_kernel_vs_oracle_other_kinds(kind, ops):
+    errs = B.random_trace_compare(B.EmuBackend, kind, ops, 30, 30, N=6, S=40, seed=7, max_trial=3)
+    assert not errs, "\n".join(errs[:10])
