@@ -46,7 +46,7 @@ __device__ __forceinline__ int env_of_wave(const StepParams& p) {
   return __builtin_amdgcn_readfirstlane(env);
 }
 
-__global__ __launch_bounds__(256) void arcle_step_kernel(const StepParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void arcle_step_kernel(const StepParams p) {
   __shared__ WaveLDS lds[WAVES_PER_WG];
   const int env = env_of_wave(p);
   if (env >= p.n_envs) return;
@@ -120,7 +120,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   b.PS = (b.P + 15) & ~15;
   b.max_trial = cfg->max_trial;
   b.div_magic = 65536u / (uint32_t)cfg->W + 1u;
-  for (uint32_t n = 0; n < 2048; n++)
+  for (uint32_t n = 0; n < ARCLE_MAX_CELLS + 16; n++)  // flat cell indices the kernel divides
     if (((n * b.div_magic) >> 16) != n / (uint32_t)cfg->W) {
       delete e;
       return ARCLE_ERR_CONFIG;

@@ -46,7 +46,7 @@ struct StepParams {
   int32_t n_envs, H, W, P, PS;  // PS = plane stride in bytes (P rounded up to 16)
   int32_t n_ops, max_trial, ingress;
   uint32_t flags;
-  uint32_t div_magic;  // floor(65536/W)+1 : (n*div_magic)>>16 == n/W for n < 2048
+  uint32_t div_magic;  // floor(65536/W)+1 : (n*div_magic)>>16 == n/W for n < 1040 (checked at create)
   int32_t nseg;        // max row segments a 16-cell lane window can span
   uint32_t ops[ARCLE_MAX_OPS];
 };
@@ -57,6 +57,10 @@ typedef uint32_t U4 __attribute__((ext_vector_type(4)));
 #else
 typedef uint32_t U4 __attribute__((vector_size(16)));
 #endif
+
+struct I2 {
+  int32_t x, y;
+};
 
 struct WaveLDS {
   uint32_t a[256];  // 1024 B staging tile (bytes of one plane)
@@ -150,6 +154,11 @@ struct Wave {
   int r0, c0;        // row / col of this lane's first cell
   uint32_t valid16;  // cells of this lane that exist (flat index < P)
   bool live;         // lane holds at least one cell (lane < PS/16)
+  // 16 <= W <= 32: the lane's window covers row r0 from column c0 (k1 cells, mask lm) and then row r0+1
+  // from column 0 (mask hm); rectangle masks then cost a dozen VALU ops (rect16 fast path)
+  bool fastw;
+  int k1;
+  uint32_t lm, hm;
 
   ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, int env_, int lane_) : p(p_), lds(l), env(env_), lane(lane_) {
     uint32_t f0 = 16u * (uint32_t)lane;
@@ -158,6 +167,10 @@ struct Wave {
     int nv = imin(imax(p.P - (int)f0, 0), 16);
     valid16 = (1u << nv) - 1u;
     live = (int)f0 < p.PS;
+    fastw = p.W >= 16 && p.W <= 32;
+    k1 = imin(16, p.W - c0);
+    lm = (1u << k1) - 1u;
+    hm = 0xffffu & ~lm;
   }
 
   // ---- plane I/O: one aligned 16 B access per lane -------------------------------------------
@@ -172,6 +185,14 @@ struct Wave {
 
   // ---- 16-bit mask of this lane's cells inside rows [x1,x2] x cols [y1,y2] (inclusive) ----------
   ARCLE_DEV uint32_t rect16(int x1, int x2, int y1, int y2) const {
+    if (fastw) {
+      // column mask of the rectangle (wave-uniform, scalar ALU); empty rectangle -> 0
+      uint32_t cm = (x1 <= x2 && y1 <= y2) ? ((2u << y2) - (1u << y1)) : 0u;
+      uint32_t dx = (uint32_t)(x2 - x1);
+      uint32_t s0 = ((uint32_t)(r0 - x1) <= dx) ? ((cm >> c0) & lm) : 0u;
+      uint32_t s1 = ((uint32_t)(r0 + 1 - x1) <= dx) ? ((cm << k1) & hm) : 0u;
+      return (s0 | s1) & valid16;
+    }
     uint32_t m = 0;
     int r = r0, c = c0, k = 0;
     for (int s = 0; s < p.nseg; s++) {
@@ -257,9 +278,15 @@ ARCLE_DEV void sel_from_rect(const Wave& w, Sel& s, int x1, int x2, int y1, int 
   s.y0 = y1;
   s.y1 = y2;
   s.nz = s.pos = s.any_nz ? w.rect16(x1, x2, y1, y2) : 0u;
+}
+
+// the raw int8 selection values (`selected = sel`, keep_sel object.py:38; mask ingress keeps what it loaded)
+ARCLE_DEV U4 sel_values(const Sel& s) {
+  if (!s.is_rect) return s.vals;
   U4 e = expand16(s.nz);
 #pragma unroll
-  for (int i = 0; i < 4; i++) s.vals[i] = e[i] & 0x01010101u;
+  for (int i = 0; i < 4; i++) e[i] &= 0x01010101u;
+  return e;
 }
 
 ARCLE_DEV void ingest_selection(const Wave& w, Sel& s) {
@@ -638,12 +665,24 @@ ARCLE_DEV void wave_reset(const StepParams& p, WaveLDS* lds, int env, int lane) 
 // one step() of one env:  O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step / RawARCEnv.step
 // ------------------------------------------------------------------------------------------------
 ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
+#ifdef ARCLE_DEBUG_STAGES  // tuning builds only: early exits to attribute the fixed cost of a launch
+  const uint32_t dbg = p.flags >> 8;
+  if (dbg == 1) return;
+#endif
   Wave w(p, lds, env, lane);
   const int P = p.P, W = p.W;
   U4 rv = load_rec(p, env);
   Rec r;
   rec_unpack(rv, r);
   const int op = (int)xl::uniform((uint32_t)p.op[env]);
+  // counters are read up front (same latency window as the record) and written back in the epilogue
+  I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
+#ifdef ARCLE_DEBUG_STAGES
+  if (dbg == 2) {
+    if (lane == 0 && op == 12345 && r.gh == 77) p.reward[env] = 1;
+    return;
+  }
+#endif
 
   if ((p.flags & ARCLE_STEP_AUTORESET) && r.term != 0) {
     init_state(w);
@@ -681,6 +720,12 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   ingest_selection(w, sel);
   if (p.ingress == INGRESS_MASK) s.bytes += P;
 
+#ifdef ARCLE_DEBUG_STAGES
+  if (dbg == 3) {
+    if (lane == 0 && sel.nz == 0x12345) p.reward[env] = 1;
+    return;
+  }
+#endif
   const Rec r_before = r;
   if (oflags & ARCLE_OPF_RESET_SEL) {  // object.py:20-25
     s.selected = u4_zero();
@@ -689,11 +734,22 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     r.active = 0;
   }
   if (oflags & ARCLE_OPF_KEEP_SEL) {  // object.py:36-40
-    s.selected = sel.vals;
+    s.selected = sel_values(sel);
     if (!(s.wr & WR_SELECTED)) s.bytes += P;
     s.wr |= WR_SELECTED;
   }
 
+#ifdef ARCLE_DEBUG_STAGES
+  if (dbg == 4) goto epilogue;
+  if (dbg == 5) {
+    if (lane == 0) {
+      *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rec_pack(r);
+      p.reward[env] = 0;
+      p.term[env] = 0;
+    }
+    return;
+  }
+#endif
   switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
     case ARCLE_OP_COLOR: {  // color.py:70-74 — whole HxW plane, grid_dim ignored
       if (sel.any_nz) {
@@ -882,6 +938,9 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     return;
   }
 
+#ifdef ARCLE_DEBUG_STAGES
+epilogue:
+#endif
   // reward(): only the LAST op of the table can be rewarded (o2arcenv.py:121-128)
   int reward = 0;
   if (op == p.n_ops - 1) {
@@ -899,8 +958,9 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   if (s.wr & WR_BACKGROUND) w.store(ARCLE_PL_BACKGROUND, s.background);
   if (lane == 0) {
     *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rec_pack(r);
-    p.cnt[2 * (size_t)env + ARCLE_CNT_STEPS] += 1;  // o2arcenv.py:142
-    if (submit_inc) p.cnt[2 * (size_t)env + ARCLE_CNT_SUBMIT] += 1;
+    cnt0.x += 1;  // o2arcenv.py:142
+    cnt0.y += submit_inc;
+    *reinterpret_cast<I2*>(p.cnt + 2 * (size_t)env) = cnt0;
     p.reward[env] = reward;
     p.term[env] = (uint8_t)(r.term != 0);
     if (p.acct) p.acct[env] += s.bytes;

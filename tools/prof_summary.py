@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Summarises a rocprofv3 rocpd .db (kernel trace): per-kernel call count / avg / median / min / max duration,
+optionally in consecutive chunks of the arcle_step_kernel launches (--chunk N) for staged experiments."""
+import sqlite3
+import sys
+
+import numpy as np
+
+db = sys.argv[1]
+chunk = int(sys.argv[sys.argv.index("--chunk") + 1]) if "--chunk" in sys.argv else 0
+c = sqlite3.connect(db)
+rows = c.execute("select name, start, end from kernels order by start").fetchall()
+by = {}
+for name, s, e in rows:
+    by.setdefault(name.split("(")[0], []).append((e - s) / 1e3)
+print(f"{'kernel':60s} {'calls':>6s} {'avg_us':>8s} {'med_us':>8s} {'min_us':>8s} {'max_us':>8s} {'total_ms':>9s}")
+for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+    v = np.array(v)
+    print(f"{k[-60:]:60s} {len(v):6d} {v.mean():8.2f} {np.median(v):8.2f} {v.min():8.2f} {v.max():8.2f} {v.sum() / 1e3:9.3f}")
+if chunk:
+    v = np.array(by.get("arcle_step_kernel", []))
+    for i in range(0, len(v), chunk):
+        w = v[i:i + chunk]
+        print(f"step launches {i:5d}..{i + len(w) - 1:5d}: avg {w.mean():7.2f} us  median {np.median(w):7.2f}  min {w.min():7.2f}")
