@@ -30,6 +30,14 @@ ARCLE_DEV void lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+// LDS reads outside the workgroup's allocation return 0 and reads inside it but outside this wave's tile
+// return bytes every caller masks away, so tile indices are not clamped on the GPU
+ARCLE_DEV int lds_idx(int i, int /*n*/) { return i; }
+// pins independent loads above the first branch so that they share one latency window
+template <class V>
+ARCLE_DEV void keep(V& a, V& b, uint32_t& c, int32_t& d) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 }  // namespace xl
 
 #include "arcle_wave.h"

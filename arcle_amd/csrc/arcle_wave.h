@@ -240,7 +240,7 @@ struct Wave {
     uint32_t sh = (uint32_t)S & 3u;
     uint32_t w[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) w[j] = buf[imin(imax(base + j, 0), 255)];
+    for (int j = 0; j < 5; j++) w[j] = buf[xl::lds_idx(base + j, 256)];
     U4 r;
 #pragma unroll
     for (int j = 0; j < 4; j++) r[j] = xl::alignbyte(w[j + 1], w[j], sh);
@@ -289,14 +289,40 @@ ARCLE_DEV U4 sel_values(const Sel& s) {
   return e;
 }
 
-ARCLE_DEV void ingest_selection(const Wave& w, Sel& s) {
+// The selection payload of this env, fetched in the same latency window as the record / op / counters
+// (all four are independent of each other): bbox = 4 ints, point = 2 ints, mask = this lane's 16 cells.
+ARCLE_DEV U4 load_payload(const Wave& w) {
+  const StepParams& p = w.p;
+  U4 v = u4_zero();
+  if (p.ingress == INGRESS_BBOX) {
+    v = *reinterpret_cast<const U4*>(reinterpret_cast<const int32_t*>(p.sel) + 4 * (size_t)w.env);
+  } else if (p.ingress == INGRESS_POINT) {
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(p.sel) + 2 * (size_t)w.env;
+    v[0] = b[0];
+    v[1] = b[1];
+  } else {
+    // full mask, contiguous int8 [N][P] as the caller holds it (no 16 B alignment guarantee)
+    const int8_t* src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)w.env * p.P + 16 * w.lane;
+    if ((p.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.sel) & 3) == 0)) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (16 * w.lane + 4 * i < p.P) v[i] = *reinterpret_cast<const uint32_t*>(src + 4 * i);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (16 * w.lane + k < p.P) v[k >> 2] |= (uint32_t)(uint8_t)src[k] << (8 * (k & 3));
+    }
+  }
+  return v;
+}
+
+ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
   const StepParams& p = w.p;
   if (p.ingress == INGRESS_BBOX) {
     // BBoxWrapper.action (bbox.py:22-30): sort the corners, sel[x1:x2+1, y1:y2+1] = 1 (slices clip at H, W;
     // negative coordinates are outside the wrapper's Discrete action space and select nothing here)
-    const int32_t* b = reinterpret_cast<const int32_t*>(p.sel) + 4 * (size_t)w.env;
-    int bx1 = (int)xl::uniform((uint32_t)b[0]), by1 = (int)xl::uniform((uint32_t)b[1]);
-    int bx2 = (int)xl::uniform((uint32_t)b[2]), by2 = (int)xl::uniform((uint32_t)b[3]);
+    int bx1 = (int)xl::uniform(payload[0]), by1 = (int)xl::uniform(payload[1]);
+    int bx2 = (int)xl::uniform(payload[2]), by2 = (int)xl::uniform(payload[3]);
     int xa = imin(bx1, bx2), xb = imin(imax(bx1, bx2), p.H - 1);
     int ya = imin(by1, by2), yb = imin(imax(by1, by2), p.W - 1);
     if (xa < 0 || ya < 0) xa = xb + 1;
@@ -305,24 +331,12 @@ ARCLE_DEV void ingest_selection(const Wave& w, Sel& s) {
   }
   if (p.ingress == INGRESS_POINT) {
     // PointWrapper.action (bbox.py:43-49)
-    const int32_t* b = reinterpret_cast<const int32_t*>(p.sel) + 2 * (size_t)w.env;
-    int x = (int)xl::uniform((uint32_t)b[0]), y = (int)xl::uniform((uint32_t)b[1]);
+    int x = (int)xl::uniform(payload[0]), y = (int)xl::uniform(payload[1]);
     bool ok = x >= 0 && x < p.H && y >= 0 && y < p.W;
     sel_from_rect(w, s, x, ok ? x : x - 1, y, y);
     return;
   }
-  // full mask, contiguous int8 [N][P] as the caller holds it (no 16 B alignment guarantee)
-  const int8_t* src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)w.env * p.P + 16 * w.lane;
-  U4 v = u4_zero();
-  if ((p.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.sel) & 3) == 0)) {
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (16 * w.lane + 4 * i < p.P) v[i] = *reinterpret_cast<const uint32_t*>(src + 4 * i);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-      if (16 * w.lane + k < p.P) v[k >> 2] |= (uint32_t)(uint8_t)src[k] << (8 * (k & 3));
-  }
+  const U4 v = payload;
   s.is_rect = false;
   s.vals = v;
   s.nz = nz16(v) & w.valid16;
@@ -671,12 +685,17 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
 #endif
   Wave w(p, lds, env, lane);
   const int P = p.P, W = p.W;
-  U4 rv = load_rec(p, env);
+  // ---- one latency window: record, op index, counters and the selection payload are independent loads ----
+  U4 rv = *reinterpret_cast<const U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES);
+  uint32_t opv = (uint32_t)p.op[env];
+  I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
+  U4 payload = load_payload(w);
+  xl::keep(rv, payload, opv, cnt0.x);  // all four are in flight before the first use
+#pragma unroll
+  for (int i = 0; i < 4; i++) rv[i] = xl::uniform(rv[i]);
   Rec r;
   rec_unpack(rv, r);
-  const int op = (int)xl::uniform((uint32_t)p.op[env]);
-  // counters are read up front (same latency window as the record) and written back in the epilogue
-  I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
+  const int op = (int)xl::uniform(opv);
 #ifdef ARCLE_DEBUG_STAGES
   if (dbg == 2) {
     if (lane == 0 && op == 12345 && r.gh == 77) p.reward[env] = 1;
@@ -717,7 +736,7 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   int eq = -1;  // grid == answer, evaluated at most once (Submit and reward see the same state)
 
   Sel sel;
-  ingest_selection(w, sel);
+  ingest_selection(w, sel, payload);
   if (p.ingress == INGRESS_MASK) s.bytes += P;
 
 #ifdef ARCLE_DEBUG_STAGES
