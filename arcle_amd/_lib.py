@@ -9,7 +9,7 @@ import shutil
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libarcle_hip.so")
+LIB_PATH = os.environ.get("ARCLE_HIP_LIB") or os.path.join(_CSRC, "libarcle_hip.so")  # override: A/B kernel tuning
 SOURCES = [os.path.join(_CSRC, "arcle_hip.hip"), os.path.join(_CSRC, "arcle_wave.h"),
            os.path.join(_CSRC, "..", "..", "include", "arcle_hip.h")]
 

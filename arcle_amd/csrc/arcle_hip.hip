@@ -33,6 +33,19 @@ ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 // LDS reads outside the workgroup's allocation return 0 and reads inside it but outside this wave's tile
 // return bytes every caller masks away, so tile indices are not clamped on the GPU
 ARCLE_DEV int lds_idx(int i, int /*n*/) { return i; }
+// 16 B plane store, write-through (`sc1`): the planes written by a step are only read again by the NEXT launch,
+// and per-XCD L2s are written back at every kernel boundary anyway; writing through lets that traffic overlap
+// the kernel instead of being flushed at its end.  Measured on the C3 mix (profiles/round1_store_policy_ab.txt):
+// plain 11.46 us, nt 11.08, sc0 11.40, sc1 9.98, sc0 sc1 10.03, sc1 nt 11.80 per launch.
+// The trailing s_nop covers the ">64-bit VMEM store data" hazard: hipcc's hazard recogniser does not see into
+// inline asm and may overwrite the data VGPRs in the very next instruction (it did: parity caught it).
+#ifndef ARCLE_STORE_POLICY
+#define ARCLE_STORE_POLICY "sc1"
+#endif
+template <class V>
+ARCLE_DEV void store16(int8_t* ptr, const V& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off " ARCLE_STORE_POLICY "\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
 // pins independent loads above the first branch so that they share one latency window
 template <class V>
 ARCLE_DEV void keep(V& a, V& b, uint32_t& c, int32_t& d) {

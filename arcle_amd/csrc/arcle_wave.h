@@ -180,7 +180,7 @@ struct Wave {
     return v;
   }
   ARCLE_DEV void store(int pl, const U4& v) const {
-    if (live) *reinterpret_cast<U4*>(p.plane[pl] + (size_t)env * p.PS + 16 * lane) = v;
+    if (live) xl::store16(p.plane[pl] + (size_t)env * p.PS + 16 * lane, v);
   }
 
   // ---- 16-bit mask of this lane's cells inside rows [x1,x2] x cols [y1,y2] (inclusive) ----------
@@ -416,9 +416,11 @@ struct Planes {
 
 ARCLE_DEV void need_grid(const Wave& w, Planes& s) {
   if (!s.have_grid) {
+#ifndef ARCLE_PREFETCH_GRID
     s.grid = w.load(ARCLE_PL_GRID);
+#endif
     s.have_grid = true;
-    s.bytes += w.p.P;
+    s.bytes += w.p.P;  // algorithmic accounting: the op semantically reads the grid
   }
 }
 
@@ -690,6 +692,12 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   uint32_t opv = (uint32_t)p.op[env];
   I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
   U4 payload = load_payload(w);
+#ifdef ARCLE_PREFETCH_GRID
+  // speculative: 26 of the 35 O2ARC ops read the grid; fetching it in the first window saves one dependent
+  // HBM latency per step at the price of 1 plane of over-fetch for the ops that do not need it
+  U4 grid_pre = w.load(ARCLE_PL_GRID);
+  xl::keep(grid_pre, payload, opv, cnt0.x);
+#endif
   xl::keep(rv, payload, opv, cnt0.x);  // all four are in flight before the first use
 #pragma unroll
   for (int i = 0; i < 4; i++) rv[i] = xl::uniform(rv[i]);
@@ -730,6 +738,9 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   Planes s;
   s.wr = 0;
   s.have_grid = false;
+#ifdef ARCLE_PREFETCH_GRID
+  s.grid = grid_pre;
+#endif
   s.bytes = 2 * ARCLE_REC_BYTES + 24;  // record R/W + action in + reward/term out
   int submit_inc = 0;
   bool domain_error = false;

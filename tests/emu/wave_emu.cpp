@@ -68,6 +68,8 @@ ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 ARCLE_DEV int lds_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }  // host memory: stay inside the tile
 template <class V>
 ARCLE_DEV void keep(V&, V&, uint32_t&, int32_t&) {}
+template <class V>
+ARCLE_DEV void store16(int8_t* ptr, const V& v) { memcpy(ptr, &v, 16); }
 }  // namespace xl
 
 #include "../../arcle_amd/csrc/arcle_wave.h"
