@@ -58,7 +58,10 @@ ARCLE_DEV void keep(V& a, V& b, uint32_t& c, int32_t& d) {
 using arcle::StepParams;
 using arcle::WaveLDS;
 
-static constexpr int WAVES_PER_WG = 4;
+#ifndef ARCLE_WAVES_PER_WG
+#define ARCLE_WAVES_PER_WG 4
+#endif
+static constexpr int WAVES_PER_WG = ARCLE_WAVES_PER_WG;
 
 __device__ __forceinline__ int env_of_wave(const StepParams& p) {
   const uint32_t nb = gridDim.x, b = blockIdx.x;          // nb is a multiple of 8
@@ -67,14 +70,16 @@ __device__ __forceinline__ int env_of_wave(const StepParams& p) {
   return __builtin_amdgcn_readfirstlane(env);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void arcle_step_kernel(const StepParams p) {
+// ING: selection ingress form; FW: 1 = launched only for 16 <= W <= 32 (fast rectangle masks), 0 = any W
+template <int ING, int FW>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(80))) void arcle_step_kernel(const StepParams p) {
   __shared__ WaveLDS lds[WAVES_PER_WG];
   const int env = env_of_wave(p);
   if (env >= p.n_envs) return;
-  arcle::wave_step(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_step<ING, FW>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
 }
 
-__global__ __launch_bounds__(256) void arcle_reset_kernel(const StepParams p) {
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const StepParams p) {
   __shared__ WaveLDS lds[WAVES_PER_WG];
   const int env = env_of_wave(p);
   if (env >= p.n_envs) return;
@@ -118,7 +123,8 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   if (!cfg || !out) return ARCLE_ERR_ARG;
   *out = nullptr;
   if (cfg->n_envs <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->H > 127 || cfg->W > 127 ||
-      cfg->H * cfg->W > ARCLE_MAX_CELLS || cfg->max_trial < -128 || cfg->max_trial > 127)
+      cfg->H * cfg->W > ARCLE_MAX_CELLS || cfg->max_trial < -128 || cfg->max_trial > 127 ||
+      (uint64_t)cfg->n_envs * (uint64_t)((cfg->H * cfg->W + 15) & ~15) >= (1ull << 32))  // 32-bit plane offsets
     return ARCLE_ERR_CONFIG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ARCLE_ERR_NO_DEVICE;
@@ -250,7 +256,7 @@ extern "C" int arcle_reset(arcle_env* e, const uint8_t* mask, void* stream) {
   if (!e) return ARCLE_ERR_ARG;
   StepParams p = e->base;
   p.rmask = mask;
-  hipLaunchKernelGGL(arcle_reset_kernel, grid_for(p.n_envs), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(arcle_reset_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
   HIP_TRY(e, hipGetLastError());
   return ARCLE_OK;
 }
@@ -268,7 +274,23 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.flags = flags;
   p.acct = e->d_acct;
   p.rmask = nullptr;
-  hipLaunchKernelGGL(arcle_step_kernel, grid_for(p.n_envs), dim3(256), 0, (hipStream_t)stream, p);
+  const bool fw = p.W >= 16 && p.W <= 32;
+  const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
+  hipStream_t st = (hipStream_t)stream;
+#define ARCLE_LAUNCH(ING)                                                              \
+  do {                                                                                 \
+    if (fw)                                                                            \
+      hipLaunchKernelGGL((arcle_step_kernel<ING, 1>), g, b, 0, st, p);                 \
+    else                                                                               \
+      hipLaunchKernelGGL((arcle_step_kernel<ING, 0>), g, b, 0, st, p);                 \
+  } while (0)
+  if (ingress == arcle::INGRESS_BBOX)
+    ARCLE_LAUNCH(arcle::INGRESS_BBOX);
+  else if (ingress == arcle::INGRESS_POINT)
+    ARCLE_LAUNCH(arcle::INGRESS_POINT);
+  else
+    ARCLE_LAUNCH(arcle::INGRESS_MASK);
+#undef ARCLE_LAUNCH
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
   return ARCLE_OK;

@@ -159,15 +159,22 @@ struct Wave {
   bool fastw;
   int k1;
   uint32_t lm, hm;
+  int ingress;    // INGRESS_* (a compile-time constant of the kernel instantiation)
+  uint32_t poff;  // byte offset of this lane's 16 cells inside a plane: env*PS + 16*lane (< 4 GiB, checked at create)
 
-  ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, int env_, int lane_) : p(p_), lds(l), env(env_), lane(lane_) {
+  // fw: 1 = the instantiation is only launched for 16 <= W <= 32 (generic rectangle code compiled out),
+  //     0 = generic
+  ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, int env_, int lane_, int ingress_, int fw)
+      : p(p_), lds(l), env(env_), lane(lane_) {
+    ingress = ingress_;
+    poff = (uint32_t)env * (uint32_t)p.PS + 16u * (uint32_t)lane;
     uint32_t f0 = 16u * (uint32_t)lane;
     r0 = (int)((f0 * p.div_magic) >> 16);
     c0 = (int)f0 - r0 * p.W;
     int nv = imin(imax(p.P - (int)f0, 0), 16);
     valid16 = (1u << nv) - 1u;
     live = (int)f0 < p.PS;
-    fastw = p.W >= 16 && p.W <= 32;
+    fastw = fw != 0;
     k1 = imin(16, p.W - c0);
     lm = (1u << k1) - 1u;
     hm = 0xffffu & ~lm;
@@ -176,11 +183,11 @@ struct Wave {
   // ---- plane I/O: one aligned 16 B access per lane -------------------------------------------
   ARCLE_DEV U4 load(int pl) const {
     U4 v = u4_zero();
-    if (live) v = *reinterpret_cast<const U4*>(p.plane[pl] + (size_t)env * p.PS + 16 * lane);
+    if (live) v = *reinterpret_cast<const U4*>(p.plane[pl] + poff);
     return v;
   }
   ARCLE_DEV void store(int pl, const U4& v) const {
-    if (live) xl::store16(p.plane[pl] + (size_t)env * p.PS + 16 * lane, v);
+    if (live) xl::store16(p.plane[pl] + poff, v);
   }
 
   // ---- 16-bit mask of this lane's cells inside rows [x1,x2] x cols [y1,y2] (inclusive) ----------
@@ -294,9 +301,9 @@ ARCLE_DEV U4 sel_values(const Sel& s) {
 ARCLE_DEV U4 load_payload(const Wave& w) {
   const StepParams& p = w.p;
   U4 v = u4_zero();
-  if (p.ingress == INGRESS_BBOX) {
+  if (w.ingress == INGRESS_BBOX) {
     v = *reinterpret_cast<const U4*>(reinterpret_cast<const int32_t*>(p.sel) + 4 * (size_t)w.env);
-  } else if (p.ingress == INGRESS_POINT) {
+  } else if (w.ingress == INGRESS_POINT) {
     const uint32_t* b = reinterpret_cast<const uint32_t*>(p.sel) + 2 * (size_t)w.env;
     v[0] = b[0];
     v[1] = b[1];
@@ -318,7 +325,7 @@ ARCLE_DEV U4 load_payload(const Wave& w) {
 
 ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
   const StepParams& p = w.p;
-  if (p.ingress == INGRESS_BBOX) {
+  if (w.ingress == INGRESS_BBOX) {
     // BBoxWrapper.action (bbox.py:22-30): sort the corners, sel[x1:x2+1, y1:y2+1] = 1 (slices clip at H, W;
     // negative coordinates are outside the wrapper's Discrete action space and select nothing here)
     int bx1 = (int)xl::uniform(payload[0]), by1 = (int)xl::uniform(payload[1]);
@@ -329,7 +336,7 @@ ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
     sel_from_rect(w, s, xa, xb, ya, yb);
     return;
   }
-  if (p.ingress == INGRESS_POINT) {
+  if (w.ingress == INGRESS_POINT) {
     // PointWrapper.action (bbox.py:43-49)
     int x = (int)xl::uniform(payload[0]), y = (int)xl::uniform(payload[1]);
     bool ok = x >= 0 && x < p.H && y >= 0 && y < p.W;
@@ -673,19 +680,20 @@ ARCLE_DEV void init_state(const Wave& w) {
 
 ARCLE_DEV void wave_reset(const StepParams& p, WaveLDS* lds, int env, int lane) {
   if (p.rmask && !p.rmask[env]) return;
-  Wave w(p, lds, env, lane);
+  Wave w(p, lds, env, lane, INGRESS_BBOX, 0);
   init_state(w);
 }
 
 // ------------------------------------------------------------------------------------------------
 // one step() of one env:  O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step / RawARCEnv.step
 // ------------------------------------------------------------------------------------------------
+template <int ING, int FW>
 ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
 #ifdef ARCLE_DEBUG_STAGES  // tuning builds only: early exits to attribute the fixed cost of a launch
   const uint32_t dbg = p.flags >> 8;
   if (dbg == 1) return;
 #endif
-  Wave w(p, lds, env, lane);
+  Wave w(p, lds, env, lane, ING, FW);
   const int P = p.P, W = p.W;
   // ---- one latency window: record, op index, counters and the selection payload are independent loads ----
   U4 rv = *reinterpret_cast<const U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES);
@@ -748,7 +756,7 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
 
   Sel sel;
   ingest_selection(w, sel, payload);
-  if (p.ingress == INGRESS_MASK) s.bytes += P;
+  if (w.ingress == INGRESS_MASK) s.bytes += P;
 
 #ifdef ARCLE_DEBUG_STAGES
   if (dbg == 3) {

@@ -83,8 +83,17 @@ const size_t STACK = 256 * 1024;
 
 void lane_main(int lane) {
   xl::cur_lane = lane;
-  if (g_kind == 0)
-    arcle::wave_step(*g_p, &g_lds, g_env, lane);
+  const bool fw = g_p->W >= 16 && g_p->W <= 32;
+  if (g_kind == 0) {
+    switch (g_p->ingress * 2 + (fw ? 1 : 0)) {  // the same instantiations the HIP library launches
+      case 0: arcle::wave_step<0, 0>(*g_p, &g_lds, g_env, lane); break;
+      case 1: arcle::wave_step<0, 1>(*g_p, &g_lds, g_env, lane); break;
+      case 2: arcle::wave_step<1, 0>(*g_p, &g_lds, g_env, lane); break;
+      case 3: arcle::wave_step<1, 1>(*g_p, &g_lds, g_env, lane); break;
+      case 4: arcle::wave_step<2, 0>(*g_p, &g_lds, g_env, lane); break;
+      default: arcle::wave_step<2, 1>(*g_p, &g_lds, g_env, lane); break;
+    }
+  }
   else
     arcle::wave_reset(*g_p, &g_lds, g_env, lane);
   xl::finished[lane] = true;

@@ -18,7 +18,7 @@ for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
     v = np.array(v)
     print(f"{k[-60:]:60s} {len(v):6d} {v.mean():8.2f} {np.median(v):8.2f} {v.min():8.2f} {v.max():8.2f} {v.sum() / 1e3:9.3f}")
 if chunk:
-    v = np.array(by.get("arcle_step_kernel", []))
+    v = np.array([d for name, s, e in rows if "arcle_step_kernel" in name for d in [(e - s) / 1e3]])
     for i in range(0, len(v), chunk):
         w = v[i:i + chunk]
         print(f"step launches {i:5d}..{i + len(w) - 1:5d}: avg {w.mean():7.2f} us  median {np.median(w):7.2f}  min {w.min():7.2f}")
