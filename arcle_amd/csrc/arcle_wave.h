@@ -451,7 +451,8 @@ ARCLE_DEV bool grid_equals_answer(const Wave& w, Planes& s, const Rec& r) {
 // _apply_patch + _apply_sel (object.py:113-165).  `tile` holds the object plane staged in LDS with an
 // extra flat offset `S0` (object cell f lives at tile[f + S0]); `osel` is the object_sel cell mask in
 // the same shifted frame.  Writes grid and selected.
-ARCLE_DEV void place(const Wave& w, Planes& s, const Rec& r, const uint32_t* tile, uint32_t osel, int S0) {
+ARCLE_DEV void place(const Wave& w, Planes& s, const Rec& r, const uint32_t* tile, uint32_t osel, int S0,
+                     bool osel_full = false) {
   const int W = w.p.W;
   s.grid = s.background;
   s.selected = u4_zero();
@@ -463,7 +464,8 @@ ARCLE_DEV void place(const Wave& w, Planes& s, const Rec& r, const uint32_t* til
     U4 po = w.shifted(tile, S);
     uint32_t draw = R & pos16(po);  // where=(p>0)  object.py:138
     s.grid = u4_sel(expand16(draw), po, s.background);
-    uint32_t ps = w.shifted_bits(osel, S) & R;  // object.py:165
+    // object.py:165; when object_sel covers the whole object tile (rectangle selection) the placed mask IS R
+    uint32_t ps = osel_full ? R : (w.shifted_bits(osel, S) & R);
     U4 e = expand16(ps);
 #pragma unroll
     for (int i = 0; i < 4; i++) s.selected[i] = e[i] & 0x01010101u;
@@ -473,12 +475,43 @@ ARCLE_DEV void place(const Wave& w, Planes& s, const Rec& r, const uint32_t* til
   s.bytes += 2 * w.p.P;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// affine tile gather for 16 <= W: out cell k of this lane reads tile byte (k < k1 ? B0 : B1) + step*k
+// (the lane's window is row r0 from column c0 for k < k1, then row r0+1 from column 0).  step = +1 / -1 are
+// contiguous runs (one shifted window per segment, byte-reversed for -1); anything else is a strided gather.
+// Cells whose source lies outside the tile get unspecified bytes: callers mask with the destination rectangle.
+// ------------------------------------------------------------------------------------------------
+ARCLE_DEV U4 window_fwd(const Wave& w, const uint32_t* tile, int first) {  // bytes [first, first+16)
+  return w.shifted(tile, first - 16 * w.lane);
+}
+ARCLE_DEV U4 window_rev(const Wave& w, const uint32_t* tile, int last) {  // bytes last, last-1, ..., last-15
+  U4 f = w.shifted(tile, last - 15 - 16 * w.lane), r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r[i] = __builtin_bswap32(f[3 - i]);
+  return r;
+}
+ARCLE_DEV U4 gather_affine(const Wave& w, const uint32_t* tile, int B0, int B1, int step) {
+  U4 lmb = expand16(w.lm);  // bytes of the first row segment
+  if (step == 1) return u4_sel(lmb, window_fwd(w, tile, B0), window_fwd(w, tile, B1));
+  if (step == -1) return u4_sel(lmb, window_rev(w, tile, B0), window_rev(w, tile, B1));
+  const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
+  U4 o = u4_zero();
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int a = ((k < w.k1) ? B0 : B1) + step * k;
+    o[k >> 2] |= (uint32_t)t8[xl::lds_idx(a, 1024)] << (8 * (k & 3));
+  }
+  return o;
+}
+
 // Result of _init_objsel (object.py:60-111)
 struct Lift {
   bool ok;        // false: inactive and nothing selected -> the op is a no-op
   bool fresh;     // a new selection was lifted
   uint32_t osel;  // object_sel cell mask, in the frame of `tile` (see S0)
   int S0;         // staged object cell f is at tile[f + S0]
+  bool osel_full; // object_sel == the whole h x w object tile (selection was a rectangle)
 };
 
 // After this call lds->a holds the object bytes (shifted by S0) and s.object/object_sel/background are
@@ -496,7 +529,7 @@ ARCLE_DEV Lift init_objsel(const Wave& w, Planes& s, Rec& r, const Sel& sel) {
     int S0 = sel.x0 * W + sel.y0;
     uint32_t orect = w.rect16(0, h - 1, 0, wd - 1);
     s.object = u4_and(w.shifted(w.lds->a, S0), expand16(orect));
-    uint32_t osel_local = w.shifted_bits(sel.pos, S0) & orect;
+    uint32_t osel_local = sel.is_rect ? orect : (w.shifted_bits(sel.pos, S0) & orect);
     U4 e = expand16(osel_local);
 #pragma unroll
     for (int i = 0; i < 4; i++) s.object_sel[i] = e[i] & 0x01010101u;
@@ -513,6 +546,7 @@ ARCLE_DEV Lift init_objsel(const Wave& w, Planes& s, Rec& r, const Sel& sel) {
     L.fresh = true;
     L.osel = sel.pos;  // in the grid frame, consistent with the tile
     L.S0 = S0;
+    L.osel_full = sel.is_rect;
     return L;
   }
   if (r.active) {  // object.py:102-107
@@ -525,12 +559,14 @@ ARCLE_DEV Lift init_objsel(const Wave& w, Planes& s, Rec& r, const Sel& sel) {
     L.fresh = false;
     L.osel = nz16(s.object_sel);
     L.S0 = 0;
+    L.osel_full = false;
     return L;
   }
   L.ok = false;
   L.fresh = false;
   L.osel = 0;
   L.S0 = 0;
+  L.osel_full = false;
   return L;
 }
 
@@ -808,7 +844,7 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
       const int dy = (arg == 2) ? 1 : (arg == 3) ? -1 : 0;
       r.ox = i8w(r.ox + dx);  // :238, int8 wrap
       r.oy = i8w(r.oy + dy);
-      place(w, s, r, w.lds->a, L.osel, L.S0);
+      place(w, s, r, w.lds->a, L.osel, L.S0, L.osel_full);
       break;
     }
     case ARCLE_OP_ROTATE:
@@ -858,6 +894,54 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
         if (arg >= 2 && (wd > p.H || h > p.W)) domain_error = true;
       }
       if (domain_error) break;
+      if (w.fastw) {
+        // ---- lean path (16 <= W <= 32): the transformed tile is gathered straight from the source plane
+        //      (the grid for a fresh selection, the stored object when continuing) ------------------------
+        const bool rect_sel = fresh && sel.is_rect;
+        int S0 = 0;
+        U4 src_sel = u4_zero();
+        if (fresh) {  // _init_objsel, object.py:67-99, fused with the transform
+          need_grid(w, s);
+          U4 pm = expand16(sel.pos);
+          s.background = u4_andn(s.grid, pm);
+          w.stage(w.lds->a, rect_sel ? s.grid : u4_and(s.grid, pm));
+          if (!rect_sel) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) src_sel[i] = pm[i] & 0x01010101u;
+          }
+          S0 = xmin * W + ymin;
+          r.ox = xmin; r.oy = ymin; r.oh = h; r.ow = wd; r.active = 1; r.parity = 0;
+          s.wr |= WR_BACKGROUND;
+          s.bytes += 3 * P;
+        } else {  // object.py:102-107
+          U4 so = w.load(ARCLE_PL_OBJECT);
+          src_sel = w.load(ARCLE_PL_OBJECT_SEL);
+          s.background = w.load(ARCLE_PL_BACKGROUND);
+          s.bytes += 5 * P;
+          w.stage(w.lds->a, so);
+        }
+        if (!rect_sel) w.stage(w.lds->b, src_sel);
+        const int B0 = ai * w.r0 + bj * w.c0 + c0 + S0;
+        const int B1 = ai * (w.r0 + 1) - bj * w.k1 + c0 + S0;
+        const uint32_t orect = w.rect16(0, nh - 1, 0, nw - 1);
+        const U4 ob = expand16(orect);
+        s.object = u4_and(gather_affine(w, w.lds->a, B0, B1, bj), ob);
+        if (rect_sel) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) s.object_sel[i] = ob[i] & 0x01010101u;
+        } else {
+          s.object_sel = u4_and(gather_affine(w, w.lds->b, B0, B1, bj), ob);
+        }
+        s.wr |= WR_OBJECT | WR_OBJECT_SEL;
+        if (kind == ARCLE_OP_ROTATE && (arg & 1)) {
+          r.ox = nx; r.oy = ny; r.oh = nh; r.ow = nw; r.parity = npar;
+        }
+        w.stage(w.lds->a, s.object);
+        // Flip D0/D1 leave object_dim = (h,w) while the tile is (w,h) (:270-273): only when the two agree is the
+        // placed selection exactly the destination rectangle
+        place(w, s, r, w.lds->a, rect_sel ? orect : nz16(s.object_sel), 0, rect_sel && nh == r.oh && nw == r.ow);
+        break;
+      }
       Lift L = init_objsel(w, s, r, sel);
       tile_transform(w, s, nh, nw, ai, bj, c0);
       if (kind == ARCLE_OP_ROTATE && (arg & 1)) {

@@ -45,6 +45,16 @@ def test_hip_vs_oracle_other_kinds(kind, ops, H, W):
     assert not errs, "\n".join(errs[:10])
 
 
+@pytest.mark.parametrize("H,W", [(30, 30), (16, 16), (20, 17), (17, 20), (12, 12), (9, 32), (32, 32)])
+def test_hip_vs_oracle_exotic_ops(H, W):
+    """Rot180, Flip D0/D1, keep_sel, paste_blank=False, Crop ... (tables no shipped env installs)."""
+    from oracle import refdriver as RD
+    w = [1] * 20 + [4] * 8 + [2] * 7
+    errs = B.random_trace_compare(B.HipBackend, "o2arc", RD.variant_table("o2arc_exotic")[1], H, W, N=96, S=96,
+                                  seed=3 * H + W, op_weights=w)
+    assert not errs, "\n".join(errs[:10])
+
+
 def test_hip_floodfill_stress():
     """Config-5 style: ARCEnv table, 70 % FloodFill point seeds on few-colour grids (long frontiers)."""
     ops = O.arc_ops()

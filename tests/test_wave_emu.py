@@ -28,3 +28,17 @@ def test_emulated_kernel_vs_oracle_o2arc(H, W):
 def test_emulated_kernel_vs_oracle_other_kinds(kind, ops):
     errs = B.random_trace_compare(B.EmuBackend, kind, ops, 30, 30, N=6, S=40, seed=7, max_trial=3)
     assert not errs, "\n".join(errs[:10])
+
+
+def exotic_table():
+    """Rot180, Flip D0/D1, keep_sel, un-wrapped Color, wrapped Move, paste_blank=False, Crop — generators no shipped
+    env installs (oracle/refdriver.py::variant_table, validated against the reference by diff_vs_reference.py)."""
+    from oracle import refdriver as RD
+    return RD.variant_table("o2arc_exotic")[1]
+
+
+@pytest.mark.parametrize("H,W", [(30, 30), (16, 16), (20, 17), (17, 20), (12, 12), (9, 32)])
+def test_emulated_kernel_vs_oracle_exotic_ops(H, W):
+    w = [1] * 20 + [4] * 8 + [2] * 7
+    errs = B.random_trace_compare(B.EmuBackend, "o2arc", exotic_table(), H, W, N=6, S=48, seed=3 * H + W, op_weights=w)
+    assert not errs, "\n".join(errs[:10])
