@@ -47,6 +47,8 @@ ARCLE_DEV void store16(int8_t* ptr, const V& v) {
   asm volatile("global_store_dwordx4 %0, %1, off " ARCLE_STORE_POLICY "\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 // pins independent loads above the first branch so that they share one latency window
+ARCLE_DEV void keep1(uint32_t& a) { asm volatile("" : "+v"(a)); }
+ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 template <class V>
 ARCLE_DEV void keep(V& a, V& b, uint32_t& c, int32_t& d) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
@@ -95,6 +97,8 @@ struct arcle_env {
   bool owns_bufs;
   StepParams base;
   uint32_t* d_status;
+  uint32_t* d_ops;
+  uint32_t ops_host[ARCLE_MAX_OPS];
   uint32_t* d_acct;
   uint64_t acct_steps;
   int device;
@@ -188,7 +192,9 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
       return ARCLE_ERR_HIP;
     }
   }
-  if (hipMalloc((void**)&e->d_status, 4) != hipSuccess || hipMemset(e->d_status, 0, 4) != hipSuccess) {
+  if (hipMalloc((void**)&e->d_status, 4) != hipSuccess || hipMemset(e->d_status, 0, 4) != hipSuccess ||
+      hipMalloc((void**)&e->d_ops, sizeof(uint32_t) * ARCLE_MAX_OPS) != hipSuccess ||
+      hipMemset(e->d_ops, 0, sizeof(uint32_t) * ARCLE_MAX_OPS) != hipSuccess) {
     arcle_destroy(e);
     return ARCLE_ERR_HIP;
   }
@@ -196,6 +202,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   b.rec = e->bufs.rec;
   b.cnt = e->bufs.cnt;
   b.status = e->d_status;
+  b.d_ops = e->d_ops;
   b.n_ops = 0;
   *out = e;
   return ARCLE_OK;
@@ -210,6 +217,7 @@ extern "C" int arcle_destroy(arcle_env* e) {
     if (e->bufs.cnt) (void)hipFree(e->bufs.cnt);
   }
   if (e->d_status) (void)hipFree(e->d_status);
+  if (e->d_ops) (void)hipFree(e->d_ops);
   if (e->d_acct) (void)hipFree(e->d_acct);
   delete e;
   return ARCLE_OK;
@@ -240,8 +248,9 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
         (k == ARCLE_OP_COPY && a > 1) || (k == ARCLE_OP_PASTE && a > 1))
       return fail(e, ARCLE_ERR_CONFIG, "op argument out of range");
   }
-  memset(e->base.ops, 0, sizeof(e->base.ops));
-  memcpy(e->base.ops, descs, sizeof(uint32_t) * (size_t)n_ops);
+  memset(e->ops_host, 0, sizeof(e->ops_host));
+  memcpy(e->ops_host, descs, sizeof(uint32_t) * (size_t)n_ops);
+  HIP_TRY(e, hipMemcpy(e->d_ops, e->ops_host, sizeof(e->ops_host), hipMemcpyHostToDevice));  // synchronous
   e->base.n_ops = n_ops;
   return ARCLE_OK;
 }

@@ -48,7 +48,7 @@ struct StepParams {
   uint32_t flags;
   uint32_t div_magic;  // floor(65536/W)+1 : (n*div_magic)>>16 == n/W for n < 1040 (checked at create)
   int32_t nseg;        // max row segments a 16-cell lane window can span
-  uint32_t ops[ARCLE_MAX_OPS];
+  const uint32_t* d_ops;  // device copy of the op table, ARCLE_MAX_OPS entries (unused slots 0)
 };
 
 // 16 bytes of a plane = 4 VGPRs; a first-class vector value so that it always lives in registers
@@ -93,6 +93,16 @@ ARCLE_DEV uint32_t pos16(const U4& v) {
 #pragma unroll
   for (int i = 0; i < 4; i++) m |= flags2nib(nzflags(v[i]) & ~v[i]) << (4 * i);
   return m;
+}
+// 0xff for every byte that is > 0 as int8
+ARCLE_DEV U4 posbytes(const U4& v) {
+  U4 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t t = nzflags(v[i]) & ~v[i];  // 0x80 in qualifying bytes
+    r[i] = t | (t - (t >> 7));
+  }
+  return r;
 }
 // 4-bit nibble -> 0xff byte mask per set bit
 ARCLE_DEV uint32_t nib2bytes(uint32_t nib) {
@@ -462,11 +472,10 @@ ARCLE_DEV void place(const Wave& w, Planes& s, const Rec& r, const uint32_t* til
     uint32_t R = w.rect16(stx, edx - 1, sty, edy - 1);
     int S = S0 - (r.ox * W + r.oy);
     U4 po = w.shifted(tile, S);
-    uint32_t draw = R & pos16(po);  // where=(p>0)  object.py:138
-    s.grid = u4_sel(expand16(draw), po, s.background);
+    const U4 rb = expand16(R);
+    s.grid = u4_sel(u4_and(rb, posbytes(po)), po, s.background);  // where=(p>0)  object.py:138
     // object.py:165; when object_sel covers the whole object tile (rectangle selection) the placed mask IS R
-    uint32_t ps = osel_full ? R : (w.shifted_bits(osel, S) & R);
-    U4 e = expand16(ps);
+    const U4 e = osel_full ? rb : expand16(w.shifted_bits(osel, S) & R);
 #pragma unroll
     for (int i = 0; i < 4; i++) s.selected[i] = e[i] & 0x01010101u;
   }
@@ -524,13 +533,14 @@ ARCLE_DEV Lift init_objsel(const Wave& w, Planes& s, Rec& r, const Sel& sel) {
     need_grid(w, s);
     int h = sel.x1 - sel.x0 + 1, wd = sel.y1 - sel.y0 + 1;
     U4 pm = expand16(sel.pos);
-    U4 mg = u4_and(s.grid, pm);
-    w.stage(w.lds->a, mg);
+    // every read of the tile below is masked by a rectangle inside the selection's bbox image, so for a
+    // rectangle selection (all cells of the bbox selected) the grid itself can be staged
+    w.stage(w.lds->a, sel.is_rect ? s.grid : u4_and(s.grid, pm));
     int S0 = sel.x0 * W + sel.y0;
     uint32_t orect = w.rect16(0, h - 1, 0, wd - 1);
-    s.object = u4_and(w.shifted(w.lds->a, S0), expand16(orect));
-    uint32_t osel_local = sel.is_rect ? orect : (w.shifted_bits(sel.pos, S0) & orect);
-    U4 e = expand16(osel_local);
+    const U4 ob = expand16(orect);
+    s.object = u4_and(w.shifted(w.lds->a, S0), ob);
+    const U4 e = sel.is_rect ? ob : expand16(w.shifted_bits(sel.pos, S0) & orect);
 #pragma unroll
     for (int i = 0; i < 4; i++) s.object_sel[i] = e[i] & 0x01010101u;
     s.background = u4_andn(s.grid, pm);
@@ -736,13 +746,17 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   uint32_t opv = (uint32_t)p.op[env];
   I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
   U4 payload = load_payload(w);
+  // the op table (<= 64 descriptors): lane L fetches slot L now; the slot of this env's op is picked with a
+  // readlane once the op index has arrived — no dependent scalar load after the first window
+  uint32_t desc_vec = p.d_ops[lane];
 #ifdef ARCLE_PREFETCH_GRID
   // speculative: 26 of the 35 O2ARC ops read the grid; fetching it in the first window saves one dependent
   // HBM latency per step at the price of 1 plane of over-fetch for the ops that do not need it
   U4 grid_pre = w.load(ARCLE_PL_GRID);
   xl::keep(grid_pre, payload, opv, cnt0.x);
 #endif
-  xl::keep(rv, payload, opv, cnt0.x);  // all four are in flight before the first use
+  xl::keep(rv, payload, opv, cnt0.x);  // everything is in flight before the first use
+  xl::keep1(desc_vec);
 #pragma unroll
   for (int i = 0; i < 4; i++) rv[i] = xl::uniform(rv[i]);
   Rec r;
@@ -765,7 +779,8 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     return;
   }
   bool bad_op = op < 0 || op >= p.n_ops;
-  if (!bad_op) bad_op = ARCLE_OP_KIND(p.ops[op]) == ARCLE_OP_NONE;
+  const uint32_t desc = bad_op ? 0u : xl::readlane(desc_vec, op);
+  if (!bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
     if (lane == 0) {
@@ -775,7 +790,6 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     }
     return;
   }
-  const uint32_t desc = p.ops[op];
   const int kind = (int)ARCLE_OP_KIND(desc), arg = (int)ARCLE_OP_ARG(desc);
   const uint32_t oflags = ARCLE_OP_FLAGS(desc);
 

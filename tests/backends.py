@@ -91,7 +91,7 @@ class _StepParams(ctypes.Structure):
                 ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32),
                 ("ingress", ctypes.c_int32), ("flags", ctypes.c_uint32), ("div_magic", ctypes.c_uint32),
-                ("nseg", ctypes.c_int32), ("ops", ctypes.c_uint32 * 64)]
+                ("nseg", ctypes.c_int32), ("d_ops", ctypes.c_void_p)]
 
 
 _emu = None
@@ -137,8 +137,9 @@ class EmuBackend:
         p.reward, p.term = self.reward.ctypes.data, self.term.ctypes.data
         p.status, p.acct = self.stat.ctypes.data, self.acct.ctypes.data
         p.n_envs, p.H, p.W, p.max_trial, p.n_ops = self.N, self.H, self.W, self.max_trial, len(self.ops)
-        for i, d in enumerate(self.ops):
-            p.ops[i] = d
+        self._ops_arr = np.zeros(64, np.uint32)  # the "device" op table
+        self._ops_arr[:len(self.ops)] = self.ops
+        p.d_ops = self._ops_arr.ctypes.data
         return p
 
     def plane(self, k):

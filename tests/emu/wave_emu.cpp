@@ -66,6 +66,8 @@ ARCLE_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 ARCLE_DEV void lds_fence() { yield(7); }
 ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 ARCLE_DEV int lds_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }  // host memory: stay inside the tile
+ARCLE_DEV void keep1(uint32_t&) {}
+ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return shfl(v, lane); }
 template <class V>
 ARCLE_DEV void keep(V&, V&, uint32_t&, int32_t&) {}
 template <class V>
