@@ -746,17 +746,12 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   uint32_t opv = (uint32_t)p.op[env];
   I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
   U4 payload = load_payload(w);
-  // the op table (<= 64 descriptors): lane L fetches slot L now; the slot of this env's op is picked with a
-  // readlane once the op index has arrived — no dependent scalar load after the first window
-  uint32_t desc_vec = p.d_ops[lane];
 #ifdef ARCLE_PREFETCH_GRID
   // speculative: 26 of the 35 O2ARC ops read the grid; fetching it in the first window saves one dependent
   // HBM latency per step at the price of 1 plane of over-fetch for the ops that do not need it
-  U4 grid_pre = w.load(ARCLE_PL_GRID);
-  xl::keep(grid_pre, payload, opv, cnt0.x);
+  U4 grid_pre = w.load(ARCLE_PL_GRID);  // no wait here: first use is inside the op that needs it
 #endif
-  xl::keep(rv, payload, opv, cnt0.x);  // everything is in flight before the first use
-  xl::keep1(desc_vec);
+  xl::keep(rv, payload, opv, cnt0.x);  // all four are in flight before the first use
 #pragma unroll
   for (int i = 0; i < 4; i++) rv[i] = xl::uniform(rv[i]);
   Rec r;
@@ -779,7 +774,9 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     return;
   }
   bool bad_op = op < 0 || op >= p.n_ops;
-  const uint32_t desc = bad_op ? 0u : xl::readlane(desc_vec, op);
+  // scalar load through the constant cache (all waves read the same 256 B table: a per-lane vector fetch of it
+  // hot-spots one L2 channel — measured +0.5 us per launch)
+  const uint32_t desc = bad_op ? 0u : p.d_ops[op];
   if (!bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
