@@ -14,7 +14,8 @@ no data-path collective (weak scaling); rank 0 prints ONE JSON line.
 Besides the contract fields the line carries
   roofline      achieved algorithmic HBM bytes/s of the step kernel: bytes from the kernel's own per-env
                 accounting (planes semantically read+written by the executed op/mode + 56 B)
-                divided by the kernel's launch duration measured with HIP events around each launch;
+                divided by the kernel's average launch duration, measured with ONE HIP-event pair recorded on the
+                launch stream around the K back-to-back launches of the timed region;
   cpu_baseline  the oracle's C restatement (oracle/arcle_oracle.c, one thread) timed on this box's host on a
                 bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -61,10 +62,10 @@ def make_actions(steps, n, seed):
     return bbox, op
 
 
-def cpu_baseline(seed, budget_s=15.0):
-    """The oracle's C restatement on the host: same workload, bounded sample, one thread."""
+def _cpu_run(threads, seed, budget_s):
     from oracle import oracle as O
-    n = 2048
+    O.set_threads(threads)
+    n = 2048 if threads == 1 else 8192
     env = O.OracleEnv(n, H, W, -1, "o2arc")
     inp, idim, ans, adim = make_tasks(n, seed)
     env.planes["input"][:] = inp
@@ -82,9 +83,22 @@ def cpu_baseline(seed, budget_s=15.0):
         dt = time.perf_counter() - t0
         if dt > budget_s:
             break
-    return {"value": done / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "host_cores_available": os.cpu_count(),
-            "sample": f"{n} envs x {done // n} steps of the same C3 action stream, oracle/arcle_oracle.c, 1 thread"}
+    O.set_threads(1)
+    return done / dt, n, done // n
+
+
+def cpu_baseline(seed):
+    """The oracle's C restatement (oracle/arcle_oracle.c) on this box's host cores, same C3 workload, bounded sample:
+    `value` is ONE thread; `all_cores` is the same code with its env loop split over host threads (OpenMP)."""
+    v1, n1, s1 = _cpu_run(1, seed, 12.0)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(avail, 64))
+    vt, nt, st = _cpu_run(threads, seed, 8.0)
+    return {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} envs x {s1} steps of the same C3 action stream, oracle/arcle_oracle.c, 1 thread",
+            "host_cores_available": avail,
+            "all_cores": {"value": vt, "unit": "env-steps/s", "cores": threads,
+                          "sample": f"{nt} envs x {st} steps, same code, OpenMP over envs"}}
 
 
 def main():
@@ -100,7 +114,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ARCLE_BENCH_FORCE_DIST"):  # the env var exercises the N>1 code path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

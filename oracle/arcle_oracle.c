@@ -303,7 +303,7 @@ static int op_rotate(view* v, const int8_t* sel, int k, uint32_t* status) {
       ny = floordiv2(my2);
     }
     if (w > v->H || h > v->W || nx < -128 || nx > 127 || ny < -128 || ny > 127) {
-      *status |= ARCLE_ST_ROTATE_DOMAIN;
+      __atomic_fetch_or(status, ARCLE_ST_ROTATE_DOMAIN, __ATOMIC_RELAXED);
       return -1; /* caller restores the pre-step state */
     }
     r[ARCLE_REC_OBJECT_POS] = (int8_t)nx;
@@ -336,7 +336,7 @@ static int op_flip(view* v, const int8_t* sel, int axis, uint32_t* status) {
   if (!init_objsel(v, sel, &a, &b, &c, &e)) return 0;
   int h = r[ARCLE_REC_OBJECT_DIM], w = r[ARCLE_REC_OBJECT_DIM + 1];
   if (axis >= 2 && (w > v->H || h > v->W)) { /* D0/D1 transpose the tile: ValueError at :45 */
-    *status |= ARCLE_ST_ROTATE_DOMAIN;
+    __atomic_fetch_or(status, ARCLE_ST_ROTATE_DOMAIN, __ATOMIC_RELAXED);
     return -1;
   }
   int t = axis == 0 ? T_FLIPH : axis == 1 ? T_FLIPV : axis == 2 ? T_D0 : T_D1;
@@ -542,7 +542,7 @@ static void step_one(oracle_env* e, int n, const int8_t* sel, int op, int32_t* r
     return;
   }
   if (op < 0 || op >= e->n_ops || ARCLE_OP_KIND(e->ops[op]) == ARCLE_OP_NONE) {
-    e->status |= ARCLE_ST_BAD_OP; /* reference: IndexError / TypeError before any mutation */
+    __atomic_fetch_or(&e->status, ARCLE_ST_BAD_OP, __ATOMIC_RELAXED); /* reference: IndexError / TypeError before any mutation */
     *reward = 0;
     *term = (uint8_t)(v.rec[ARCLE_REC_TERMINATED] != 0);
     return;
@@ -584,9 +584,15 @@ static void step_one(oracle_env* e, int n, const int8_t* sel, int op, int32_t* r
   *term = (uint8_t)(v.rec[ARCLE_REC_TERMINATED] != 0);
 }
 
+/* Envs are independent, so the env loops below may be split over host threads (OpenMP, used only for the
+ * "all cores" CPU baseline; oracle_set_threads(1) — the default — keeps the plain serial loop). */
+static int g_threads = 1;
+void oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 int oracle_step_mask(oracle_env* e, const int8_t* sel, const int32_t* op, int32_t* reward, uint8_t* term,
                      uint32_t flags) {
   size_t P = (size_t)e->H * e->W;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (int n = 0; n < e->n_envs; n++) step_one(e, n, sel + n * P, op[n], &reward[n], &term[n], flags);
   return 0;
 }
@@ -594,8 +600,9 @@ int oracle_step_mask(oracle_env* e, const int8_t* sel, const int32_t* op, int32_
 /* BBoxWrapper.action, bbox.py:22-30 (non-negative coordinates; slices clip at H, W) */
 int oracle_step_bbox(oracle_env* e, const int32_t* bbox, const int32_t* op, int32_t* reward, uint8_t* term,
                      uint32_t flags) {
-  int8_t sel[ARCLE_MAX_CELLS];
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (int n = 0; n < e->n_envs; n++) {
+    int8_t sel[ARCLE_MAX_CELLS];
     int x1 = bbox[4 * n], y1 = bbox[4 * n + 1], x2 = bbox[4 * n + 2], y2 = bbox[4 * n + 3];
     if (x1 > x2) { int t = x1; x1 = x2; x2 = t; }
     if (y1 > y2) { int t = y1; y1 = y2; y2 = t; }
@@ -610,8 +617,9 @@ int oracle_step_bbox(oracle_env* e, const int32_t* bbox, const int32_t* op, int3
 /* PointWrapper.action, bbox.py:43-49 (out-of-range points select nothing) */
 int oracle_step_point(oracle_env* e, const int32_t* xy, const int32_t* op, int32_t* reward, uint8_t* term,
                       uint32_t flags) {
-  int8_t sel[ARCLE_MAX_CELLS];
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (int n = 0; n < e->n_envs; n++) {
+    int8_t sel[ARCLE_MAX_CELLS];
     int x = xy[2 * n], y = xy[2 * n + 1];
     memset(sel, 0, (size_t)e->H * e->W);
     if (x >= 0 && x < e->H && y >= 0 && y < e->W) sel[x * e->W + y] = 1;

@@ -79,7 +79,7 @@ def build(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return _LIB_PATH
-    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-o", _LIB_PATH, src])
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-Wall", "-o", _LIB_PATH, src])
     return _LIB_PATH
 
 
@@ -99,10 +99,16 @@ def lib():
         L.oracle_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_get_status.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.oracle_get_status.restype = ctypes.c_uint32
+        L.oracle_set_threads.argtypes = [ctypes.c_int]
         for name in ("oracle_step_mask", "oracle_step_bbox", "oracle_step_point"):
             getattr(L, name).argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint32]
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """Host threads used by the env loops of the step entry points (OpenMP); 1 = serial (default)."""
+    lib().oracle_set_threads(int(n))
 
 
 def _p(a):
