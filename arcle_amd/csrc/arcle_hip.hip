@@ -88,6 +88,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const St
   arcle::wave_reset(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
 }
 
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_table_kernel(const StepParams p) {
+  __shared__ WaveLDS lds[WAVES_PER_WG];
+  const int env = env_of_wave(p);
+  if (env >= p.n_envs) return;
+  arcle::wave_reset_table(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side: the C ABI
 // ------------------------------------------------------------------------------------------------
@@ -252,6 +259,33 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
   memcpy(e->ops_host, descs, sizeof(uint32_t) * (size_t)n_ops);
   HIP_TRY(e, hipMemcpy(e->d_ops, e->ops_host, sizeof(e->ops_host), hipMemcpyHostToDevice));  // synchronous
   e->base.n_ops = n_ops;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_set_task_table(arcle_env* e, const int8_t* in_planes, const int8_t* in_dims,
+                                    const int8_t* ans_planes, const int8_t* ans_dims, int32_t n_tasks) {
+  if (!e || !in_planes || !in_dims || !ans_planes || !ans_dims) return ARCLE_ERR_ARG;
+  if (n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "empty task table");
+  if ((reinterpret_cast<uintptr_t>(in_planes) & 15) || (reinterpret_cast<uintptr_t>(ans_planes) & 15))
+    return fail(e, ARCLE_ERR_ARG, "task table planes must be 16-byte aligned");
+  e->base.tbl_in = in_planes;
+  e->base.tbl_in_dim = in_dims;
+  e->base.tbl_ans = ans_planes;
+  e->base.tbl_ans_dim = ans_dims;
+  e->base.n_tasks = n_tasks;
+  return ARCLE_OK;
+}
+
+static dim3 grid_for(int n_envs);
+
+extern "C" int arcle_reset_from_table(arcle_env* e, const int32_t* task_idx, const uint8_t* mask, void* stream) {
+  if (!e || !task_idx) return ARCLE_ERR_ARG;
+  if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
+  StepParams p = e->base;
+  p.rmask = mask;
+  p.task_idx = task_idx;
+  hipLaunchKernelGGL(arcle_reset_table_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
   return ARCLE_OK;
 }
 

@@ -42,7 +42,11 @@ struct StepParams {
   uint8_t* term;
   uint32_t* status;
   uint32_t* acct;        // optional per-env algorithmic-byte accumulator
-  const uint8_t* rmask;  // reset kernel only
+  const uint8_t* rmask;  // reset kernels only
+  const int32_t* task_idx;                   // reset-from-table kernel only
+  const int8_t *tbl_in, *tbl_ans;            // task table planes [n_tasks][PS]
+  const int8_t *tbl_in_dim, *tbl_ans_dim;    // task table dims   [n_tasks][2]
+  int32_t n_tasks;
   int32_t n_envs, H, W, P, PS;  // PS = plane stride in bytes (P rounded up to 16)
   int32_t n_ops, max_trial, ingress;
   uint32_t flags;
@@ -728,6 +732,44 @@ ARCLE_DEV void wave_reset(const StepParams& p, WaveLDS* lds, int env, int lane) 
   if (p.rmask && !p.rmask[env]) return;
   Wave w(p, lds, env, lane, INGRESS_BBOX, 0);
   init_state(w);
+}
+
+// reset() with a caller-chosen task (base.py:95-108): the (input, answer) pair comes from the device task table
+ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, int env, int lane) {
+  if (p.rmask && !p.rmask[env]) return;
+  const int t = (int)xl::uniform((uint32_t)p.task_idx[env]);
+  if (t < 0 || t >= p.n_tasks) {
+    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_TASK);
+    return;
+  }
+  Wave w(p, lds, env, lane, INGRESS_BBOX, 0);
+  U4 in = u4_zero(), an = u4_zero();
+  if (w.live) {
+    in = *reinterpret_cast<const U4*>(p.tbl_in + (size_t)t * p.PS + 16 * lane);
+    an = *reinterpret_cast<const U4*>(p.tbl_ans + (size_t)t * p.PS + 16 * lane);
+  }
+  w.store(ARCLE_PL_INPUT, in);
+  w.store(ARCLE_PL_ANSWER, an);
+  w.store(ARCLE_PL_GRID, in);
+  U4 z = u4_zero();
+  if (p.plane[ARCLE_PL_SELECTED]) w.store(ARCLE_PL_SELECTED, z);
+  if (p.plane[ARCLE_PL_CLIP]) w.store(ARCLE_PL_CLIP, z);
+  if (p.plane[ARCLE_PL_OBJECT]) w.store(ARCLE_PL_OBJECT, z);
+  if (p.plane[ARCLE_PL_OBJECT_SEL]) w.store(ARCLE_PL_OBJECT_SEL, z);
+  if (p.plane[ARCLE_PL_BACKGROUND]) w.store(ARCLE_PL_BACKGROUND, z);
+  if (lane == 0) {
+    Rec r;
+    r.in_h = r.gh = p.tbl_in_dim[2 * t];
+    r.in_w = r.gw = p.tbl_in_dim[2 * t + 1];
+    r.ah = p.tbl_ans_dim[2 * t];
+    r.aw = p.tbl_ans_dim[2 * t + 1];
+    r.ch = r.cw = r.oh = r.ow = r.ox = r.oy = 0;
+    r.trials = i8w(p.max_trial);
+    r.term = r.active = r.parity = 0;
+    *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rec_pack(r);
+    p.cnt[2 * (size_t)env + ARCLE_CNT_STEPS] = 0;
+    p.cnt[2 * (size_t)env + ARCLE_CNT_SUBMIT] = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ KIND_PLANES = {  # which planes each env kind's state dict holds (o2arcenv.py:16
     "raw": ["input", "grid", "answer"],
 }
 STEP_AUTORESET = 1
-ST_BAD_OP, ST_ROTATE_DOMAIN = 1, 2
+ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK = 1, 2, 4
 
 
 def _ptr(t):
@@ -124,6 +124,35 @@ class EnvBatch:
         self.plane("answer").copy_(t(ans))
         self.field("input_dim").copy_(t(input_dim))
         self.field("answer_dim").copy_(t(answer_dim))
+
+    def set_task_table(self, inputs, answers):
+        """Packs a list of (input, answer) grid pairs (un-padded 2-D int8 arrays) into the device task table that
+        `reset_from_table` indexes.  One upload; resets afterwards move no grids over PCIe."""
+        T = len(inputs)
+        tin = np.zeros((T, self.PS), np.int8)
+        tan = np.zeros((T, self.PS), np.int8)
+        din = np.zeros((T, 2), np.int8)
+        dan = np.zeros((T, 2), np.int8)
+        for j, (a, b) in enumerate(zip(inputs, answers)):
+            a, b = np.asarray(a, np.int8), np.asarray(b, np.int8)
+            if max(a.shape[0], b.shape[0]) > self.H or max(a.shape[1], b.shape[1]) > self.W:
+                raise ValueError("task grid larger than max_grid_size")
+            tin[j, :self.P].reshape(self.H, self.W)[:a.shape[0], :a.shape[1]] = a
+            tan[j, :self.P].reshape(self.H, self.W)[:b.shape[0], :b.shape[1]] = b
+            din[j], dan[j] = a.shape, b.shape
+        self._table = [torch.from_numpy(x).to(self.device) for x in (tin, din, tan, dan)]  # keep alive
+        self._check(self.L.arcle_set_task_table(self._h, _ptr(self._table[0]), _ptr(self._table[1]), _ptr(self._table[2]),
+                                                _ptr(self._table[3]), T), "arcle_set_task_table")
+        self.n_tasks = T
+
+    def reset_from_table(self, task_idx, mask=None):
+        """task_idx: int32 [N] (device) indices into the task table; mask: optional uint8/bool [N]."""
+        if task_idx.dtype != torch.int32 or task_idx.device != self.device or not task_idx.is_contiguous():
+            task_idx = task_idx.to(device=self.device, dtype=torch.int32).contiguous()
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        self._check(self.L.arcle_reset_from_table(self._h, _ptr(task_idx), _ptr(m), self._stream()), "arcle_reset_from_table")
 
     # ---- the hot path -------------------------------------------------------------------------
     def reset(self, mask=None):

@@ -33,8 +33,13 @@ class ARCVecEnv:
         self.batch = EnvBatch(self.N, self.H, self.W, max_trial, env_cls.KIND, device)
         self.batch.set_op_table(actions.table_descs(self.operations))
         self.device = self.batch.device
-        self.flags = STEP_AUTORESET if autoreset else 0
         self.rng = rng if rng is not None else np.random.default_rng()
+        # autoreset: False | True (Gymnasium next-step autoreset of the SAME task, inside the step kernel)
+        #            | "resample" (same-step autoreset with a NEW random task from the device task table)
+        self.autoreset = autoreset
+        self.flags = STEP_AUTORESET if autoreset is True else 0
+        self._gen = torch.Generator(device=self.batch.device)
+        self._gen.manual_seed(int(self.rng.integers(0, 2**31)))
         self.task_index = np.zeros(self.N, np.int64)
         self.subprob_index = np.zeros(self.N, np.int64)
         self._truncated = torch.zeros(self.N, dtype=torch.bool, device=self.device)
@@ -63,7 +68,24 @@ class ARCVecEnv:
                 "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1],
                 "task_index": self.task_index, "subprob_index": self.subprob_index}
 
-    # ---- reset: Loader.pick per env on the host (plugin point), init_state on device -------------------
+    # ---- reset: task choice vectorised on the host (no per-env Python), grids come from the device task table ----
+    def _build_task_table(self):
+        """Flattens Loader.data (loader.py:89-113) into one device table: all demo pairs, then all test pairs;
+        per-task offsets/counts let `reset` turn (prob_index, subprob_index) into a table index."""
+        data = self.loader.data
+        ins, outs = [], []
+        self._off = {True: np.zeros(len(data), np.int64), False: np.zeros(len(data), np.int64)}
+        self._cnt = {True: np.zeros(len(data), np.int64), False: np.zeros(len(data), np.int64)}
+        for adaptation, (ii, oi) in ((True, (0, 1)), (False, (2, 3))):
+            for t, task in enumerate(data):
+                self._off[adaptation][t] = len(ins)
+                self._cnt[adaptation][t] = len(task[ii])
+                ins.extend(task[ii])
+                outs.extend(task[oi])
+        self.batch.set_task_table(ins, outs)
+        self._dev_off = {k: torch.from_numpy(v).to(self.device) for k, v in self._off.items()}
+        self._dev_cnt = {k: torch.from_numpy(v).to(self.device) for k, v in self._cnt.items()}
+
     def reset(self, seed=None, options=None, env_mask=None):
         """options as base.py:87-93 (prob_index / subprob_index may be ints or per-env sequences; adaptation).
         env_mask (bool [N], host or device) restricts the reset to some envs (they get NEW tasks)."""
@@ -73,35 +95,48 @@ class ARCVecEnv:
         if options.get("reset_on_submit"):
             raise NotImplementedError("reset_on_submit=True is not supported on device (SURVEY.md A.6-7)")
         adaptation = True if options.get("adaptation") is None else bool(options.get("adaptation"))
-        ids = np.arange(self.N)
-        if env_mask is not None:
-            m = env_mask.cpu().numpy() if torch.is_tensor(env_mask) else np.asarray(env_mask)
-            ids = ids[m.astype(bool)]
+        self.adaptation = adaptation
         if self.loader is None:
             raise ValueError("ARCVecEnv needs a data_loader (or write tasks with batch.set_tasks and call batch.reset)")
-        data = self.loader.data
-        pidx = options.get("prob_index")
-        sidx = options.get("subprob_index")
-        ins, outs = [], []
-        for j, n in enumerate(ids):
-            p = int(self.rng.integers(0, len(data))) if pidx is None else int(pidx if np.isscalar(pidx) else pidx[j])
-            ex_in, ex_out, tt_in, tt_out, _ = self.loader.pick(data_index=p)
-            src_in, src_out = (ex_in, ex_out) if adaptation else (tt_in, tt_out)
-            s = int(self.rng.integers(0, len(src_in))) if sidx is None else int(sidx if np.isscalar(sidx) else sidx[j])
-            ins.append(src_in[s])
-            outs.append(src_out[s])
-            self.task_index[n], self.subprob_index[n] = p, s
-        if len(ids):
-            self.batch.set_tasks(ins, outs, env_ids=ids)
-            mask = None
-            if env_mask is not None:
-                mask = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
-                mask[torch.as_tensor(ids, device=self.device)] = 1
-            self.batch.reset(mask)
+        if not hasattr(self, "_off"):
+            self._build_task_table()
+        n_tasks = len(self.loader.data)
+        pidx, sidx = options.get("prob_index"), options.get("subprob_index")
+        p = self.rng.integers(0, n_tasks, self.N) if pidx is None else np.broadcast_to(np.asarray(pidx, np.int64), (self.N,))
+        if ((p < 0) | (p >= n_tasks)).any():
+            raise AssertionError(f"Problem indices should be in [0, {n_tasks}).")  # loader.py:55
+        cnt = self._cnt[adaptation][p]
+        if (cnt == 0).any():
+            raise ValueError("a selected task has no pair of the requested kind")
+        s_ = (self.rng.random(self.N) * cnt).astype(np.int64) if sidx is None else np.broadcast_to(np.asarray(sidx, np.int64), (self.N,))
+        if ((s_ < 0) | (s_ >= cnt)).any():
+            raise IndexError("subprob_index out of range")
+        idx = torch.from_numpy((self._off[adaptation][p] + s_).astype(np.int32)).to(self.device)
+        mask = None
+        if env_mask is not None:
+            mask = torch.as_tensor(env_mask, device=self.device).to(torch.uint8)
+            keep = ~(mask.bool().cpu().numpy())
+            p = np.where(keep, self.task_index, p)
+            s_ = np.where(keep, self.subprob_index, s_)
+        self.task_index, self.subprob_index = np.asarray(p).copy(), np.asarray(s_).copy()
+        self.batch.reset_from_table(idx, mask)
         return self._obs, self._info()
+
+    def _resample_terminated(self, term):
+        """autoreset='resample': envs that just terminated get a NEW random task, entirely on device."""
+        ad = getattr(self, "adaptation", True)
+        n_tasks = len(self.loader.data)
+        p = torch.randint(0, n_tasks, (self.N,), device=self.device, generator=self._gen)
+        cnt = self._dev_cnt[ad][p]
+        s_ = (torch.rand(self.N, device=self.device, generator=self._gen) * cnt).long()
+        s_ = torch.minimum(s_, cnt - 1)
+        self.batch.reset_from_table((self._dev_off[ad][p] + s_).int(), term)
 
     # ---- step ------------------------------------------------------------------------------------------
     def _ret(self, reward, term):
+        if self.autoreset == "resample":
+            term = term.clone()  # the step outputs are overwritten by the next launch
+            self._resample_terminated(term)
         return self._obs, reward, term.bool(), self._truncated, self._info()
 
     def step_bbox(self, bbox, operation):

@@ -107,6 +107,7 @@ enum arcle_op_kind {
 /* ---- sticky device status bits (arcle_get_status) ---- */
 #define ARCLE_ST_BAD_OP 1u       /* operation index out of range / empty slot: step skipped
                                     (reference: IndexError / TypeError)                   */
+#define ARCLE_ST_BAD_TASK 4u      /* arcle_reset_from_table: task index outside the table: env left untouched */
 #define ARCLE_ST_ROTATE_DOMAIN 2u /* Rotate produced a position outside int8 or a tile that
                                     does not fit HxW (reference: ValueError/garbage,
                                     SURVEY.md A.6-2, A.6-6): step skipped                  */
@@ -151,6 +152,17 @@ int arcle_set_op_table(arcle_env* env, const uint32_t* descs, int32_t n_ops);
  * (non-zero = reset) or NULL for all envs. The task (input, answer, dims) must have been
  * written into PL_INPUT, PL_ANSWER, REC_INPUT_DIM, REC_ANSWER_DIM by the host layer. */
 int arcle_reset(arcle_env* env, const uint8_t* mask, void* stream);
+
+/* Device task table: n_tasks (input, answer) pairs, already zero-padded to the plane stride PS = H*W rounded up
+ * to 16: in_planes / ans_planes int8 [n_tasks][PS], in_dims / ans_dims int8 [n_tasks][2] (device pointers, owned
+ * by the caller, must stay alive).  It is the packed form of what Loader.parse yields (loader.py:89-113), one entry
+ * per (task, pair). */
+int arcle_set_task_table(arcle_env* env, const int8_t* in_planes, const int8_t* in_dims, const int8_t* ans_planes,
+                         const int8_t* ans_dims, int32_t n_tasks);
+/* reset() with the task choice made by the caller (base.py:95-108): for every env with mask[env] != 0 (mask NULL =
+ * all) copies table entry task_idx[env] (device int32[n_envs]) into PL_INPUT / PL_ANSWER / REC_*_DIM and runs
+ * init_state.  No host loop, no host->device copy of grids. */
+int arcle_reset_from_table(arcle_env* env, const int32_t* task_idx, const uint8_t* mask, void* stream);
 
 /* One step() of every env. Replaces O2ARCv2Env.step (o2arcenv.py:130-147).
  *   op      device int32[n_envs]       action['operation']

@@ -87,7 +87,9 @@ class _StepParams(ctypes.Structure):
     _fields_ = [("plane", ctypes.c_void_p * 8), ("rec", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
                 ("op", ctypes.c_void_p), ("sel", ctypes.c_void_p), ("reward", ctypes.c_void_p),
                 ("term", ctypes.c_void_p), ("status", ctypes.c_void_p), ("acct", ctypes.c_void_p),
-                ("rmask", ctypes.c_void_p),
+                ("rmask", ctypes.c_void_p), ("task_idx", ctypes.c_void_p), ("tbl_in", ctypes.c_void_p),
+                ("tbl_ans", ctypes.c_void_p), ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p),
+                ("n_tasks", ctypes.c_int32),
                 ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32),
                 ("ingress", ctypes.c_int32), ("flags", ctypes.c_uint32), ("div_magic", ctypes.c_uint32),
@@ -158,6 +160,26 @@ class EmuBackend:
         rc = emu_lib().emu_run(1, ctypes.byref(p))
         assert rc == 0, f"wave emulator reported error {rc}"
 
+    def set_task_table(self, inputs, answers):
+        T = len(inputs)
+        self.tbl = [np.zeros((T, self.PS), np.int8), np.zeros((T, 2), np.int8), np.zeros((T, self.PS), np.int8),
+                    np.zeros((T, 2), np.int8)]
+        for j, (a, b) in enumerate(zip(inputs, answers)):
+            self.tbl[0][j, :self.P].reshape(self.H, self.W)[:a.shape[0], :a.shape[1]] = a
+            self.tbl[2][j, :self.P].reshape(self.H, self.W)[:b.shape[0], :b.shape[1]] = b
+            self.tbl[1][j], self.tbl[3][j] = a.shape, b.shape
+
+    def reset_from_table(self, idx, mask=None):
+        p = self._params()
+        idx = np.ascontiguousarray(idx, np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rmask = None if m is None else m.ctypes.data
+        p.task_idx = idx.ctypes.data
+        p.tbl_in, p.tbl_in_dim, p.tbl_ans, p.tbl_ans_dim = [t.ctypes.data for t in self.tbl]
+        p.n_tasks = len(self.tbl[0])
+        rc = emu_lib().emu_run(2, ctypes.byref(p))
+        assert rc == 0, f"wave emulator reported error {rc}"
+
     def step(self, ingress, payload, op, flags=0):
         p = self._params()
         if ingress == "mask":
@@ -223,6 +245,14 @@ class HipBackend:
         if field in self.b.planes:
             return self.b.plane(field).cpu().numpy().copy()
         return self.b.field(field).cpu().numpy().copy()
+
+    def set_task_table(self, inputs, answers):
+        self.b.set_task_table(inputs, answers)
+
+    def reset_from_table(self, idx, mask=None):
+        t = self.torch
+        self.b.reset_from_table(t.as_tensor(np.ascontiguousarray(idx, np.int32), device=self.b.device),
+                                None if mask is None else t.as_tensor(np.ascontiguousarray(mask, np.uint8), device=self.b.device))
 
     def padding_is_zero(self):
         return all(not bool(p[:, self.b.P:].any()) for p in self.b.planes.values())
@@ -373,4 +403,51 @@ def random_trace_compare(backend_cls, kind, ops, H, W, N, S, seed, max_trial=-1,
                 errs.append(f"{tag} field {f}: envs {bad.tolist()} ops {op[bad].tolist()}")
         if len(errs) > 12:
             break
+    return errs
+
+
+def task_table_compare(backend_cls, H, W, N, T, seed):
+    """reset_from_table (device task table, per-env task index, optional mask) vs the oracle's set_tasks + reset."""
+    rng = np.random.default_rng(seed)
+    ins = [rng.integers(0, 10, (rng.integers(1, H + 1), rng.integers(1, W + 1))).astype(np.int8) for _ in range(T)]
+    outs = [rng.integers(0, 10, (rng.integers(1, H + 1), rng.integers(1, W + 1))).astype(np.int8) for _ in range(T)]
+    ops = O.o2arc_ops()
+    be = backend_cls(N, H, W, 5, "o2arc", ops)
+    orc = OracleBackend(N, H, W, 5, "o2arc", ops)
+    be.set_task_table(ins, outs)
+    idx = rng.integers(0, T, N)
+    be.reset_from_table(idx)
+    orc.env.set_tasks([ins[i] for i in idx], [outs[i] for i in idx])
+    orc.reset()
+    errs = []
+
+    def check(tag):
+        for f in PLANES + list(REC):
+            if not np.array_equal(be.get(f), orc.get(f)):
+                errs.append(f"{tag}: field {f} differs")
+        if not np.array_equal(be.counters(), orc.counters()):
+            errs.append(f"{tag}: counters differ")
+
+    check("after reset_from_table")
+    for s in range(12):  # dirty the state, then reset a masked subset onto new tasks
+        op = rng.integers(0, 35, N).astype(np.int32)
+        bb = np.stack([rng.integers(0, H, N), rng.integers(0, W, N), rng.integers(0, H, N), rng.integers(0, W, N)], 1)
+        be.step("bbox", bb, op)
+        orc.step("bbox", bb, op)
+    if be.status() != orc.status():  # (non-square grids: Rotate may flag ARCLE_ST_ROTATE_DOMAIN on both sides)
+        errs.append("status flags differ after the random steps")
+    mask = (rng.random(N) < 0.5).astype(np.uint8)
+    idx2 = rng.integers(0, T, N)
+    be.reset_from_table(idx2, mask)
+    sel = np.nonzero(mask)[0]
+    new_in = [ins[idx2[n]] if mask[n] else ins[idx[n]] for n in range(N)]
+    new_out = [outs[idx2[n]] if mask[n] else outs[idx[n]] for n in range(N)]
+    orc.env.set_tasks(new_in, new_out)
+    orc.reset(mask)
+    check("after masked reset_from_table")
+    bad = idx2.copy()
+    bad[0] = T + 3
+    be.reset_from_table(bad, np.ones(N, np.uint8))
+    if not be.status() & 4:
+        errs.append("out-of-range task index did not raise ARCLE_ST_BAD_TASK")
     return errs

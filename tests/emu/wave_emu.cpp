@@ -96,6 +96,8 @@ void lane_main(int lane) {
       default: arcle::wave_step<2, 1>(*g_p, &g_lds, g_env, lane); break;
     }
   }
+  else if (g_kind == 2)
+    arcle::wave_reset_table(*g_p, &g_lds, g_env, lane);
   else
     arcle::wave_reset(*g_p, &g_lds, g_env, lane);
   xl::finished[lane] = true;
@@ -146,7 +148,7 @@ void run_wave() {
 }
 }  // namespace
 
-// kind: 0 = step, 1 = reset.  Fills derived fields (P, PS, div_magic, nseg) like arcle_create does.
+// kind: 0 = step, 1 = reset, 2 = reset from the task table.  Fills derived fields (P, PS, div_magic, nseg) like arcle_create does.
 extern "C" int emu_run(int kind, arcle::StepParams* p) {
   p->P = p->H * p->W;
   p->PS = (p->P + 15) & ~15;

@@ -159,6 +159,47 @@ def test_properties_at_full_size():
     assert b.status() == 0
 
 
+@pytest.mark.parametrize("H,W", [(30, 30), (10, 10), (5, 7)])
+def test_hip_reset_from_task_table(H, W):
+    errs = B.task_table_compare(B.HipBackend, H, W, N=200, T=37, seed=H)
+    assert not errs, "\n".join(errs)
+
+
+def test_vec_env_reset_and_resample_autoreset():
+    """ARCVecEnv.reset goes through the device task table; autoreset='resample' gives terminated envs a new task."""
+    import torch
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    loader = SyntheticLoader(n_tasks=11, max_size=(8, 8), seed=3, p_same=1.0)
+    venv = ARCVecEnv(O2ARCv2Env, 512, loader, max_grid_size=(8, 8), max_trial=2, autoreset="resample",
+                     rng=np.random.default_rng(0))
+    obs, info = venv.reset(options={"adaptation": True})
+    # every env holds the (input, answer) pair its task_index / subprob_index names
+    for n in (0, 17, 511):
+        t, s_ = int(info["task_index"][n]), int(info["subprob_index"][n])
+        a = loader.data[t][0][s_]
+        assert tuple(obs["input_dim"][n].tolist()) == a.shape
+        assert np.array_equal(obs["input"][n, :a.shape[0], :a.shape[1]].cpu().numpy(), a)
+        assert np.array_equal(obs["grid"][n].cpu().numpy(), obs["input"][n].cpu().numpy())
+    # submit immediately: answer == input (p_same=1) -> every env terminates with reward 1 and is re-initialised
+    op = torch.full((512,), 34, dtype=torch.int32, device=venv.device)
+    box = torch.zeros((512, 4), dtype=torch.int32, device=venv.device)
+    obs, reward, term, trunc, info = venv.step_bbox(box, op)
+    assert int(reward.sum()) == 512 and bool(term.all())
+    assert int(obs["terminated"].sum()) == 0 and int(info["steps"].max()) == 0  # fresh episodes
+    assert int(obs["trials_remain"].min()) == 2
+    venv.check_errors()
+    # indexed reset of a masked subset
+    mask = torch.zeros(512, dtype=torch.bool)
+    mask[:100] = True
+    obs, info = venv.reset(options={"prob_index": 4, "subprob_index": 0, "adaptation": False}, env_mask=mask)
+    a = loader.data[4][2][0]
+    assert np.array_equal(obs["input"][5, :a.shape[0], :a.shape[1]].cpu().numpy(), a)
+    assert (info["task_index"][:100] == 4).all()
+    with pytest.raises(AssertionError):
+        venv.reset(options={"prob_index": 99})
+
+
 def test_single_env_gym_api_matches_oracle():
     """The Gymnasium-style single env (reference API: dict obs, dict action) on the GPU."""
     from arcle_amd.envs import O2ARCv2Env

@@ -42,3 +42,9 @@ def test_emulated_kernel_vs_oracle_exotic_ops(H, W):
     w = [1] * 20 + [4] * 8 + [2] * 7
     errs = B.random_trace_compare(B.EmuBackend, "o2arc", exotic_table(), H, W, N=6, S=48, seed=3 * H + W, op_weights=w)
     assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("H,W", [(30, 30), (10, 10), (5, 7)])
+def test_emulated_reset_from_task_table(H, W):
+    errs = B.task_table_compare(B.EmuBackend, H, W, N=12, T=9, seed=H)
+    assert not errs, "\n".join(errs)
