@@ -1,0 +1,123 @@
+"""Host-side logic that needs no GPU: op descriptors (names, wrappers, table validation), loaders (ARC JSON layout,
+MiniARC quirks, Loader.pick), wrappers' mask arithmetic, the gymnasium-free spaces."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from arcle_amd import actions as A
+from arcle_amd import loaders, spaces, wrappers
+from arcle_amd.envs import ARCEnv, O2ARCv2Env, RawARCEnv
+
+
+def names(ops):
+    return ["".join(map(str.capitalize, op.__name__.split("_"))) for op in ops]
+
+
+def test_op_names_match_reference_capitalisation():
+    # base.py:66 applied to the reference's __name__s
+    n = names(O2ARCv2Env.default_operations())
+    assert n[0] == "Color0" and n[13] == "Floodfill3" and n[20:24] == ["MoveU", "MoveD", "MoveR", "MoveL"]
+    assert n[24:28] == ["Rotate90", "Rotate270", "FlipH", "FlipV"]
+    assert n[28:] == ["CopyI", "CopyO", "Paste", "CopyFromInput", "ResetGrid", "ResizeGrid", "Submit"]
+    assert names(RawARCEnv.default_operations())[10:] == ["ResizeToAnswer", "Submit"]
+    assert len(ARCEnv.default_operations()) == 27 and names(ARCEnv.default_operations())[-1] == "Submit"
+
+
+def test_descriptor_encoding_and_wrappers():
+    op = A.reset_sel(A.gen_flood_fill(7))
+    assert op.desc == A.OP_FLOODFILL | (7 << 8) | (A.OPF_RESET_SEL << 16) and op.__name__ == "FloodFill7"
+    both = A.keep_sel(A.reset_sel(A.gen_color(3)))
+    assert (both.desc >> 16) == 3 and both.__name__ == "Color3"
+    assert A.gen_flip("D1").arg == 3 and A.gen_copy("O").arg == 1 and A.gen_paste(True).arg == 1
+    for bad in (lambda: A.gen_move(4), lambda: A.gen_rotate(0), lambda: A.gen_rotate(4), lambda: A.gen_flip("X"),
+                lambda: A.gen_copy("Z")):
+        with pytest.raises(AssertionError):  # the reference asserts too (object.py:175,226,261,289)
+            bad()
+    with pytest.raises(TypeError):
+        A.table_descs([A.gen_color(1), lambda s, a: None])
+    with pytest.raises(TypeError):
+        A.gen_color(1)({}, {})  # descriptors are not host callables
+
+
+def test_loader_pick_semantics(tmp_path):
+    class Two(loaders.Loader):
+        def get_path(self, **kw):
+            return ["a", "b"]
+
+        def parse(self, **kw):
+            g = lambda v: np.full((2, 2), v, np.int8)  # noqa: E731
+            return [([g(1)], [g(2)], [g(3)], [g(4)], {"id": "a"}), ([g(5)], [g(6)], [g(7)], [g(8)], {"id": "b"})]
+
+    ld = Two()
+    assert ld.pick(1)[4]["id"] == "b" and ld.pick(data_index=0)[0][0][0, 0] == 1
+    with pytest.raises(AssertionError):
+        ld.pick(2)
+    assert Two(rng=np.random.default_rng(0)).pick()[4]["id"] in ("a", "b")
+
+
+def test_arc_and_miniarc_json_layout(tmp_path):
+    root = tmp_path / "data"
+    (root / "training").mkdir(parents=True)
+    (root / "evaluation").mkdir()
+    task = {"train": [{"input": [[1, 2], [3, 4]], "output": [[4, 3], [2, 1]]}], "test": [{"input": [[0]], "output": [[9]]}]}
+    (root / "training" / "abc123.json").write_text(json.dumps(task))
+    (root / "training" / "000aaa.json").write_text(json.dumps(task))
+    ld = loaders.ARCLoader(train=True, root=str(root))
+    assert [d[4]["id"] for d in ld.data] == ["000aaa", "abc123"]  # sorted paths, loader.py:86
+    ti, to, ei, eo, _ = ld.data[0]
+    assert ti[0].dtype == np.int8 and to[0].tolist() == [[4, 3], [2, 1]] and eo[0].tolist() == [[9]]
+    assert loaders.ARCLoader(train=False, root=str(root)).data == []
+    mini = tmp_path / "mini"
+    mini.mkdir()
+    (mini / "some_description_l6abcd.json").write_text('{"train": [{"input": [[null, 1]], "output": [[1, 1]]}], "test": [{"input": [[2]], "output": [[2]]}]}')
+    m = loaders.MiniARCLoader(root=str(mini))
+    assert m.data[0][4] == {"id": "l6abcd", "description": "some description"}
+    assert m.data[0][0][0].tolist() == [[0, 1]]  # null -> "0" -> int8 0, loader.py:139
+
+
+def test_synthetic_loader_is_deterministic_and_arc_shaped():
+    a = loaders.SyntheticLoader(n_tasks=5, max_size=(9, 7), seed=4)
+    b = loaders.SyntheticLoader(n_tasks=5, max_size=(9, 7), seed=4)
+    assert len(a.data) == 5
+    for (ti, to, ei, eo, d), (ti2, *_rest) in zip(a.data, b.data):
+        assert len(ti) == len(to) == 2 and len(ei) == len(eo) == 1 and d["id"].startswith("synthetic")
+        assert all(g.dtype == np.int8 and g.shape[0] <= 9 and g.shape[1] <= 7 and g.min() >= 0 and g.max() <= 9 for g in ti + to + ei + eo)
+        assert np.array_equal(ti[0], ti2[0])
+
+
+class _FakeEnv(spaces.Env):
+    H, W = 5, 6
+    operations = list(range(12))
+
+    def step(self, action):
+        return action
+
+
+def test_wrappers_build_the_reference_masks():
+    bw = wrappers.BBoxWrapper(_FakeEnv())
+    a = bw.action((3, 4, 1, 2, 7))  # unsorted corners (bbox.py:24-29)
+    m = np.zeros((5, 6), np.int8)
+    m[1:4, 2:5] = 1
+    assert a["operation"] == 7 and a["selection"].dtype == np.int8 and np.array_equal(a["selection"], m)
+    assert bw.step((0, 0, 0, 0, 1))["selection"].sum() == 1
+    assert [s.n for s in bw.action_space.spaces] == [5, 6, 5, 6, 12]
+    pw = wrappers.PointWrapper(_FakeEnv())
+    a = pw.action((4, 5, 3))
+    assert a["selection"][4, 5] == 1 and a["selection"].sum() == 1 and [s.n for s in pw.action_space.spaces] == [5, 6, 12]
+
+
+def test_spaces_fallback_sampling():
+    if spaces.HAVE_GYMNASIUM:
+        pytest.skip("real gymnasium present")
+    d = spaces.Discrete(5)
+    d.seed(0)
+    assert all(0 <= d.sample() < 5 for _ in range(20))
+    assert d.sample(mask=np.array([0, 0, 1, 0, 0])) == 2
+    t = spaces.Tuple((spaces.Discrete(3), spaces.Discrete(4)))
+    assert len(t.sample()) == 2
+    b = spaces.Box(0, 1, (3, 3), dtype=np.int8)
+    assert b.sample().shape == (3, 3) and b.sample().dtype == np.int8
+    dd = spaces.Dict({"selection": b, "operation": d})
+    assert set(dd.sample()) == {"selection", "operation"} and dd["operation"].n == 5
