@@ -173,6 +173,10 @@ struct Wave {
   bool fastw;
   int k1;
   uint32_t lm, hm;
+  // rollout mode: the env's planes stay in registers across steps; load/store then never touch HBM
+  bool resident;
+  mutable U4 cache[ARCLE_N_PLANES];
+  mutable uint32_t dirty;  // planes of `cache` that differ from HBM
   int ingress;    // INGRESS_* (a compile-time constant of the kernel instantiation)
   uint32_t poff;  // byte offset of this lane's 16 cells inside a plane: env*PS + 16*lane (< 4 GiB, checked at create)
 
@@ -181,6 +185,8 @@ struct Wave {
   ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, int env_, int lane_, int ingress_, int fw)
       : p(p_), lds(l), env(env_), lane(lane_) {
     ingress = ingress_;
+    resident = false;
+    dirty = 0;
     poff = (uint32_t)env * (uint32_t)p.PS + 16u * (uint32_t)lane;
     uint32_t f0 = 16u * (uint32_t)lane;
     r0 = (int)((f0 * p.div_magic) >> 16);
@@ -195,13 +201,22 @@ struct Wave {
   }
 
   // ---- plane I/O: one aligned 16 B access per lane -------------------------------------------
-  ARCLE_DEV U4 load(int pl) const {
+  ARCLE_DEV U4 load_hbm(int pl) const {
     U4 v = u4_zero();
     if (live) v = *reinterpret_cast<const U4*>(p.plane[pl] + poff);
     return v;
   }
-  ARCLE_DEV void store(int pl, const U4& v) const {
+  ARCLE_DEV void store_hbm(int pl, const U4& v) const {
     if (live) xl::store16(p.plane[pl] + poff, v);
+  }
+  ARCLE_DEV U4 load(int pl) const { return resident ? cache[pl] : load_hbm(pl); }
+  ARCLE_DEV void store(int pl, const U4& v) const {
+    if (resident) {
+      cache[pl] = v;
+      dirty |= 1u << pl;
+    } else {
+      store_hbm(pl, v);
+    }
   }
 
   // ---- 16-bit mask of this lane's cells inside rows [x1,x2] x cols [y1,y2] (inclusive) ----------
@@ -437,9 +452,7 @@ struct Planes {
 
 ARCLE_DEV void need_grid(const Wave& w, Planes& s) {
   if (!s.have_grid) {
-#ifndef ARCLE_PREFETCH_GRID
     s.grid = w.load(ARCLE_PL_GRID);
-#endif
     s.have_grid = true;
     s.bytes += w.p.P;  // algorithmic accounting: the op semantically reads the grid
   }
@@ -702,7 +715,7 @@ ARCLE_DEV U4 load_rec(const StepParams& p, int env) {
 // ------------------------------------------------------------------------------------------------
 // init_state (base.py:155-166 + o2arcenv.py:16-34 / arcenv.py:81-89), counters as in reset (base.py:73-79)
 // ------------------------------------------------------------------------------------------------
-ARCLE_DEV void init_state(const Wave& w) {
+ARCLE_DEV void init_state(const Wave& w, Rec& r, I2& cnt) {
   const StepParams& p = w.p;
   U4 in = w.load(ARCLE_PL_INPUT);
   w.store(ARCLE_PL_GRID, in);
@@ -712,26 +725,31 @@ ARCLE_DEV void init_state(const Wave& w) {
   if (p.plane[ARCLE_PL_OBJECT]) w.store(ARCLE_PL_OBJECT, z);
   if (p.plane[ARCLE_PL_OBJECT_SEL]) w.store(ARCLE_PL_OBJECT_SEL, z);
   if (p.plane[ARCLE_PL_BACKGROUND]) w.store(ARCLE_PL_BACKGROUND, z);
-  U4 rv = load_rec(p, w.env);
-  Rec r;
-  rec_unpack(rv, r);
   r.gh = r.in_h;
   r.gw = r.in_w;
   r.ch = r.cw = r.oh = r.ow = r.ox = r.oy = 0;
   r.trials = i8w(p.max_trial);
   r.term = r.active = r.parity = 0;
-  xl::lds_fence();  // (emulator) every lane has read the record before lane 0 rewrites it
-  if (w.lane == 0) {
-    *reinterpret_cast<U4*>(p.rec + (size_t)w.env * ARCLE_REC_BYTES) = rec_pack(r);
-    p.cnt[2 * (size_t)w.env + ARCLE_CNT_STEPS] = 0;
-    p.cnt[2 * (size_t)w.env + ARCLE_CNT_SUBMIT] = 0;
+  cnt.x = 0;
+  cnt.y = 0;
+}
+
+ARCLE_DEV void store_rec_cnt(const StepParams& p, int env, int lane, const Rec& r, const I2& cnt) {
+  if (lane == 0) {
+    *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rec_pack(r);
+    *reinterpret_cast<I2*>(p.cnt + 2 * (size_t)env) = cnt;
   }
 }
 
 ARCLE_DEV void wave_reset(const StepParams& p, WaveLDS* lds, int env, int lane) {
   if (p.rmask && !p.rmask[env]) return;
   Wave w(p, lds, env, lane, INGRESS_BBOX, 0);
-  init_state(w);
+  Rec r;
+  rec_unpack(load_rec(p, env), r);
+  I2 cnt;
+  init_state(w, r, cnt);
+  xl::lds_fence();  // (emulator) every lane has read the record before lane 0 rewrites it
+  store_rec_cnt(p, env, lane, r, cnt);
 }
 
 // reset() with a caller-chosen task (base.py:95-108): the (input, answer) pair comes from the device task table
@@ -775,45 +793,27 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, int env, int 
 // ------------------------------------------------------------------------------------------------
 // one step() of one env:  O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step / RawARCEnv.step
 // ------------------------------------------------------------------------------------------------
-template <int ING, int FW>
-ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
-#ifdef ARCLE_DEBUG_STAGES  // tuning builds only: early exits to attribute the fixed cost of a launch
-  const uint32_t dbg = p.flags >> 8;
-  if (dbg == 1) return;
-#endif
-  Wave w(p, lds, env, lane, ING, FW);
-  const int P = p.P, W = p.W;
-  // ---- one latency window: record, op index, counters and the selection payload are independent loads ----
-  U4 rv = *reinterpret_cast<const U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES);
-  uint32_t opv = (uint32_t)p.op[env];
-  I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
-  U4 payload = load_payload(w);
-#ifdef ARCLE_PREFETCH_GRID
-  // speculative: 26 of the 35 O2ARC ops read the grid; fetching it in the first window saves one dependent
-  // HBM latency per step at the price of 1 plane of over-fetch for the ops that do not need it
-  U4 grid_pre = w.load(ARCLE_PL_GRID);  // no wait here: first use is inside the op that needs it
-#endif
-  xl::keep(rv, payload, opv, cnt0.x);  // all four are in flight before the first use
-#pragma unroll
-  for (int i = 0; i < 4; i++) rv[i] = xl::uniform(rv[i]);
-  Rec r;
-  rec_unpack(rv, r);
-  const int op = (int)xl::uniform(opv);
-#ifdef ARCLE_DEBUG_STAGES
-  if (dbg == 2) {
-    if (lane == 0 && op == 12345 && r.gh == 77) p.reward[env] = 1;
-    return;
-  }
-#endif
+struct StepOut {
+  int reward;      // 0/1
+  bool term;       // bool(state['terminated'])
+  uint32_t bytes;  // algorithmic HBM bytes of the step (0 for skipped steps)
+};
 
+// Everything of step() between "record/op/payload are in registers" and "record/counters/outputs go back to
+// memory": autoreset, op decode, the operation itself, reward.  Planes are read/written through w.load/w.store, so
+// the same code serves the single-step kernel (HBM) and the rollout kernel (register-resident planes).
+template <int ING, int FW>
+ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, const int op) {
+  const StepParams& p = w.p;
+  const int P = p.P, W = p.W, lane = w.lane;
+  StepOut out;
+  out.reward = 0;
+  out.bytes = 0;
   if ((p.flags & ARCLE_STEP_AUTORESET) && r.term != 0) {
-    init_state(w);
-    if (lane == 0) {
-      p.reward[env] = 0;
-      p.term[env] = 0;
-      if (p.acct) p.acct[env] += (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
-    }
-    return;
+    init_state(w, r, cnt0);
+    out.term = 0;
+    out.bytes = (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
+    return out;
   }
   bool bad_op = op < 0 || op >= p.n_ops;
   // scalar load through the constant cache (all waves read the same 256 B table: a per-lane vector fetch of it
@@ -822,12 +822,9 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   if (!bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
-    if (lane == 0) {
-      xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
-      p.reward[env] = 0;
-      p.term[env] = (uint8_t)(r.term != 0);
-    }
-    return;
+    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
+    out.term = r.term != 0;
+    return out;
   }
   const int kind = (int)ARCLE_OP_KIND(desc), arg = (int)ARCLE_OP_ARG(desc);
   const uint32_t oflags = ARCLE_OP_FLAGS(desc);
@@ -835,9 +832,6 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   Planes s;
   s.wr = 0;
   s.have_grid = false;
-#ifdef ARCLE_PREFETCH_GRID
-  s.grid = grid_pre;
-#endif
   s.bytes = 2 * ARCLE_REC_BYTES + 24;  // record R/W + action in + reward/term out
   int submit_inc = 0;
   bool domain_error = false;
@@ -847,12 +841,6 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   ingest_selection(w, sel, payload);
   if (w.ingress == INGRESS_MASK) s.bytes += P;
 
-#ifdef ARCLE_DEBUG_STAGES
-  if (dbg == 3) {
-    if (lane == 0 && sel.nz == 0x12345) p.reward[env] = 1;
-    return;
-  }
-#endif
   const Rec r_before = r;
   if (oflags & ARCLE_OPF_RESET_SEL) {  // object.py:20-25
     s.selected = u4_zero();
@@ -866,17 +854,6 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     s.wr |= WR_SELECTED;
   }
 
-#ifdef ARCLE_DEBUG_STAGES
-  if (dbg == 4) goto epilogue;
-  if (dbg == 5) {
-    if (lane == 0) {
-      *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rec_pack(r);
-      p.reward[env] = 0;
-      p.term[env] = 0;
-    }
-    return;
-  }
-#endif
   switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
     case ARCLE_OP_COLOR: {  // color.py:70-74 — whole HxW plane, grid_dim ignored
       if (sel.any_nz) {
@@ -1105,17 +1082,12 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   }
 
   if (domain_error) {  // the reference raised inside the op: the step did not happen
-    if (lane == 0) {
-      xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
-      p.reward[env] = 0;
-      p.term[env] = (uint8_t)(r_before.term != 0);
-    }
-    return;
+    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+    r = r_before;
+    out.term = r.term != 0;
+    return out;
   }
 
-#ifdef ARCLE_DEBUG_STAGES
-epilogue:
-#endif
   // reward(): only the LAST op of the table can be rewarded (o2arcenv.py:121-128)
   int reward = 0;
   if (op == p.n_ops - 1) {
@@ -1123,7 +1095,7 @@ epilogue:
     reward = eq;
   }
 
-  // ---- epilogue: write back what changed --------------------------------------------------------
+  // write back the planes the op changed
   xl::lds_fence();
   if (s.wr & WR_GRID) w.store(ARCLE_PL_GRID, s.grid);
   if (s.wr & WR_SELECTED) w.store(ARCLE_PL_SELECTED, s.selected);
@@ -1131,14 +1103,37 @@ epilogue:
   if (s.wr & WR_OBJECT) w.store(ARCLE_PL_OBJECT, s.object);
   if (s.wr & WR_OBJECT_SEL) w.store(ARCLE_PL_OBJECT_SEL, s.object_sel);
   if (s.wr & WR_BACKGROUND) w.store(ARCLE_PL_BACKGROUND, s.background);
+  cnt0.x += 1;  // o2arcenv.py:142
+  cnt0.y += submit_inc;
+  out.reward = reward;
+  out.term = r.term != 0;
+  out.bytes = s.bytes;
+  return out;
+}
+
+template <int ING, int FW>
+ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
+  Wave w(p, lds, env, lane, ING, FW);
+  // ---- one latency window: record, op index, counters and the selection payload are independent loads ----
+  U4 rv = *reinterpret_cast<const U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES);
+  uint32_t opv = (uint32_t)p.op[env];
+  I2 cnt0 = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
+  U4 payload = load_payload(w);
+  xl::keep(rv, payload, opv, cnt0.x);  // all four are in flight before the first use
+#pragma unroll
+  for (int i = 0; i < 4; i++) rv[i] = xl::uniform(rv[i]);
+  Rec r;
+  rec_unpack(rv, r);
+  const int op = (int)xl::uniform(opv);
+
+  StepOut out = step_core<ING, FW>(w, r, cnt0, payload, op);
+  // ---- epilogue: record, counters and the step outputs --------------------------------------------
   if (lane == 0) {
     *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rec_pack(r);
-    cnt0.x += 1;  // o2arcenv.py:142
-    cnt0.y += submit_inc;
     *reinterpret_cast<I2*>(p.cnt + 2 * (size_t)env) = cnt0;
-    p.reward[env] = reward;
-    p.term[env] = (uint8_t)(r.term != 0);
-    if (p.acct) p.acct[env] += s.bytes;
+    p.reward[env] = out.reward;
+    p.term[env] = (uint8_t)out.term;
+    if (p.acct) p.acct[env] += out.bytes;
   }
 }
 
