@@ -81,6 +81,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(8
   arcle::wave_step<ING, FW>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
 }
 
+template <int ING, int FW>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams p) {
+  __shared__ WaveLDS lds[WAVES_PER_WG];
+  const int env = env_of_wave(p);
+  if (env >= p.n_envs) return;
+  arcle::wave_rollout<ING, FW>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+}
+
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const StepParams p) {
   __shared__ WaveLDS lds[WAVES_PER_WG];
   const int env = env_of_wave(p);
@@ -350,6 +358,44 @@ extern "C" int arcle_step_bbox(arcle_env* e, const int32_t* bbox, const int32_t*
 extern "C" int arcle_step_point(arcle_env* e, const int32_t* xy, const int32_t* op, int32_t* reward, uint8_t* term,
                                 uint32_t flags, void* stream) {
   return launch_step(e, arcle::INGRESS_POINT, xy, op, reward, term, flags, stream);
+}
+
+static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
+                          uint8_t* term, uint32_t flags, void* stream) {
+  if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
+  if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
+  if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
+  StepParams p = e->base;
+  p.ingress = ingress;
+  p.sel = sel;
+  p.op = op;
+  p.reward = reward;
+  p.term = term;
+  p.flags = flags;
+  p.acct = nullptr;
+  p.rmask = nullptr;
+  p.n_steps = n_steps;
+  const bool fw = p.W >= 16 && p.W <= 32;
+  const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
+  hipStream_t st = (hipStream_t)stream;
+  if (ingress == arcle::INGRESS_BBOX) {
+    if (fw) hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_BBOX, 1>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_BBOX, 0>), g, b, 0, st, p);
+  } else {
+    if (fw) hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_POINT, 1>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_POINT, 0>), g, b, 0, st, p);
+  }
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_rollout_bbox(arcle_env* e, int32_t n_steps, const int32_t* bbox, const int32_t* op, int32_t* reward,
+                                  uint8_t* term, uint32_t flags, void* stream) {
+  return launch_rollout(e, arcle::INGRESS_BBOX, n_steps, bbox, op, reward, term, flags, stream);
+}
+extern "C" int arcle_rollout_point(arcle_env* e, int32_t n_steps, const int32_t* xy, const int32_t* op, int32_t* reward,
+                                   uint8_t* term, uint32_t flags, void* stream) {
+  return launch_rollout(e, arcle::INGRESS_POINT, n_steps, xy, op, reward, term, flags, stream);
 }
 
 extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void* stream) {

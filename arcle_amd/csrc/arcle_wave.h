@@ -47,6 +47,7 @@ struct StepParams {
   const int8_t *tbl_in, *tbl_ans;            // task table planes [n_tasks][PS]
   const int8_t *tbl_in_dim, *tbl_ans_dim;    // task table dims   [n_tasks][2]
   int32_t n_tasks;
+  int32_t n_steps;  // rollout kernel only: steps per launch
   int32_t n_envs, H, W, P, PS;  // PS = plane stride in bytes (P rounded up to 16)
   int32_t n_ops, max_trial, ingress;
   uint32_t flags;
@@ -327,13 +328,14 @@ ARCLE_DEV U4 sel_values(const Sel& s) {
 
 // The selection payload of this env, fetched in the same latency window as the record / op / counters
 // (all four are independent of each other): bbox = 4 ints, point = 2 ints, mask = this lane's 16 cells.
-ARCLE_DEV U4 load_payload(const Wave& w) {
+ARCLE_DEV U4 load_payload(const Wave& w, size_t step = 0) {  // step: rollout kernels index [step][env]
   const StepParams& p = w.p;
   U4 v = u4_zero();
+  const size_t e = step * (size_t)p.n_envs + (size_t)w.env;
   if (w.ingress == INGRESS_BBOX) {
-    v = *reinterpret_cast<const U4*>(reinterpret_cast<const int32_t*>(p.sel) + 4 * (size_t)w.env);
+    v = *reinterpret_cast<const U4*>(reinterpret_cast<const int32_t*>(p.sel) + 4 * e);
   } else if (w.ingress == INGRESS_POINT) {
-    const uint32_t* b = reinterpret_cast<const uint32_t*>(p.sel) + 2 * (size_t)w.env;
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(p.sel) + 2 * e;
     v[0] = b[0];
     v[1] = b[1];
   } else {
@@ -1135,6 +1137,45 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     p.term[env] = (uint8_t)out.term;
     if (p.acct) p.acct[env] += out.bytes;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// n_steps consecutive step()s of one env in ONE launch (a rollout / trace replay: the caller already holds the
+// whole action sequence, e.g. tests/o2arc_check.py:139-199 of the reference or a scripted policy).  The env's
+// planes and record live in registers for the whole rollout: HBM sees the planes once in and (if changed) once
+// out, plus 20 B of action in and 5 B of reward/terminated out per step.
+//   sel: int32 [n_steps][n_envs][4|2]   op: int32 [n_steps][n_envs]
+//   reward: int32 [n_steps][n_envs]     term: uint8 [n_steps][n_envs]
+// ------------------------------------------------------------------------------------------------
+template <int ING, int FW>
+ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, int env, int lane) {
+  Wave w(p, lds, env, lane, ING, FW);
+#pragma unroll
+  for (int pl = 0; pl < ARCLE_N_PLANES; pl++) w.cache[pl] = p.plane[pl] ? w.load_hbm(pl) : u4_zero();
+  w.resident = true;
+  Rec r;
+  rec_unpack(load_rec(p, env), r);
+  I2 cnt = *reinterpret_cast<const I2*>(p.cnt + 2 * (size_t)env);
+  const size_t N = (size_t)p.n_envs;
+  U4 next_payload = load_payload(w, 0);
+  uint32_t next_op = (uint32_t)p.op[env];
+  for (int t = 0; t < p.n_steps; t++) {
+    const U4 payload = next_payload;
+    const int op = (int)xl::uniform(next_op);
+    if (t + 1 < p.n_steps) {  // the next action is in flight while this one executes
+      next_payload = load_payload(w, (size_t)t + 1);
+      next_op = (uint32_t)p.op[((size_t)t + 1) * N + env];
+    }
+    const StepOut out = step_core<ING, FW>(w, r, cnt, payload, op);
+    if (lane == 0) {
+      p.reward[(size_t)t * N + env] = out.reward;
+      p.term[(size_t)t * N + env] = (uint8_t)out.term;
+    }
+  }
+#pragma unroll
+  for (int pl = 0; pl < ARCLE_N_PLANES; pl++)
+    if (w.dirty & (1u << pl)) w.store_hbm(pl, w.cache[pl]);
+  store_rec_cnt(p, env, lane, r, cnt);
 }
 
 }  // namespace arcle

@@ -194,6 +194,20 @@ class EnvBatch:
         if rc != 0:
             self._check(rc, "arcle_step_bbox")
 
+    def rollout(self, payload, op, flags=0, point=False):
+        """T steps in one launch.  payload int32 [T,N,4] (bbox) or [T,N,2] (point), op int32 [T,N];
+        returns (reward int32 [T,N], terminated uint8 [T,N]).  Same semantics as T step_bbox/step_point calls."""
+        T = int(op.shape[0])
+        payload = payload.to(device=self.device, dtype=torch.int32).contiguous()
+        op = op.to(device=self.device, dtype=torch.int32).contiguous()
+        assert payload.shape == (T, self.N, 2 if point else 4) and op.shape == (T, self.N)
+        reward = torch.empty((T, self.N), dtype=torch.int32, device=self.device)
+        term = torch.empty((T, self.N), dtype=torch.uint8, device=self.device)
+        fn = self.L.arcle_rollout_point if point else self.L.arcle_rollout_bbox
+        self._check(fn(self._h, T, _ptr(payload), _ptr(op), _ptr(reward), _ptr(term), int(flags), self._stream()),
+                    "arcle_rollout")
+        return reward, term
+
     # ---- status / accounting ------------------------------------------------------------------
     def status(self, clear=True):
         s = ctypes.c_uint32(0)

@@ -148,6 +148,17 @@ class ARCVecEnv:
     def step(self, action):
         return self._ret(*self.batch.step_mask(action["selection"], action["operation"], self.flags))
 
+    def rollout_bbox(self, bbox, operation):
+        """T steps in ONE launch: bbox int32 [T,N,4], operation int32 [T,N] -> (obs, reward [T,N], terminated [T,N]).
+        For callers that already hold the action sequence (trace replay, scripted policies); the state is only
+        observable after the last step."""
+        reward, term = self.batch.rollout(bbox, operation, self.flags)
+        return self._obs, reward, term.bool(), self._info()
+
+    def rollout_point(self, xy, operation):
+        reward, term = self.batch.rollout(xy, operation, self.flags, point=True)
+        return self._obs, reward, term.bool(), self._info()
+
     def check_errors(self):
         """Raises if any env saw an out-of-range op / out-of-domain Rotate since the last check
         (the reference raises IndexError / ValueError at the offending step)."""

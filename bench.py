@@ -101,6 +101,26 @@ def cpu_baseline(seed):
                           "sample": f"{nt} envs x {st} steps, same code, OpenMP over envs"}}
 
 
+def rollout_leg(batch, bbox, op, start, dev, T=128, reps=8):
+    """NOT the headline metric: the same action stream replayed with arcle_rollout_bbox (T steps per launch, env
+    state resident in registers between the steps; only per-step reward/terminated and the final state reach HBM).
+    For callers that hold the action sequence up front (trace replay, scripted policies)."""
+    T = min(T, bbox.shape[0] - start)
+    bb, oo = bbox[start:start + T].contiguous(), op[start:start + T].contiguous()
+    batch.rollout(bb, oo)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        batch.rollout(bb, oo)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    return {"mode": "arcle_rollout_bbox", "steps_per_launch": T, "value": T * batch.N / sec, "unit": "env-steps/s",
+            "us_per_step_batch": sec / T * 1e6,
+            "note": "state stays on chip between steps; not comparable with the per-step HBM roofline above"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +236,8 @@ def main():
                        "parallelism": f"env-shard x{world} (no data-path collective)"},
             "roofline": roofline,
         }
+        if world == 1:
+            out["extras"] = {"rollout": rollout_leg(batch, bbox, op, Wm, dev)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(out))

@@ -180,6 +180,17 @@ int arcle_step_bbox(arcle_env* env, const int32_t* bbox, const int32_t* op, int3
 int arcle_step_point(arcle_env* env, const int32_t* xy, const int32_t* op, int32_t* reward,
                      uint8_t* term, uint32_t flags, void* stream);
 
+/* n_steps consecutive step()s of every env in ONE launch — a rollout / trace replay for callers that already hold
+ * the whole action sequence (the loop `for a in trace: env.step(a)`, e.g. tests/o2arc_check.py:139-199 of the
+ * reference).  Semantically identical to n_steps calls of arcle_step_bbox/_point; the env state is kept on chip
+ * between the steps, so only the final state is observable afterwards.
+ *   bbox / xy  device int32[n_steps][n_envs][4 | 2]      op      device int32[n_steps][n_envs]
+ *   reward     device int32[n_steps][n_envs] out         term    device uint8[n_steps][n_envs] out */
+int arcle_rollout_bbox(arcle_env* env, int32_t n_steps, const int32_t* bbox, const int32_t* op, int32_t* reward,
+                       uint8_t* term, uint32_t flags, void* stream);
+int arcle_rollout_point(arcle_env* env, int32_t n_steps, const int32_t* xy, const int32_t* op, int32_t* reward,
+                        uint8_t* term, uint32_t flags, void* stream);
+
 /* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*). Synchronises
  * the stream. */
 int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);

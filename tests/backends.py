@@ -89,7 +89,7 @@ class _StepParams(ctypes.Structure):
                 ("term", ctypes.c_void_p), ("status", ctypes.c_void_p), ("acct", ctypes.c_void_p),
                 ("rmask", ctypes.c_void_p), ("task_idx", ctypes.c_void_p), ("tbl_in", ctypes.c_void_p),
                 ("tbl_ans", ctypes.c_void_p), ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p),
-                ("n_tasks", ctypes.c_int32),
+                ("n_tasks", ctypes.c_int32), ("n_steps", ctypes.c_int32),
                 ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32),
                 ("ingress", ctypes.c_int32), ("flags", ctypes.c_uint32), ("div_magic", ctypes.c_uint32),
@@ -159,6 +159,19 @@ class EmuBackend:
         p.rmask = None if m is None else m.ctypes.data
         rc = emu_lib().emu_run(1, ctypes.byref(p))
         assert rc == 0, f"wave emulator reported error {rc}"
+
+    def rollout(self, ingress, payload, op, flags=0):
+        p = self._params()
+        T = len(op)
+        pay = np.ascontiguousarray(payload, np.int32)
+        opa = np.ascontiguousarray(op, np.int32)
+        reward = np.zeros((T, self.N), np.int32)
+        term = np.zeros((T, self.N), np.uint8)
+        p.sel, p.op, p.ingress, p.flags, p.n_steps = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags, T
+        p.reward, p.term = reward.ctypes.data, term.ctypes.data
+        rc = emu_lib().emu_run(3, ctypes.byref(p))
+        assert rc == 0, f"wave emulator reported error {rc}"
+        return reward, term
 
     def set_task_table(self, inputs, answers):
         T = len(inputs)
@@ -245,6 +258,13 @@ class HipBackend:
         if field in self.b.planes:
             return self.b.plane(field).cpu().numpy().copy()
         return self.b.field(field).cpu().numpy().copy()
+
+    def rollout(self, ingress, payload, op, flags=0):
+        t = self.torch
+        r, tm = self.b.rollout(t.as_tensor(np.ascontiguousarray(payload, np.int32), device=self.b.device),
+                               t.as_tensor(np.ascontiguousarray(op, np.int32), device=self.b.device), flags,
+                               point=(ingress == "point"))
+        return r.cpu().numpy(), tm.cpu().numpy()
 
     def set_task_table(self, inputs, answers):
         self.b.set_task_table(inputs, answers)
@@ -450,4 +470,48 @@ def task_table_compare(backend_cls, H, W, N, T, seed):
     be.reset_from_table(bad, np.ones(N, np.uint8))
     if not be.status() & 4:
         errs.append("out-of-range task index did not raise ARCLE_ST_BAD_TASK")
+    return errs
+
+
+def rollout_compare(backend_cls, kind, ops, H, W, N, T, seed, ingress="bbox", flags=0, max_trial=3):
+    """One T-step rollout launch vs T sequential oracle steps: per-step reward/terminated, final state, counters."""
+    rng = np.random.default_rng(seed)
+    be = backend_cls(N, H, W, max_trial, kind, ops)
+    orc = OracleBackend(N, H, W, max_trial, kind, ops)
+    inp = np.zeros((N, H, W), np.int8)
+    idim = np.zeros((N, 2), np.int8)
+    for n in range(N):
+        ih, iw = rng.integers(1, H + 1), rng.integers(1, W + 1)
+        inp[n, :ih, :iw] = rng.integers(0, 4, (ih, iw))
+        idim[n] = (ih, iw)
+    for b in (be, orc):
+        b.set_tasks(inp, idim, inp.copy(), idim.copy())
+        b.reset()
+    op = rng.integers(0, len(ops), (T, N)).astype(np.int32)
+    op[rng.random((T, N)) < 0.05] = len(ops) - 1  # some submits (answer == input: terminations, trial counting)
+    if ingress == "bbox":
+        pay = np.stack([rng.integers(0, H, (T, N)), rng.integers(0, W, (T, N)), rng.integers(0, H, (T, N)),
+                        rng.integers(0, W, (T, N))], -1).astype(np.int32)
+        small = rng.random((T, N)) < 0.5
+        pay[..., 2] = np.where(small, np.minimum(H - 1, pay[..., 0] + rng.integers(0, 3, (T, N))), pay[..., 2])
+        pay[..., 3] = np.where(small, np.minimum(W - 1, pay[..., 1] + rng.integers(0, 3, (T, N))), pay[..., 3])
+    else:
+        pay = np.stack([rng.integers(0, H, (T, N)), rng.integers(0, W, (T, N))], -1).astype(np.int32)
+    r1, t1 = be.rollout(ingress, pay, op, flags)
+    errs = []
+    for t in range(T):
+        r2, t2 = orc.step(ingress, pay[t], op[t], flags)
+        if not np.array_equal(r1[t], r2):
+            errs.append(f"step {t}: reward differs for envs {np.nonzero(r1[t] != r2)[0].tolist()}")
+        if not np.array_equal(t1[t], t2):
+            errs.append(f"step {t}: terminated differs for envs {np.nonzero(t1[t] != t2)[0].tolist()}")
+    for f in [f for f in PLANES if f in O.KIND_PLANES[kind]] + list(REC):
+        if f in ("clip_dim", "object_dim", "object_pos", "active", "rotation_parity") and kind != "o2arc" and not (kind == "arc" and f == "clip_dim"):
+            continue
+        if not np.array_equal(be.get(f), orc.get(f)):
+            errs.append(f"final state: field {f} differs")
+    if not np.array_equal(be.counters(), orc.counters()):
+        errs.append("final counters differ")
+    if be.status() != orc.status():
+        errs.append("status flags differ")
     return errs

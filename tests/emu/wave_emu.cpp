@@ -98,6 +98,14 @@ void lane_main(int lane) {
   }
   else if (g_kind == 2)
     arcle::wave_reset_table(*g_p, &g_lds, g_env, lane);
+  else if (g_kind == 3) {
+    switch (g_p->ingress * 2 + (fw ? 1 : 0)) {
+      case 2: arcle::wave_rollout<1, 0>(*g_p, &g_lds, g_env, lane); break;
+      case 3: arcle::wave_rollout<1, 1>(*g_p, &g_lds, g_env, lane); break;
+      case 4: arcle::wave_rollout<2, 0>(*g_p, &g_lds, g_env, lane); break;
+      default: arcle::wave_rollout<2, 1>(*g_p, &g_lds, g_env, lane); break;
+    }
+  }
   else
     arcle::wave_reset(*g_p, &g_lds, g_env, lane);
   xl::finished[lane] = true;
@@ -148,7 +156,7 @@ void run_wave() {
 }
 }  // namespace
 
-// kind: 0 = step, 1 = reset, 2 = reset from the task table.  Fills derived fields (P, PS, div_magic, nseg) like arcle_create does.
+// kind: 0 = step, 1 = reset, 2 = reset from the task table, 3 = rollout.  Fills derived fields (P, PS, div_magic, nseg) like arcle_create does.
 extern "C" int emu_run(int kind, arcle::StepParams* p) {
   p->P = p->H * p->W;
   p->PS = (p->P + 15) & ~15;

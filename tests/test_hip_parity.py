@@ -200,6 +200,18 @@ def test_vec_env_reset_and_resample_autoreset():
         venv.reset(options={"prob_index": 99})
 
 
+@pytest.mark.parametrize("H,W,ingress", [(30, 30, "bbox"), (10, 10, "bbox"), (30, 30, "point"), (5, 7, "bbox"), (16, 24, "bbox")])
+def test_hip_rollout_equals_sequential_steps(H, W, ingress):
+    """arcle_rollout_* (T steps in one launch, planes resident in registers) == T oracle steps."""
+    for flags in (0, O.STEP_AUTORESET):
+        errs = B.rollout_compare(B.HipBackend, "o2arc", O.o2arc_ops(), H, W, N=160, T=64, seed=H + W + flags,
+                                 ingress=ingress, flags=flags)
+        assert not errs, "\n".join(errs[:10])
+    for kind, ops in (("arc", O.arc_ops()), ("raw", O.raw_ops())):
+        errs = B.rollout_compare(B.HipBackend, kind, ops, H, W, N=64, T=48, seed=3, ingress=ingress)
+        assert not errs, "\n".join(errs[:10])
+
+
 def test_single_env_gym_api_matches_oracle():
     """The Gymnasium-style single env (reference API: dict obs, dict action) on the GPU."""
     from arcle_amd.envs import O2ARCv2Env

@@ -48,3 +48,17 @@ def test_emulated_kernel_vs_oracle_exotic_ops(H, W):
 def test_emulated_reset_from_task_table(H, W):
     errs = B.task_table_compare(B.EmuBackend, H, W, N=12, T=9, seed=H)
     assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("H,W,ingress", [(30, 30, "bbox"), (10, 10, "bbox"), (30, 30, "point"), (5, 7, "bbox")])
+def test_emulated_rollout_equals_sequential_steps(H, W, ingress):
+    for flags in (0, O.STEP_AUTORESET):
+        errs = B.rollout_compare(B.EmuBackend, "o2arc", O.o2arc_ops(), H, W, N=6, T=40, seed=H + W + flags,
+                                 ingress=ingress, flags=flags)
+        assert not errs, "\n".join(errs[:10])
+
+
+def test_emulated_rollout_other_kinds():
+    for kind, ops in (("arc", O.arc_ops()), ("raw", O.raw_ops())):
+        errs = B.rollout_compare(B.EmuBackend, kind, ops, 30, 30, N=4, T=30, seed=9)
+        assert not errs, "\n".join(errs[:10])
