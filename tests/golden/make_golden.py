@@ -62,7 +62,7 @@ def fields_of(variant):
     return ["input", "grid", "input_dim", "grid_dim", "trials_remain", "terminated"]
 
 
-def capture(name, variant, H, W, max_trial, N, S, seed, script=None, weird=False, full_every=16):
+def capture(name, variant, H, W, max_trial, N, S, seed, script=None, weird=False, full_every=16, bool_masks=False):
     """script(rng, s, n, H, W, n_ops) -> (op, mask) overrides the random action stream (ingress = mask)."""
     rng = RD.SplitMix64(seed)
     kind, table = RD.variant_table(variant)
@@ -106,7 +106,9 @@ def capture(name, variant, H, W, max_trial, N, S, seed, script=None, weird=False
             step_masks[n] = m
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                _, r, t, trunc, info = env.step({"selection": m.copy(), "operation": int(o)})
+                # bool_masks: the reference is fed np.bool_ selections (base.py:136 allows both); the fixture stores 0/1
+                _, r, t, trunc, info = env.step({"selection": m.astype(bool) if bool_masks else m.copy(),
+                                                 "operation": int(o)})
             assert trunc is False
             reward[s, n], term[s, n] = int(r), int(bool(t))
             steps[s, n] = info["steps"]
@@ -123,7 +125,7 @@ def capture(name, variant, H, W, max_trial, N, S, seed, script=None, weird=False
             hashes[s, :, fi] = checksum(arr)
             if s in full_steps:
                 full[f].append(arr)
-    meta = dict(variant=variant, kind=kind, H=H, W=W, max_trial=max_trial, N=N, S=S,
+    meta = dict(variant=variant, kind=kind, H=H, W=W, max_trial=max_trial, N=N, S=S, bool_masks=bool_masks,
                 ops=[int(x) for x in table], seed=seed)
     inp = np.zeros((N, H, W), np.int8)
     ans = np.zeros((N, H, W), np.int8)
@@ -220,9 +222,11 @@ class QuirkScript:
 
 def main():
     RD.import_reference()
-    capture("o2arc_05", "o2arc", 5, 5, -1, 16, 128, 101)
-    capture("o2arc_10", "o2arc", 10, 10, 3, 16, 128, 102)
-    capture("o2arc_30", "o2arc", 30, 30, -1, 16, 160, 103)
+    capture("o2arc_05", "o2arc", 5, 5, -1, 32, 128, 101)
+    capture("o2arc_10", "o2arc", 10, 10, 3, 32, 128, 102)
+    capture("o2arc_30", "o2arc", 30, 30, -1, 32, 160, 103)
+    capture("o2arc_30_bool", "o2arc", 30, 30, 3, 16, 96, 112, bool_masks=True)
+    capture("o2arc_20", "o2arc", 20, 20, -1, 16, 96, 113)
     capture("o2arc_30_t127", "o2arc", 30, 30, 127, 8, 96, 104, weird=True)
     capture("o2arc_crop_10", "o2arc_crop", 10, 10, -1, 8, 96, 105)
     capture("o2arc_exotic_12", "o2arc_exotic", 12, 12, -1, 8, 128, 106)

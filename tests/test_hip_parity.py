@@ -20,7 +20,8 @@ def _gpu():
     import torch
     assert torch.cuda.is_available(), "these tests need the MI355X"
     from arcle_amd import _lib
-    _lib.lib()  # the product library must be present and loadable: no silent fallback
+    _lib.build()  # no-op when csrc/libarcle_hip.so is up to date (it travels with the snapshot)
+    _lib.lib()    # the product library must be present and loadable: no silent fallback
 
 
 @pytest.mark.parametrize("name", B.fixture_names())
