@@ -89,6 +89,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const 
   arcle::wave_rollout<ING, FW>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
 }
 
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_flatten_kernel(const StepParams p) {
+  __shared__ WaveLDS lds[WAVES_PER_WG];
+  const int env = env_of_wave(p);
+  if (env >= p.n_envs) return;
+  arcle::wave_flatten(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+}
+
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const StepParams p) {
   __shared__ WaveLDS lds[WAVES_PER_WG];
   const int env = env_of_wave(p);
@@ -396,6 +403,27 @@ extern "C" int arcle_rollout_bbox(arcle_env* e, int32_t n_steps, const int32_t* 
 extern "C" int arcle_rollout_point(arcle_env* e, int32_t n_steps, const int32_t* xy, const int32_t* op, int32_t* reward,
                                    uint8_t* term, uint32_t flags, void* stream) {
   return launch_rollout(e, arcle::INGRESS_POINT, n_steps, xy, op, reward, term, flags, stream);
+}
+
+extern "C" int arcle_flat_obs_size(const arcle_env* e) {
+  if (!e) return ARCLE_ERR_ARG;
+  int n = 0;
+  const int P = e->base.P;
+  const bool o2 = e->bufs.plane[ARCLE_PL_SELECTED] != nullptr, clip = e->bufs.plane[ARCLE_PL_CLIP] != nullptr;
+  n += 2 * P + 4 + 2;  // grid, grid_dim, input, input_dim, terminated, trials_remain
+  if (clip) n += P + 2;
+  if (o2) n += 4 * P + 6;  // background, object, object_sel, selected + active, object_dim, object_pos, parity
+  return n;
+}
+
+extern "C" int arcle_flatten_obs(arcle_env* e, int8_t* out, void* stream) {
+  if (!e || !out) return ARCLE_ERR_ARG;
+  StepParams p = e->base;
+  p.flat_out = out;
+  p.flat_len = arcle_flat_obs_size(e);
+  hipLaunchKernelGGL(arcle_flatten_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
 }
 
 extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void* stream) {

@@ -48,6 +48,8 @@ struct StepParams {
   const int8_t *tbl_in_dim, *tbl_ans_dim;    // task table dims   [n_tasks][2]
   int32_t n_tasks;
   int32_t n_steps;  // rollout kernel only: steps per launch
+  int8_t* flat_out;  // flatten kernel only
+  int32_t flat_len;
   int32_t n_envs, H, W, P, PS;  // PS = plane stride in bytes (P rounded up to 16)
   int32_t n_ops, max_trial, ingress;
   uint32_t flags;
@@ -1176,6 +1178,48 @@ ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, int env, int lane
   for (int pl = 0; pl < ARCLE_N_PLANES; pl++)
     if (w.dirty & (1u << pl)) w.store_hbm(pl, w.cache[pl]);
   store_rec_cnt(p, env, lane, r, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// flattened observation row of one env (Gymnasium FlattenObservation key order; GPTPolicy.py:17-35)
+// ------------------------------------------------------------------------------------------------
+ARCLE_DEV void flat_plane(const Wave& w, int8_t* row, int& off, int pl) {
+  if (!w.p.plane[pl]) return;
+  U4 v = w.load_hbm(pl);
+  int8_t* d = row + off + 16 * w.lane;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    if ((w.valid16 >> k) & 1u) d[k] = (int8_t)u4_byte(v, k);
+  off += w.p.P;
+}
+ARCLE_DEV void flat_scalar(const Wave& w, int8_t* row, int& off, const int8_t* rec, int field, int n) {
+  if (w.lane < n) row[off + w.lane] = rec[field + w.lane];
+  off += n;
+}
+ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, int env, int lane) {
+  Wave w(p, lds, env, lane, INGRESS_BBOX, 0);
+  int8_t* row = p.flat_out + (size_t)env * p.flat_len;
+  const int8_t* rec = p.rec + (size_t)env * ARCLE_REC_BYTES;
+  const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
+  int off = 0;
+  flat_plane(w, row, off, ARCLE_PL_CLIP);
+  if (clip) flat_scalar(w, row, off, rec, ARCLE_REC_CLIP_DIM, 2);
+  flat_plane(w, row, off, ARCLE_PL_GRID);
+  flat_scalar(w, row, off, rec, ARCLE_REC_GRID_DIM, 2);
+  flat_plane(w, row, off, ARCLE_PL_INPUT);
+  flat_scalar(w, row, off, rec, ARCLE_REC_INPUT_DIM, 2);
+  if (o2) {
+    flat_scalar(w, row, off, rec, ARCLE_REC_ACTIVE, 1);
+    flat_plane(w, row, off, ARCLE_PL_BACKGROUND);
+    flat_plane(w, row, off, ARCLE_PL_OBJECT);
+    flat_scalar(w, row, off, rec, ARCLE_REC_OBJECT_DIM, 2);
+    flat_scalar(w, row, off, rec, ARCLE_REC_OBJECT_POS, 2);
+    flat_plane(w, row, off, ARCLE_PL_OBJECT_SEL);
+    flat_scalar(w, row, off, rec, ARCLE_REC_PARITY, 1);
+    flat_plane(w, row, off, ARCLE_PL_SELECTED);
+  }
+  flat_scalar(w, row, off, rec, ARCLE_REC_TERMINATED, 1);
+  flat_scalar(w, row, off, rec, ARCLE_REC_TRIALS, 1);
 }
 
 }  // namespace arcle

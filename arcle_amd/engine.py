@@ -208,6 +208,16 @@ class EnvBatch:
                     "arcle_rollout")
         return reward, term
 
+    def flat_obs(self, out=None):
+        """[N, L] int8 flattened observations in Gymnasium FlattenObservation key order (agents/models/GPTPolicy.py:
+        17-35 of the reference); L = 7*H*W + 14 for O2ARCv2Env.  One kernel, written into `out` if given."""
+        L = self.L.arcle_flat_obs_size(self._h)
+        if out is None:
+            out = torch.empty((self.N, L), dtype=torch.int8, device=self.device)
+        assert out.shape == (self.N, L) and out.dtype == torch.int8 and out.is_contiguous() and out.device == self.device
+        self._check(self.L.arcle_flatten_obs(self._h, _ptr(out), self._stream()), "arcle_flatten_obs")
+        return out
+
     # ---- status / accounting ------------------------------------------------------------------
     def status(self, clear=True):
         s = ctypes.c_uint32(0)

@@ -159,6 +159,11 @@ class ARCVecEnv:
         reward, term = self.batch.rollout(xy, operation, self.flags, point=True)
         return self._obs, reward, term.bool(), self._info()
 
+    def flat_obs(self, out=None):
+        """The observation as one [N, L] int8 tensor in FlattenObservation key order (what the reference's policies
+        consume, agents/models/GPTPolicy.py:17-35)."""
+        return self.batch.flat_obs(out)
+
     def check_errors(self):
         """Raises if any env saw an out-of-range op / out-of-domain Rotate since the last check
         (the reference raises IndexError / ValueError at the offending step)."""

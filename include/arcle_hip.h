@@ -191,6 +191,14 @@ int arcle_rollout_bbox(arcle_env* env, int32_t n_steps, const int32_t* bbox, con
 int arcle_rollout_point(arcle_env* env, int32_t n_steps, const int32_t* xy, const int32_t* op, int32_t* reward,
                         uint8_t* term, uint32_t flags, void* stream);
 
+/* Flattened observation: out int8 [n_envs][arcle_flat_obs_size()] (device), one row per env holding the state dict in
+ * Gymnasium FlattenObservation order (keys sorted, nested object_states in place) — what the reference's policies
+ * consume (agents/models/GPTPolicy.py:17-35 `unflatten_vec`):  clip, clip_dim, grid, grid_dim, input, input_dim,
+ * active, background, object, object_dim, object_pos, object_sel, rotation_parity, selected, terminated, trials_remain
+ * = 7*H*W + 14 bytes for O2ARCv2Env (6314 at 30x30); env kinds without some keys simply omit them. */
+int arcle_flat_obs_size(const arcle_env* env);
+int arcle_flatten_obs(arcle_env* env, int8_t* out, void* stream);
+
 /* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*). Synchronises
  * the stream. */
 int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);

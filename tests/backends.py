@@ -90,6 +90,7 @@ class _StepParams(ctypes.Structure):
                 ("rmask", ctypes.c_void_p), ("task_idx", ctypes.c_void_p), ("tbl_in", ctypes.c_void_p),
                 ("tbl_ans", ctypes.c_void_p), ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p),
                 ("n_tasks", ctypes.c_int32), ("n_steps", ctypes.c_int32),
+                ("flat_out", ctypes.c_void_p), ("flat_len", ctypes.c_int32),
                 ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32),
                 ("ingress", ctypes.c_int32), ("flags", ctypes.c_uint32), ("div_magic", ctypes.c_uint32),

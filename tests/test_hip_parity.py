@@ -213,6 +213,30 @@ def test_hip_rollout_equals_sequential_steps(H, W, ingress):
         assert not errs, "\n".join(errs[:10])
 
 
+@pytest.mark.parametrize("kind,ops", [("o2arc", O.o2arc_ops()), ("arc", O.arc_ops()), ("raw", O.raw_ops())])
+def test_flattened_observation_layout(kind, ops):
+    """arcle_flatten_obs == concatenation of the state fields in sorted-key order (GPTPolicy.py:17-35 unflatten_vec)."""
+    import torch
+    H = W = 30
+    be = B.HipBackend(100, H, W, 3, kind, ops)
+    rng = np.random.default_rng(1)
+    inp = rng.integers(0, 10, (100, H, W)).astype(np.int8)
+    dims = np.full((100, 2), 30, np.int8)
+    be.set_tasks(inp, dims, inp, dims)
+    be.reset()
+    for _ in range(20):
+        bb = rng.integers(0, 30, (100, 4)).astype(np.int32)
+        be.step("bbox", bb, rng.integers(0, len(ops), 100).astype(np.int32))
+    flat = be.b.flat_obs().cpu().numpy()
+    order = {"o2arc": ["clip", "clip_dim", "grid", "grid_dim", "input", "input_dim", "active", "background", "object",
+                       "object_dim", "object_pos", "object_sel", "rotation_parity", "selected", "terminated", "trials_remain"],
+             "arc": ["clip", "clip_dim", "grid", "grid_dim", "input", "input_dim", "terminated", "trials_remain"],
+             "raw": ["grid", "grid_dim", "input", "input_dim", "terminated", "trials_remain"]}[kind]
+    want = np.concatenate([be.get(f).reshape(100, -1) for f in order], axis=1)
+    assert flat.shape == want.shape and (kind != "o2arc" or flat.shape[1] == 6314)
+    assert np.array_equal(flat, want)
+
+
 def test_single_env_gym_api_matches_oracle():
     """The Gymnasium-style single env (reference API: dict obs, dict action) on the GPU."""
     from arcle_amd.envs import O2ARCv2Env
