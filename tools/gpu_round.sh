@@ -1,15 +1,18 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun) from the repo root: smoke, GPU parity tests, bench, rocprofv3 kernel trace.
+# Runs on the GPU box (via gpurun) from the repo root: smoke, GPU parity tests, bench, rocprofv3 kernel trace, PMC passes.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
 rocm-smi --showproductname > $O/gpu_info.log 2>&1; nproc >> $O/gpu_info.log; lscpu | head -20 >> $O/gpu_info.log
-echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke.log
-echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 --tb=short > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -40 $O/pytest_gpu.log
-echo "== bench"; timeout 600 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?"; tail -5 $O/bench.log
-echo "== rocprof"
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 --tb=short > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+echo "== bench"; timeout 600 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?"; grep '^{' $O/bench.log
+echo "== rocprof kernel trace of the same command"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o step -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/rocprof.log 2>&1; echo "rocprof rc=$?"; tail -3 $O/rocprof.log
-find $O/prof -name "*stats*" | head; for f in $(find $O/prof -name "*kernel_stats*.csv"); do head -8 $f; done
+rm -rf $O/prof
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o step -- python $R/bench.py --no-cpu-baseline > $O/rocprof.log 2>&1; echo "rocprof rc=$?"
+python $R/tools/prof_summary.py $O/prof/step_results.db | head -8
+echo "== PMC passes"
+bash $R/tools/gpu_pmc.sh 2>&1 | tail -24
