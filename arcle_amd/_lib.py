@@ -17,7 +17,7 @@ ABI_VERSION = 1
 N_PLANES = 8
 MAX_OPS = 64
 EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buffers", "arcle_set_op_table",
-           "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table", "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_flat_obs_size", "arcle_flatten_obs", "arcle_get_status",
+           "arcle_can_elide_selected", "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table", "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_flat_obs_size", "arcle_flatten_obs", "arcle_get_status",
            "arcle_enable_accounting", "arcle_get_accounting", "arcle_last_error"]
 
 
@@ -68,6 +68,7 @@ def lib():
     L.arcle_destroy.argtypes = [vp]
     L.arcle_get_buffers.argtypes = [vp, ctypes.POINTER(Buffers)]
     L.arcle_set_op_table.argtypes = [vp, ctypes.POINTER(u32), i32]
+    L.arcle_can_elide_selected.argtypes = [vp]
     L.arcle_reset.argtypes = [vp, vp, vp]
     L.arcle_set_task_table.argtypes = [vp, vp, vp, vp, vp, i32]
     L.arcle_reset_from_table.argtypes = [vp, vp, vp, vp]

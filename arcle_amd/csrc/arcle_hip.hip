@@ -291,6 +291,13 @@ extern "C" int arcle_set_task_table(arcle_env* e, const int8_t* in_planes, const
   return ARCLE_OK;
 }
 
+extern "C" int arcle_can_elide_selected(const arcle_env* e) {
+  if (!e || e->base.n_ops <= 0) return 0;
+  for (int i = 0; i < e->base.n_ops; i++)
+    if (ARCLE_OP_FLAGS(e->ops_host[i]) & ARCLE_OPF_KEEP_SEL) return 0;
+  return e->bufs.plane[ARCLE_PL_SELECTED] != nullptr;
+}
+
 static dim3 grid_for(int n_envs);
 
 extern "C" int arcle_reset_from_table(arcle_env* e, const int32_t* task_idx, const uint8_t* mask, void* stream) {

@@ -847,9 +847,13 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
 
   const Rec r_before = r;
   if (oflags & ARCLE_OPF_RESET_SEL) {  // object.py:20-25
-    s.selected = u4_zero();
-    s.wr |= WR_SELECTED;
-    s.bytes += P;
+    // with ARCLE_STEP_ELIDE_SELECTED an env that enters the step inactive is known to hold an all-zero `selected`
+    // plane already (see include/arcle_hip.h): the zero-fill would rewrite zeros with zeros
+    if (!((p.flags & ARCLE_STEP_ELIDE_SELECTED) && r.active == 0)) {
+      s.selected = u4_zero();
+      s.wr |= WR_SELECTED;
+    }
+    s.bytes += P;  // semantic accounting is unchanged
     r.active = 0;
   }
   if (oflags & ARCLE_OPF_KEEP_SEL) {  // object.py:36-40

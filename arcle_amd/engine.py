@@ -25,6 +25,7 @@ KIND_PLANES = {  # which planes each env kind's state dict holds (o2arcenv.py:16
     "raw": ["input", "grid", "answer"],
 }
 STEP_AUTORESET = 1
+STEP_ELIDE_SELECTED = 2
 ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK = 1, 2, 4
 
 
@@ -94,6 +95,8 @@ class EnvBatch:
         arr = (ctypes.c_uint32 * len(descs))(*[int(d) for d in descs])
         self._check(self.L.arcle_set_op_table(self._h, arr, len(descs)), "arcle_set_op_table")
         self.n_ops = len(descs)
+        # flag for step launches on states that only ever evolved through this library (see ARCLE_STEP_ELIDE_SELECTED)
+        self.elide_flag = STEP_ELIDE_SELECTED if self.L.arcle_can_elide_selected(self._h) else 0
 
     def set_tasks(self, inputs, answers, env_ids=None):
         """Uploads tasks.  inputs/answers: sequences of un-padded 2-D int8 arrays (what Loader.pick yields)."""

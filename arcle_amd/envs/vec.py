@@ -37,7 +37,8 @@ class ARCVecEnv:
         # autoreset: False | True (Gymnasium next-step autoreset of the SAME task, inside the step kernel)
         #            | "resample" (same-step autoreset with a NEW random task from the device task table)
         self.autoreset = autoreset
-        self.flags = STEP_AUTORESET if autoreset is True else 0
+        # the vector env's state only evolves through the kernels, so redundant zero-fills of `selected` can be elided
+        self.flags = (STEP_AUTORESET if autoreset is True else 0) | self.batch.elide_flag
         self._gen = torch.Generator(device=self.batch.device)
         self._gen.manual_seed(int(self.rng.integers(0, 2**31)))
         self.task_index = np.zeros(self.N, np.int64)

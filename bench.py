@@ -152,6 +152,7 @@ def main():
     # shard = contiguous global env ids [rank*n, (rank+1)*n); per-shard seeds keyed by rank
     batch = EnvBatch(n, H, W, -1, "o2arc", dev)
     batch.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
+    FL = batch.elide_flag  # ARCLE_STEP_ELIDE_SELECTED: what ARCVecEnv passes (state evolves only through the kernels)
     batch.set_tasks_padded(*make_tasks(n, 1000 + rank))
     batch.reset()
     K, Wm = a.steps, a.warmup
@@ -168,7 +169,7 @@ def main():
             dist.barrier()
 
     for i in range(Wm):  # untimed warm-up steps
-        batch.step_bbox_ptr(bptr[i], optr[i], 0, sh)
+        batch.step_bbox_ptr(bptr[i], optr[i], FL, sh)
     torch.cuda.synchronize(dev)
     # snapshot of the state the timed region starts from (replayed below for the byte accounting)
     snap = {k: v.clone() for k, v in batch.planes.items()}
@@ -181,7 +182,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record(stream)  # HIP events on the stream the kernel is launched on
     for i in range(Wm, Wm + K):
-        batch.step_bbox_ptr(bptr[i], optr[i], 0, sh)
+        batch.step_bbox_ptr(bptr[i], optr[i], FL, sh)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     barrier()
@@ -206,7 +207,7 @@ def main():
         batch.enable_accounting(True)
         batch.accounting(clear=True)
         for i in range(Wm, Wm + K):
-            batch.step_bbox_ptr(bptr[i], optr[i], 0, sh)
+            batch.step_bbox_ptr(bptr[i], optr[i], FL, sh)
         torch.cuda.synchronize(dev)
         nbytes, nsteps = batch.accounting(clear=True)
         batch.enable_accounting(False)

@@ -103,6 +103,13 @@ enum arcle_op_kind {
  * reward 0, terminated 0 for that step (Gymnasium "next-step" autoreset; not in the
  * reference, which keeps mutating a terminated env — that is the default here too). */
 #define ARCLE_STEP_AUTORESET 1u
+/* reset_sel (object.py:20-25) need not rewrite a `selected` plane that is already zero.  Whenever the op table holds
+ * no keep_sel-wrapped op, `active == 0` implies `selected == 0` (object ops set both, reset_sel / init_state clear both,
+ * nothing else writes `selected`), so with this flag the zero-fill is skipped when the env enters the step with
+ * active == 0.  The state after the step is bit-identical; only a redundant 1-plane write disappears.  Do NOT set it
+ * for states written from outside (e.g. a state dict uploaded for transition()) that may violate the invariant;
+ * arcle_set_op_table() reports through arcle_can_elide_selected() whether the installed table permits it. */
+#define ARCLE_STEP_ELIDE_SELECTED 2u
 
 /* ---- sticky device status bits (arcle_get_status) ---- */
 #define ARCLE_ST_BAD_OP 1u       /* operation index out of range / empty slot: step skipped
@@ -146,6 +153,9 @@ int arcle_get_buffers(const arcle_env* env, arcle_buffers* out);
 /* Installs the operation table (host array of descriptors). Replaces the list returned by
  * create_operations() (o2arcenv.py:76-113, arcenv.py:26-41,110-138). */
 int arcle_set_op_table(arcle_env* env, const uint32_t* descs, int32_t n_ops);
+
+/* 1 if the installed op table keeps the invariant documented at ARCLE_STEP_ELIDE_SELECTED, else 0. */
+int arcle_can_elide_selected(const arcle_env* env);
 
 /* Re-initialises envs from PL_INPUT / REC_INPUT_DIM (init_state: base.py:155-166,
  * o2arcenv.py:16-34; counters as in reset base.py:73-79). `mask` is a device uint8[n_envs]

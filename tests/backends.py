@@ -301,7 +301,15 @@ def load_fixture(name):
     return fx
 
 
-def replay_fixture(backend_cls, name, max_steps=None):
+STEP_ELIDE_SELECTED = 2
+
+
+def can_elide(ops):
+    """ARCLE_STEP_ELIDE_SELECTED is only valid for tables without keep_sel-wrapped ops (include/arcle_hip.h)."""
+    return not any((d >> 16) & O.F_KEEP_SEL for d in ops)
+
+
+def replay_fixture(backend_cls, name, max_steps=None, flags=0):
     """Replays a golden trace set on a backend; returns a list of mismatch descriptions (empty = parity)."""
     fx = load_fixture(name)
     m = fx["meta"]
@@ -315,11 +323,11 @@ def replay_fixture(backend_cls, name, max_steps=None):
     for s in range(S):
         ing = int(fx["ingress"][s])
         if ing == 0:
-            r, t = be.step("bbox", fx["bbox"][s], fx["op"][s])
+            r, t = be.step("bbox", fx["bbox"][s], fx["op"][s], flags)
         elif ing == 1:
-            r, t = be.step("point", fx["xy"][s], fx["op"][s])
+            r, t = be.step("point", fx["xy"][s], fx["op"][s], flags)
         else:
-            r, t = be.step("mask", fx["masks"][mask_idx[s]], fx["op"][s])
+            r, t = be.step("mask", fx["masks"][mask_idx[s]], fx["op"][s], flags)
         if not np.array_equal(r, fx["reward"][s]):
             errs.append(f"{name} step {s}: reward {r.tolist()} != {fx['reward'][s].tolist()}")
         if not np.array_equal(t, fx["term"][s]):

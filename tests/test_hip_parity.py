@@ -28,12 +28,17 @@ def _gpu():
 def test_hip_matches_golden(name):
     errs = B.replay_fixture(B.HipBackend, name)
     assert not errs, "\n".join(errs[:10])
+    fx = B.load_fixture(name)
+    if fx["meta"]["kind"] == "o2arc" and B.can_elide(fx["meta"]["ops"]):
+        # the same vectors with ARCLE_STEP_ELIDE_SELECTED (what ARCVecEnv and bench.py pass): identical states
+        errs = B.replay_fixture(B.HipBackend, name, flags=B.STEP_ELIDE_SELECTED)
+        assert not errs, "elide: " + "\n".join(errs[:10])
 
 
 @pytest.mark.parametrize("H,W", [(30, 30), (10, 10), (5, 5), (3, 3), (7, 12), (12, 7), (32, 32), (1, 17), (20, 1),
                                  (16, 16), (2, 100), (15, 17)])
 def test_hip_vs_oracle_o2arc(H, W):
-    for flags in (0, O.STEP_AUTORESET):
+    for flags in (0, O.STEP_AUTORESET, B.STEP_ELIDE_SELECTED, O.STEP_AUTORESET | B.STEP_ELIDE_SELECTED):
         errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), H, W, N=96, S=96, seed=H * 100 + W + flags,
                                       max_trial=3 if flags else -1, flags=flags, op_weights=OBJ_HEAVY, bad_ops=True)
         assert not errs, "\n".join(errs[:10])
@@ -89,7 +94,7 @@ def _full_size_run(N, S, seed, sample):
     bb, oo = torch.from_numpy(bbox).cuda(), torch.from_numpy(op).cuda()
     rewards = np.zeros((S, N), np.int32)
     for s in range(S):
-        r, t = b.step_bbox(bb[s], oo[s])
+        r, t = b.step_bbox(bb[s], oo[s], b.elide_flag)  # the flags bench.py / ARCVecEnv use
         rewards[s] = r.cpu().numpy()
     torch.cuda.synchronize()
     assert b.status() == 0

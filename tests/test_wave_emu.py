@@ -16,9 +16,16 @@ def test_emulated_kernel_matches_golden(name):
     assert not errs, "\n".join(errs[:10])
 
 
+@pytest.mark.parametrize("name", ["o2arc_30", "o2arc_10", "quirks_30", "o2arc_crop_10"])
+def test_emulated_kernel_matches_golden_with_selected_elision(name):
+    """ARCLE_STEP_ELIDE_SELECTED (skip the redundant zero-fill of `selected` for inactive envs) changes no state."""
+    errs = B.replay_fixture(B.EmuBackend, name, max_steps=96, flags=B.STEP_ELIDE_SELECTED)
+    assert not errs, "\n".join(errs[:10])
+
+
 @pytest.mark.parametrize("H,W", [(30, 30), (10, 10), (5, 5), (3, 3), (7, 12), (12, 7), (32, 32), (1, 17), (20, 1), (16, 16)])
 def test_emulated_kernel_vs_oracle_o2arc(H, W):
-    for flags in (0, O.STEP_AUTORESET):
+    for flags in (0, O.STEP_AUTORESET, B.STEP_ELIDE_SELECTED, O.STEP_AUTORESET | B.STEP_ELIDE_SELECTED):
         errs = B.random_trace_compare(B.EmuBackend, "o2arc", O.o2arc_ops(), H, W, N=6, S=40, seed=H * 100 + W + flags,
                                       max_trial=3 if flags else -1, flags=flags, op_weights=OBJ_HEAVY, bad_ops=True)
         assert not errs, "\n".join(errs[:10])
