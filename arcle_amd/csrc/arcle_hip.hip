@@ -47,6 +47,10 @@ ARCLE_DEV void store16(int8_t* ptr, const V& v) {
   asm volatile("global_store_dwordx4 %0, %1, off " ARCLE_STORE_POLICY "\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 // pins independent loads above the first branch so that they share one latency window
+ARCLE_DEV uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz constant clock
+// neighbouring lane's value through DPP wave shifts (no LDS): lane j-1 / lane j+1, 0 at the wave boundary
+ARCLE_DEV uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+ARCLE_DEV uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 ARCLE_DEV void keep1(uint32_t& a) { asm volatile("" : "+v"(a)); }
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 template <class V>
@@ -444,8 +448,8 @@ extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void*
 extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   if (!e) return ARCLE_ERR_ARG;
   if (on && !e->d_acct) {
-    HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 4));
-    HIP_TRY(e, hipMemset(e->d_acct, 0, (size_t)e->cfg.n_envs * 4));
+    HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 16));
+    HIP_TRY(e, hipMemset(e->d_acct, 0, (size_t)e->cfg.n_envs * 16));
     e->acct_steps = 0;
   } else if (!on && e->d_acct) {
     HIP_TRY(e, hipDeviceSynchronize());
@@ -454,6 +458,15 @@ extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   }
   return ARCLE_OK;
 }
+
+#ifdef ARCLE_TRACE_WAVES
+extern "C" int arcle_debug_copy_trace(arcle_env* e, uint64_t* host_out) {  // diagnostic builds only
+  if (!e || !e->d_acct) return ARCLE_ERR_ARG;
+  HIP_TRY(e, hipDeviceSynchronize());
+  HIP_TRY(e, hipMemcpy(host_out, e->d_acct, (size_t)e->cfg.n_envs * 16, hipMemcpyDeviceToHost));
+  return ARCLE_OK;
+}
+#endif
 
 extern "C" int arcle_get_accounting(arcle_env* e, uint64_t* bytes, uint64_t* steps, int clear, void* stream) {
   if (!e || !bytes || !steps) return ARCLE_ERR_ARG;

@@ -694,13 +694,32 @@ ARCLE_DEV void op_floodfill(const Wave& w, Planes& s, const Rec& r, const Sel& s
   uint32_t notfirst = to32(w, w.rect16(0, p.H - 1, 1, p.W - 1));
   uint32_t notlast = to32(w, w.rect16(0, p.H - 1, 0, p.W - 2));
   uint32_t F = (w.lane == (seed >> 5)) ? (1u << (seed & 31)) : 0u;
-  for (int it = 0; it < ARCLE_MAX_CELLS; it++) {
-    uint32_t grow = (board_shl(w, F, 1) & notfirst) | (board_shr(w, F, 1) & notlast) | board_shl(w, F, p.W) |
-                    board_shr(w, F, p.W);
-    uint32_t Fn = F | (grow & M);
-    bool changed = w.any(Fn != F);
-    F = Fn;
-    if (!changed) break;
+  if (w.fastw) {
+    // 16 <= W <= 32: every neighbour shift (1 or W bits) only needs the adjacent lanes' words, fetched with two DPP
+    // wave shifts per propagation step (no LDS round trip); 4 steps per convergence ballot (the closure is monotone,
+    // extra steps are harmless)
+    const uint32_t Wb = (uint32_t)p.W;
+    for (int it = 0; it < ARCLE_MAX_CELLS / 4 + 1; it++) {
+      const uint32_t F0 = F;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t prev = xl::lane_prev(F), next = xl::lane_next(F);  // lane j-1 / j+1, 0 outside the wave
+        const uint32_t l1 = (F << 1) | (prev >> 31), r1 = (F >> 1) | (next << 31);
+        const uint32_t lW = (Wb == 32) ? prev : ((F << Wb) | (prev >> (32 - Wb)));
+        const uint32_t rW = (Wb == 32) ? next : ((F >> Wb) | (next << (32 - Wb)));
+        F |= ((l1 & notfirst) | (r1 & notlast) | lW | rW) & M;
+      }
+      if (!w.any(F != F0)) break;
+    }
+  } else {
+    for (int it = 0; it < ARCLE_MAX_CELLS; it++) {
+      uint32_t grow = (board_shl(w, F, 1) & notfirst) | (board_shr(w, F, 1) & notlast) | board_shl(w, F, p.W) |
+                      board_shr(w, F, p.W);
+      uint32_t Fn = F | (grow & M);
+      bool changed = w.any(Fn != F);
+      F = Fn;
+      if (!changed) break;
+    }
   }
   uint32_t vis = to16(w, F);
   s.grid = u4_sel(expand16(vis), u4_splat((uint32_t)color), s.grid);
@@ -1121,6 +1140,9 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
 
 template <int ING, int FW>
 ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
+#ifdef ARCLE_TRACE_WAVES  // diagnostic build: per-wave start/end shader clocks into the acct buffer (as uint64[N][2])
+  const uint64_t t_start = xl::clock();
+#endif
   Wave w(p, lds, env, lane, ING, FW);
   // ---- one latency window: record, op index, counters and the selection payload are independent loads ----
   U4 rv = *reinterpret_cast<const U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES);
@@ -1141,7 +1163,15 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     *reinterpret_cast<I2*>(p.cnt + 2 * (size_t)env) = cnt0;
     p.reward[env] = out.reward;
     p.term[env] = (uint8_t)out.term;
+#ifdef ARCLE_TRACE_WAVES
+    if (p.acct) {
+      uint64_t* tr = reinterpret_cast<uint64_t*>(p.acct) + 2 * (size_t)env;
+      tr[0] = t_start;
+      tr[1] = xl::clock();
+    }
+#else
     if (p.acct) p.acct[env] += out.bytes;
+#endif
   }
 }
 

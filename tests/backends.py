@@ -524,3 +524,68 @@ def rollout_compare(backend_cls, kind, ops, H, W, N, T, seed, ingress="bbox", fl
     if be.status() != orc.status():
         errs.append("status flags differ")
     return errs
+
+
+def spiral_grid(H, W):
+    """A 1-cell-wide spiral corridor of colour 1 in a field of colour 2 (worst case for frontier flood fill: the
+    region's graph diameter is ~H*W/2 cells)."""
+    g = np.full((H, W), 2, np.int8)
+    i, j, d = 0, 0, 0
+    dirs = [(0, 1), (1, 0), (0, -1), (-1, 0)]
+    g[0, 0] = 1
+
+    def free(a, b_):  # inside and not next to an older part of the corridor
+        return 0 <= a < H and 0 <= b_ < W and g[a, b_] == 2
+
+    turns = 0
+    while turns < 2:
+        di, dj = dirs[d]
+        ni, nj = i + di, j + dj
+        n2i, n2j = ni + di, nj + dj
+        ok = free(ni, nj) and (not (0 <= n2i < H and 0 <= n2j < W) or g[n2i, n2j] == 2)
+        if ok:  # also keep one cell of field between parallel arms
+            li, lj = ni + dirs[(d + 3) % 4][0], nj + dirs[(d + 3) % 4][1]
+            if 0 <= li < H and 0 <= lj < W and g[li, lj] == 1 and (li, lj) != (i, j):
+                ok = False
+        if ok:
+            i, j = ni, nj
+            g[i, j] = 1
+            turns = 0
+        else:
+            d = (d + 1) % 4
+            turns += 1
+    return g
+
+
+def floodfill_worst_case_compare(backend_cls, H, W):
+    """FloodFill from both ends of a spiral corridor, from the field around it, and on a uniform grid (full-board
+    region), point / 1x1-bbox / mask ingress; backend vs oracle."""
+    g = spiral_grid(H, W)
+    ones = np.argwhere(g == 1)
+    seeds = [tuple(ones[0]), tuple(ones[-1]), tuple(np.argwhere(g == 2)[0]), (H - 1, W - 1), (H // 2, W // 2)]
+    N = len(seeds) * 2
+    ops = O.o2arc_ops()
+    be, orc = backend_cls(N, H, W, -1, "o2arc", ops), OracleBackend(N, H, W, -1, "o2arc", ops)
+    inp = np.stack([g] * len(seeds) + [np.full((H, W), 3, np.int8)] * len(seeds))
+    dims = np.tile(np.array([[H, W]], np.int8), (N, 1))
+    for b_ in (be, orc):
+        b_.set_tasks(inp, dims, inp, dims)
+        b_.reset()
+    xy = np.array(seeds * 2, np.int32)
+    errs = []
+    for step, (ing, op) in enumerate((("point", 15), ("bbox", 17), ("mask", 10))):
+        if ing == "point":
+            pay = xy
+        elif ing == "bbox":
+            pay = np.concatenate([xy, xy], 1)
+        else:
+            pay = np.zeros((N, H, W), np.int8)
+            pay[np.arange(N), xy[:, 0], xy[:, 1]] = 1
+        opv = np.full(N, op, np.int32)
+        be.step(ing, pay, opv)
+        orc.step(ing, pay, opv)
+        if not np.array_equal(be.get("grid"), orc.get("grid")):
+            errs.append(f"{H}x{W} FloodFill step {step} ({ing}): grid differs for envs "
+                        f"{np.nonzero((be.get('grid') != orc.get('grid')).reshape(N, -1).any(1))[0].tolist()}")
+    assert int((orc.get("grid")[0] == 0).sum()) > H  # the corridor really was filled
+    return errs

@@ -66,6 +66,17 @@ ARCLE_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 ARCLE_DEV void lds_fence() { yield(7); }
 ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 ARCLE_DEV int lds_idx(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }  // host memory: stay inside the tile
+ARCLE_DEV uint64_t clock() { return 0; }
+ARCLE_DEV uint32_t lane_prev(uint32_t v) {
+  int me = cur_lane;
+  uint32_t r = shfl(v, (me + 63) & 63);
+  return me == 0 ? 0u : r;
+}
+ARCLE_DEV uint32_t lane_next(uint32_t v) {
+  int me = cur_lane;
+  uint32_t r = shfl(v, (me + 1) & 63);
+  return me == 63 ? 0u : r;
+}
 ARCLE_DEV void keep1(uint32_t&) {}
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return shfl(v, lane); }
 template <class V>

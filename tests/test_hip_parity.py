@@ -69,6 +69,13 @@ def test_hip_floodfill_stress():
     assert not errs, "\n".join(errs[:10])
 
 
+@pytest.mark.parametrize("H,W", [(30, 30), (32, 32), (17, 21), (12, 12), (6, 40), (16, 16), (31, 33)])
+def test_hip_floodfill_worst_case(H, W):
+    """Spiral corridor (graph diameter ~H*W/2) and full-board regions: the frontier loop must converge exactly."""
+    errs = B.floodfill_worst_case_compare(B.HipBackend, H, W)
+    assert not errs, "\n".join(errs)
+
+
 def _full_size_run(N, S, seed, sample):
     """Runs N envs for S bbox steps on the GPU; returns the final state of the `sample` envs + everything needed
     to re-run just those envs elsewhere."""

@@ -69,3 +69,9 @@ def test_emulated_rollout_other_kinds():
     for kind, ops in (("arc", O.arc_ops()), ("raw", O.raw_ops())):
         errs = B.rollout_compare(B.EmuBackend, kind, ops, 30, 30, N=4, T=30, seed=9)
         assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("H,W", [(30, 30), (32, 32), (17, 21), (12, 12), (6, 40)])
+def test_emulated_floodfill_worst_case(H, W):
+    errs = B.floodfill_worst_case_compare(B.EmuBackend, H, W)
+    assert not errs, "\n".join(errs)

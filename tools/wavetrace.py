@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic (needs gpurun_lib_trace.so built with -DARCLE_TRACE_WAVES, ARCLE_HIP_LIB pointing at it): per-wave
+start/end timestamps (100 MHz realtime clock) of ONE launch of the C3 mix -> dispatch ramp, per-op lifetimes, tail."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from arcle_amd import actions, _lib
+from arcle_amd.engine import EnvBatch
+from arcle_amd.envs import O2ARCv2Env
+dev = torch.device("cuda:0"); n = 8192; K = 40
+b = EnvBatch(n, 30, 30, -1, "o2arc", dev)
+b.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
+b.set_tasks_padded(*bench.make_tasks(n, 1)); b.reset()
+bn, on = bench.make_actions(K, n, 5)
+bb, oo = torch.from_numpy(bn).to(dev), torch.from_numpy(on).to(dev)
+b.enable_accounting(True)
+L = _lib.lib()
+L.arcle_debug_copy_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+names = ["".join(map(str.capitalize, o.__name__.split("_"))) for o in O2ARCv2Env.default_operations()]
+cls = {"color": range(0, 10), "floodfill": range(10, 20), "move": range(20, 24), "rot/flip": range(24, 28),
+       "copy/paste": range(28, 31), "critical": range(31, 34), "submit": [34]}
+for rep in range(3):
+    for i in range(K - 1):
+        b.step_bbox(bb[i], oo[i], b.elide_flag)
+    torch.cuda.synchronize()
+    b.step_bbox(bb[K - 1], oo[K - 1], b.elide_flag)
+    tr = np.zeros((n, 2), np.uint64)
+    assert L.arcle_debug_copy_trace(b._h, tr.ctypes.data) == 0
+    t0 = tr[:, 0].min()
+    st = (tr[:, 0] - t0).astype(np.float64) / 100.0  # us
+    en = (tr[:, 1] - t0).astype(np.float64) / 100.0
+    life = en - st
+    ops = on[K - 1]
+    print(f"rep {rep}: first start 0, last start {st.max():.2f} us, last end {en.max():.2f} us; lifetime mean {life.mean():.2f} "
+          f"p50 {np.median(life):.2f} p90 {np.percentile(life,90):.2f} max {life.max():.2f}")
+    print("   start percentiles (us): " + " ".join(f"p{q}={np.percentile(st,q):.2f}" for q in (10, 50, 90, 99)))
+    print("   end   percentiles (us): " + " ".join(f"p{q}={np.percentile(en,q):.2f}" for q in (10, 50, 90, 99)))
+    for k, r in cls.items():
+        m = np.isin(ops, list(r))
+        print(f"   {k:10s} n={m.sum():5d} lifetime mean {life[m].mean():5.2f} p90 {np.percentile(life[m],90):5.2f}  end mean {en[m].mean():5.2f} max {en[m].max():5.2f}")
