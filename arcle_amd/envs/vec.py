@@ -67,7 +67,10 @@ class ARCVecEnv:
         b = self.batch
         return {"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
                 "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1],
-                "task_index": self.task_index, "subprob_index": self.subprob_index}
+                # host copies of the last explicit reset()'s choice; `table_index` (device, entry of the task table)
+                # also follows autoreset="resample"
+                "task_index": self.task_index, "subprob_index": self.subprob_index,
+                "table_index": getattr(self, "table_index", None)}
 
     # ---- reset: task choice vectorised on the host (no per-env Python), grids come from the device task table ----
     def _build_task_table(self):
@@ -120,6 +123,8 @@ class ARCVecEnv:
             p = np.where(keep, self.task_index, p)
             s_ = np.where(keep, self.subprob_index, s_)
         self.task_index, self.subprob_index = np.asarray(p).copy(), np.asarray(s_).copy()
+        prev = getattr(self, "table_index", None)
+        self.table_index = idx if (mask is None or prev is None) else torch.where(mask.bool(), idx, prev)
         self.batch.reset_from_table(idx, mask)
         return self._obs, self._info()
 
@@ -131,7 +136,9 @@ class ARCVecEnv:
         cnt = self._dev_cnt[ad][p]
         s_ = (torch.rand(self.N, device=self.device, generator=self._gen) * cnt).long()
         s_ = torch.minimum(s_, cnt - 1)
-        self.batch.reset_from_table((self._dev_off[ad][p] + s_).int(), term)
+        idx = (self._dev_off[ad][p] + s_).int()
+        self.table_index = torch.where(term.bool(), idx, self.table_index)
+        self.batch.reset_from_table(idx, term)
 
     # ---- step ------------------------------------------------------------------------------------------
     def _ret(self, reward, term):

@@ -216,7 +216,7 @@ def test_vec_env_reset_and_resample_autoreset():
 @pytest.mark.parametrize("H,W,ingress", [(30, 30, "bbox"), (10, 10, "bbox"), (30, 30, "point"), (5, 7, "bbox"), (16, 24, "bbox")])
 def test_hip_rollout_equals_sequential_steps(H, W, ingress):
     """arcle_rollout_* (T steps in one launch, planes resident in registers) == T oracle steps."""
-    for flags in (0, O.STEP_AUTORESET):
+    for flags in (0, O.STEP_AUTORESET, B.STEP_ELIDE_SELECTED):
         errs = B.rollout_compare(B.HipBackend, "o2arc", O.o2arc_ops(), H, W, N=160, T=64, seed=H + W + flags,
                                  ingress=ingress, flags=flags)
         assert not errs, "\n".join(errs[:10])

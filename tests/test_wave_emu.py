@@ -59,7 +59,7 @@ def test_emulated_reset_from_task_table(H, W):
 
 @pytest.mark.parametrize("H,W,ingress", [(30, 30, "bbox"), (10, 10, "bbox"), (30, 30, "point"), (5, 7, "bbox")])
 def test_emulated_rollout_equals_sequential_steps(H, W, ingress):
-    for flags in (0, O.STEP_AUTORESET):
+    for flags in (0, O.STEP_AUTORESET, B.STEP_ELIDE_SELECTED):
         errs = B.rollout_compare(B.EmuBackend, "o2arc", O.o2arc_ops(), H, W, N=6, T=40, seed=H + W + flags,
                                  ingress=ingress, flags=flags)
         assert not errs, "\n".join(errs[:10])
