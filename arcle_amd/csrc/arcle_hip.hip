@@ -77,20 +77,22 @@ __device__ __forceinline__ int env_of_wave(const StepParams& p) {
 }
 
 // ING: selection ingress form; FW: 1 = launched only for 16 <= W <= 32 (fast rectangle masks), 0 = any W
-template <int ING, int FW>
+// TBL: arcle::TBL_O2ARC / _ARC / _RAW when the installed op table is the canonical one of that env class (descriptor
+//      computed in registers), arcle::TBL_LOOKUP for any other table
+template <int ING, int FW, int TBL>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(80))) void arcle_step_kernel(const StepParams p) {
   __shared__ WaveLDS lds[WAVES_PER_WG];
   const int env = env_of_wave(p);
   if (env >= p.n_envs) return;
-  arcle::wave_step<ING, FW>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_step<ING, FW, TBL>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
 }
 
-template <int ING, int FW>
+template <int ING, int FW, int TBL>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams p) {
   __shared__ WaveLDS lds[WAVES_PER_WG];
   const int env = env_of_wave(p);
   if (env >= p.n_envs) return;
-  arcle::wave_rollout<ING, FW>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_rollout<ING, FW, TBL>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_flatten_kernel(const StepParams p) {
@@ -125,6 +127,7 @@ struct arcle_env {
   uint32_t* d_status;
   uint32_t* d_ops;
   uint32_t ops_host[ARCLE_MAX_OPS];
+  int canonical;  // arcle::TBL_*: the installed table equals a canonical one
   uint32_t* d_acct;
   uint64_t acct_steps;
   int device;
@@ -255,6 +258,36 @@ extern "C" int arcle_get_buffers(const arcle_env* e, arcle_buffers* out) {
   return ARCLE_OK;
 }
 
+// which canonical table (if any) the descriptors are: must match arcle::decode_op<> exactly
+static int canonical_table(const uint32_t* d, int n) {
+  auto D = [](int k, int a, int f) { return ARCLE_OP_DESC(k, a, f); };
+  const uint32_t R = ARCLE_OPF_RESET_SEL;
+  bool colors_r = n >= 20, colors = n >= 10, floods = n >= 20;
+  for (int i = 0; i < 10 && i < n; i++) {
+    colors_r = colors_r && d[i] == D(ARCLE_OP_COLOR, i, R);
+    colors = colors && d[i] == D(ARCLE_OP_COLOR, i, 0);
+  }
+  for (int i = 10; i < 20 && i < n; i++) {
+    colors_r = colors_r && d[i] == D(ARCLE_OP_FLOODFILL, i - 10, R);
+    floods = floods && d[i] == D(ARCLE_OP_FLOODFILL, i - 10, 0);
+  }
+  if (n == 35 && colors_r) {
+    const uint32_t t[15] = {D(ARCLE_OP_MOVE, 0, 0), D(ARCLE_OP_MOVE, 1, 0), D(ARCLE_OP_MOVE, 2, 0), D(ARCLE_OP_MOVE, 3, 0),
+                            D(ARCLE_OP_ROTATE, 1, 0), D(ARCLE_OP_ROTATE, 3, 0), D(ARCLE_OP_FLIP, 0, 0), D(ARCLE_OP_FLIP, 1, 0),
+                            D(ARCLE_OP_COPY, 0, R), D(ARCLE_OP_COPY, 1, R), D(ARCLE_OP_PASTE, 1, R),
+                            D(ARCLE_OP_COPY_FROM_INPUT, 0, R), D(ARCLE_OP_RESET_GRID, 0, R), D(ARCLE_OP_RESIZE_GRID, 0, R),
+                            D(ARCLE_OP_SUBMIT, 0, 0)};
+    if (!memcmp(d + 20, t, sizeof t)) return arcle::TBL_O2ARC;
+  }
+  if (n == 27 && colors && floods) {
+    const uint32_t t[7] = {D(ARCLE_OP_COPY, 0, 0), D(ARCLE_OP_COPY, 1, 0), D(ARCLE_OP_PASTE, 1, 0), D(ARCLE_OP_COPY_FROM_INPUT, 0, 0),
+                           D(ARCLE_OP_RESET_GRID, 0, 0), D(ARCLE_OP_RESIZE_GRID, 0, 0), D(ARCLE_OP_SUBMIT, 0, 0)};
+    if (!memcmp(d + 20, t, sizeof t)) return arcle::TBL_ARC;
+  }
+  if (n == 12 && colors && d[10] == D(ARCLE_OP_RESIZE_TO_ANSWER, 0, 0) && d[11] == D(ARCLE_OP_SUBMIT, 0, 0)) return arcle::TBL_RAW;
+  return arcle::TBL_LOOKUP;
+}
+
 extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n_ops) {
   if (!e || !descs) return ARCLE_ERR_ARG;
   if (n_ops <= 0 || n_ops > ARCLE_MAX_OPS) return fail(e, ARCLE_ERR_CONFIG, "n_ops out of range");
@@ -278,6 +311,7 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
   memcpy(e->ops_host, descs, sizeof(uint32_t) * (size_t)n_ops);
   HIP_TRY(e, hipMemcpy(e->d_ops, e->ops_host, sizeof(e->ops_host), hipMemcpyHostToDevice));  // synchronous
   e->base.n_ops = n_ops;
+  e->canonical = canonical_table(e->ops_host, n_ops);
   return ARCLE_OK;
 }
 
@@ -346,12 +380,21 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   const bool fw = p.W >= 16 && p.W <= 32;
   const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
   hipStream_t st = (hipStream_t)stream;
-#define ARCLE_LAUNCH(ING)                                                              \
-  do {                                                                                 \
-    if (fw)                                                                            \
-      hipLaunchKernelGGL((arcle_step_kernel<ING, 1>), g, b, 0, st, p);                 \
-    else                                                                               \
-      hipLaunchKernelGGL((arcle_step_kernel<ING, 0>), g, b, 0, st, p);                 \
+#define ARCLE_LAUNCH2(ING, FWV)                                                                      \
+  do {                                                                                               \
+    switch (e->canonical) {                                                                          \
+      case arcle::TBL_O2ARC: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_O2ARC>), g, b, 0, st, p); break; \
+      case arcle::TBL_ARC: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_ARC>), g, b, 0, st, p); break;     \
+      case arcle::TBL_RAW: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_RAW>), g, b, 0, st, p); break;     \
+      default: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_LOOKUP>), g, b, 0, st, p); break;              \
+    }                                                                                                \
+  } while (0)
+#define ARCLE_LAUNCH(ING)        \
+  do {                           \
+    if (fw)                      \
+      ARCLE_LAUNCH2(ING, 1);     \
+    else                         \
+      ARCLE_LAUNCH2(ING, 0);     \
   } while (0)
   if (ingress == arcle::INGRESS_BBOX)
     ARCLE_LAUNCH(arcle::INGRESS_BBOX);
@@ -359,6 +402,7 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     ARCLE_LAUNCH(arcle::INGRESS_POINT);
   else
     ARCLE_LAUNCH(arcle::INGRESS_MASK);
+#undef ARCLE_LAUNCH2
 #undef ARCLE_LAUNCH
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
@@ -396,13 +440,20 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   const bool fw = p.W >= 16 && p.W <= 32;
   const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
   hipStream_t st = (hipStream_t)stream;
+  const bool o2 = e->canonical == arcle::TBL_O2ARC;  // the other tables use the lookup instantiation here
+#define ARCLE_RL(ING, FWV)                                                                                     \
+  do {                                                                                                         \
+    if (o2) hipLaunchKernelGGL((arcle_rollout_kernel<ING, FWV, arcle::TBL_O2ARC>), g, b, 0, st, p);            \
+    else hipLaunchKernelGGL((arcle_rollout_kernel<ING, FWV, arcle::TBL_LOOKUP>), g, b, 0, st, p);              \
+  } while (0)
   if (ingress == arcle::INGRESS_BBOX) {
-    if (fw) hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_BBOX, 1>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_BBOX, 0>), g, b, 0, st, p);
+    if (fw) ARCLE_RL(arcle::INGRESS_BBOX, 1);
+    else ARCLE_RL(arcle::INGRESS_BBOX, 0);
   } else {
-    if (fw) hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_POINT, 1>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_POINT, 0>), g, b, 0, st, p);
+    if (fw) ARCLE_RL(arcle::INGRESS_POINT, 1);
+    else ARCLE_RL(arcle::INGRESS_POINT, 0);
   }
+#undef ARCLE_RL
   HIP_TRY(e, hipGetLastError());
   return ARCLE_OK;
 }
@@ -448,8 +499,8 @@ extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void*
 extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   if (!e) return ARCLE_ERR_ARG;
   if (on && !e->d_acct) {
-    HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 16));
-    HIP_TRY(e, hipMemset(e->d_acct, 0, (size_t)e->cfg.n_envs * 16));
+    HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 64));
+    HIP_TRY(e, hipMemset(e->d_acct, 0, (size_t)e->cfg.n_envs * 64));
     e->acct_steps = 0;
   } else if (!on && e->d_acct) {
     HIP_TRY(e, hipDeviceSynchronize());
@@ -463,7 +514,7 @@ extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
 extern "C" int arcle_debug_copy_trace(arcle_env* e, uint64_t* host_out) {  // diagnostic builds only
   if (!e || !e->d_acct) return ARCLE_ERR_ARG;
   HIP_TRY(e, hipDeviceSynchronize());
-  HIP_TRY(e, hipMemcpy(host_out, e->d_acct, (size_t)e->cfg.n_envs * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(e, hipMemcpy(host_out, e->d_acct, (size_t)e->cfg.n_envs * 64, hipMemcpyDeviceToHost));
   return ARCLE_OK;
 }
 #endif

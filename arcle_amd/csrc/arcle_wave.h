@@ -180,6 +180,9 @@ struct Wave {
   bool resident;
   mutable U4 cache[ARCLE_N_PLANES];
   mutable uint32_t dirty;  // planes of `cache` that differ from HBM
+#ifdef ARCLE_TRACE_WAVES
+  mutable uint64_t t_desc, t_sel;
+#endif
   int ingress;    // INGRESS_* (a compile-time constant of the kernel instantiation)
   uint32_t poff;  // byte offset of this lane's 16 cells inside a plane: env*PS + 16*lane (< 4 GiB, checked at create)
 
@@ -816,6 +819,51 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, int env, int 
 // ------------------------------------------------------------------------------------------------
 // one step() of one env:  O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step / RawARCEnv.step
 // ------------------------------------------------------------------------------------------------
+// Descriptor of slot `op` for the three canonical tables, computed in scalar registers instead of fetched: the
+// table lookup is a dependent scalar load on every wave's critical path (~0.5 us measured), and these tables are
+// what O2ARCv2Env / ARCEnv / RawARCEnv install (o2arcenv.py:88-113, arcenv.py:123-137, arcenv.py:26-41).  The host
+// selects the instantiation only when the installed table equals the canonical one; any other table uses the lookup.
+enum { TBL_LOOKUP = 0, TBL_O2ARC = 1, TBL_ARC = 2, TBL_RAW = 3 };
+
+ARCLE_DEV uint32_t packed_slot(uint64_t lo, uint64_t hi, int i) {  // 8-bit fields: kind | arg << 4 | flags << 6
+  const uint64_t w = (i < 8) ? lo : hi;
+  const uint32_t f = (uint32_t)(w >> (8 * (i & 7))) & 0xffu;
+  return ARCLE_OP_DESC(f & 0xfu, (f >> 4) & 0x3u, f >> 6);
+}
+#define ARCLE_PK(kind, arg, flags) ((uint64_t)((kind) | ((arg) << 4) | ((flags) << 6)))
+#define ARCLE_PK8(a, b, c, d, e, f, g, h) \
+  ((a) | ((b) << 8) | ((c) << 16) | ((d) << 24) | ((e) << 32) | ((f) << 40) | ((g) << 48) | ((h) << 56))
+
+template <int TBL>
+ARCLE_DEV uint32_t decode_op(const StepParams& p, int op) {
+  if (TBL == TBL_O2ARC) {  // 0-9 Color|R, 10-19 FloodFill|R, 20.. below
+    if (op < 10) return ARCLE_OP_DESC(ARCLE_OP_COLOR, op, ARCLE_OPF_RESET_SEL);
+    if (op < 20) return ARCLE_OP_DESC(ARCLE_OP_FLOODFILL, op - 10, ARCLE_OPF_RESET_SEL);
+    const uint64_t lo = ARCLE_PK8(ARCLE_PK(ARCLE_OP_MOVE, 0, 0), ARCLE_PK(ARCLE_OP_MOVE, 1, 0), ARCLE_PK(ARCLE_OP_MOVE, 2, 0),
+                                  ARCLE_PK(ARCLE_OP_MOVE, 3, 0), ARCLE_PK(ARCLE_OP_ROTATE, 1, 0), ARCLE_PK(ARCLE_OP_ROTATE, 3, 0),
+                                  ARCLE_PK(ARCLE_OP_FLIP, 0, 0), ARCLE_PK(ARCLE_OP_FLIP, 1, 0));
+    const uint64_t hi = ARCLE_PK8(ARCLE_PK(ARCLE_OP_COPY, 0, 1), ARCLE_PK(ARCLE_OP_COPY, 1, 1), ARCLE_PK(ARCLE_OP_PASTE, 1, 1),
+                                  ARCLE_PK(ARCLE_OP_COPY_FROM_INPUT, 0, 1), ARCLE_PK(ARCLE_OP_RESET_GRID, 0, 1),
+                                  ARCLE_PK(ARCLE_OP_RESIZE_GRID, 0, 1), ARCLE_PK(ARCLE_OP_SUBMIT, 0, 0), (uint64_t)0);
+    return packed_slot(lo, hi, op - 20);
+  }
+  if (TBL == TBL_ARC) {
+    if (op < 10) return ARCLE_OP_DESC(ARCLE_OP_COLOR, op, 0);
+    if (op < 20) return ARCLE_OP_DESC(ARCLE_OP_FLOODFILL, op - 10, 0);
+    const uint64_t lo = ARCLE_PK8(ARCLE_PK(ARCLE_OP_COPY, 0, 0), ARCLE_PK(ARCLE_OP_COPY, 1, 0), ARCLE_PK(ARCLE_OP_PASTE, 1, 0),
+                                  ARCLE_PK(ARCLE_OP_COPY_FROM_INPUT, 0, 0), ARCLE_PK(ARCLE_OP_RESET_GRID, 0, 0),
+                                  ARCLE_PK(ARCLE_OP_RESIZE_GRID, 0, 0), ARCLE_PK(ARCLE_OP_SUBMIT, 0, 0), (uint64_t)0);
+    return packed_slot(lo, 0, op - 20);
+  }
+  if (TBL == TBL_RAW) {
+    if (op < 10) return ARCLE_OP_DESC(ARCLE_OP_COLOR, op, 0);
+    return op == 10 ? ARCLE_OP_DESC(ARCLE_OP_RESIZE_TO_ANSWER, 0, 0) : ARCLE_OP_DESC(ARCLE_OP_SUBMIT, 0, 0);
+  }
+  // any other table: scalar load through the constant cache (a per-lane vector fetch of the 256 B table hot-spots one
+  // L2 channel)
+  return p.d_ops[op];
+}
+
 struct StepOut {
   int reward;      // 0/1
   bool term;       // bool(state['terminated'])
@@ -825,7 +873,7 @@ struct StepOut {
 // Everything of step() between "record/op/payload are in registers" and "record/counters/outputs go back to
 // memory": autoreset, op decode, the operation itself, reward.  Planes are read/written through w.load/w.store, so
 // the same code serves the single-step kernel (HBM) and the rollout kernel (register-resident planes).
-template <int ING, int FW>
+template <int ING, int FW, int TBL>
 ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, const int op) {
   const StepParams& p = w.p;
   const int P = p.P, W = p.W, lane = w.lane;
@@ -839,10 +887,11 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     return out;
   }
   bool bad_op = op < 0 || op >= p.n_ops;
-  // scalar load through the constant cache (all waves read the same 256 B table: a per-lane vector fetch of it
-  // hot-spots one L2 channel — measured +0.5 us per launch)
-  const uint32_t desc = bad_op ? 0u : p.d_ops[op];
+  const uint32_t desc = bad_op ? 0u : decode_op<TBL>(p, op);
   if (!bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
+#ifdef ARCLE_TRACE_WAVES
+  w.t_desc = xl::clock();
+#endif
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
     if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
@@ -863,6 +912,9 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   Sel sel;
   ingest_selection(w, sel, payload);
   if (w.ingress == INGRESS_MASK) s.bytes += P;
+#ifdef ARCLE_TRACE_WAVES
+  w.t_sel = xl::clock();
+#endif
 
   const Rec r_before = r;
   if (oflags & ARCLE_OPF_RESET_SEL) {  // object.py:20-25
@@ -1138,7 +1190,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   return out;
 }
 
-template <int ING, int FW>
+template <int ING, int FW, int TBL>
 ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
 #ifdef ARCLE_TRACE_WAVES  // diagnostic build: per-wave start/end shader clocks into the acct buffer (as uint64[N][2])
   const uint64_t t_start = xl::clock();
@@ -1155,8 +1207,13 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
   Rec r;
   rec_unpack(rv, r);
   const int op = (int)xl::uniform(opv);
-
-  StepOut out = step_core<ING, FW>(w, r, cnt0, payload, op);
+#ifdef ARCLE_TRACE_WAVES
+  const uint64_t t_win1 = xl::clock();  // first latency window complete
+#endif
+  StepOut out = step_core<ING, FW, TBL>(w, r, cnt0, payload, op);
+#ifdef ARCLE_TRACE_WAVES
+  const uint64_t t_core = xl::clock();  // op applied, plane stores issued
+#endif
   // ---- epilogue: record, counters and the step outputs --------------------------------------------
   if (lane == 0) {
     *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rec_pack(r);
@@ -1165,9 +1222,13 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
     p.term[env] = (uint8_t)out.term;
 #ifdef ARCLE_TRACE_WAVES
     if (p.acct) {
-      uint64_t* tr = reinterpret_cast<uint64_t*>(p.acct) + 2 * (size_t)env;
+      uint64_t* tr = reinterpret_cast<uint64_t*>(p.acct) + 8 * (size_t)env;
       tr[0] = t_start;
-      tr[1] = xl::clock();
+      tr[1] = t_win1;
+      tr[2] = t_core;
+      tr[3] = xl::clock();
+      tr[4] = w.t_desc;
+      tr[5] = w.t_sel;
     }
 #else
     if (p.acct) p.acct[env] += out.bytes;
@@ -1183,7 +1244,7 @@ ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
 //   sel: int32 [n_steps][n_envs][4|2]   op: int32 [n_steps][n_envs]
 //   reward: int32 [n_steps][n_envs]     term: uint8 [n_steps][n_envs]
 // ------------------------------------------------------------------------------------------------
-template <int ING, int FW>
+template <int ING, int FW, int TBL>
 ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, int env, int lane) {
   Wave w(p, lds, env, lane, ING, FW);
 #pragma unroll
@@ -1202,7 +1263,7 @@ ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, int env, int lane
       next_payload = load_payload(w, (size_t)t + 1);
       next_op = (uint32_t)p.op[((size_t)t + 1) * N + env];
     }
-    const StepOut out = step_core<ING, FW>(w, r, cnt, payload, op);
+    const StepOut out = step_core<ING, FW, TBL>(w, r, cnt, payload, op);
     if (lane == 0) {
       p.reward[(size_t)t * N + env] = out.reward;
       p.term[(size_t)t * N + env] = (uint8_t)out.term;

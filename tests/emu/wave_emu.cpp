@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 
 #define ARCLE_DEV inline
 
@@ -94,27 +95,42 @@ int g_env, g_kind;
 char* g_stacks;
 const size_t STACK = 256 * 1024;
 
+int g_tbl;  // arcle::TBL_* of the installed table (emu_run compares it with the canonical decoders)
+
+#define RUN_STEP(I, F)                                                                        \
+  do {                                                                                        \
+    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_step<I, F, arcle::TBL_O2ARC>(*g_p, &g_lds, g_env, lane);   \
+    else if (g_tbl == arcle::TBL_ARC) arcle::wave_step<I, F, arcle::TBL_ARC>(*g_p, &g_lds, g_env, lane);  \
+    else if (g_tbl == arcle::TBL_RAW) arcle::wave_step<I, F, arcle::TBL_RAW>(*g_p, &g_lds, g_env, lane);  \
+    else arcle::wave_step<I, F, arcle::TBL_LOOKUP>(*g_p, &g_lds, g_env, lane);                            \
+  } while (0)
+#define RUN_ROLL(I, F)                                                                        \
+  do {                                                                                        \
+    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_rollout<I, F, arcle::TBL_O2ARC>(*g_p, &g_lds, g_env, lane); \
+    else arcle::wave_rollout<I, F, arcle::TBL_LOOKUP>(*g_p, &g_lds, g_env, lane);                          \
+  } while (0)
+
 void lane_main(int lane) {
   xl::cur_lane = lane;
   const bool fw = g_p->W >= 16 && g_p->W <= 32;
   if (g_kind == 0) {
     switch (g_p->ingress * 2 + (fw ? 1 : 0)) {  // the same instantiations the HIP library launches
-      case 0: arcle::wave_step<0, 0>(*g_p, &g_lds, g_env, lane); break;
-      case 1: arcle::wave_step<0, 1>(*g_p, &g_lds, g_env, lane); break;
-      case 2: arcle::wave_step<1, 0>(*g_p, &g_lds, g_env, lane); break;
-      case 3: arcle::wave_step<1, 1>(*g_p, &g_lds, g_env, lane); break;
-      case 4: arcle::wave_step<2, 0>(*g_p, &g_lds, g_env, lane); break;
-      default: arcle::wave_step<2, 1>(*g_p, &g_lds, g_env, lane); break;
+      case 0: RUN_STEP(0, 0); break;
+      case 1: RUN_STEP(0, 1); break;
+      case 2: RUN_STEP(1, 0); break;
+      case 3: RUN_STEP(1, 1); break;
+      case 4: RUN_STEP(2, 0); break;
+      default: RUN_STEP(2, 1); break;
     }
   }
   else if (g_kind == 2)
     arcle::wave_reset_table(*g_p, &g_lds, g_env, lane);
   else if (g_kind == 3) {
     switch (g_p->ingress * 2 + (fw ? 1 : 0)) {
-      case 2: arcle::wave_rollout<1, 0>(*g_p, &g_lds, g_env, lane); break;
-      case 3: arcle::wave_rollout<1, 1>(*g_p, &g_lds, g_env, lane); break;
-      case 4: arcle::wave_rollout<2, 0>(*g_p, &g_lds, g_env, lane); break;
-      default: arcle::wave_rollout<2, 1>(*g_p, &g_lds, g_env, lane); break;
+      case 2: RUN_ROLL(1, 0); break;
+      case 3: RUN_ROLL(1, 1); break;
+      case 4: RUN_ROLL(2, 0); break;
+      default: RUN_ROLL(2, 1); break;
     }
   }
   else
@@ -176,6 +192,21 @@ extern "C" int emu_run(int kind, arcle::StepParams* p) {
   if (!g_stacks) g_stacks = (char*)malloc(64 * STACK);
   g_p = p;
   g_kind = kind;
+  // canonical-table detection, the same rule libarcle_hip uses: the table must equal what decode_op<TBL> computes
+  g_tbl = arcle::TBL_LOOKUP;
+  if (p->d_ops) {
+    for (int t : {arcle::TBL_O2ARC, arcle::TBL_ARC, arcle::TBL_RAW}) {
+      const int n = t == arcle::TBL_O2ARC ? 35 : t == arcle::TBL_ARC ? 27 : 12;
+      bool same = p->n_ops == n;
+      for (int i = 0; same && i < n; i++) {
+        uint32_t d = t == arcle::TBL_O2ARC ? arcle::decode_op<arcle::TBL_O2ARC>(*p, i)
+                   : t == arcle::TBL_ARC   ? arcle::decode_op<arcle::TBL_ARC>(*p, i)
+                                           : arcle::decode_op<arcle::TBL_RAW>(*p, i);
+        same = d == p->d_ops[i];
+      }
+      if (same) g_tbl = t;
+    }
+  }
   xl::error_flag = 0;
   for (int env = 0; env < p->n_envs; env++) {
     g_env = env;

@@ -25,17 +25,24 @@ for rep in range(3):
         b.step_bbox(bb[i], oo[i], b.elide_flag)
     torch.cuda.synchronize()
     b.step_bbox(bb[K - 1], oo[K - 1], b.elide_flag)
-    tr = np.zeros((n, 2), np.uint64)
+    tr = np.zeros((n, 8), np.uint64)
     assert L.arcle_debug_copy_trace(b._h, tr.ctypes.data) == 0
     t0 = tr[:, 0].min()
     st = (tr[:, 0] - t0).astype(np.float64) / 100.0  # us
-    en = (tr[:, 1] - t0).astype(np.float64) / 100.0
+    en = (tr[:, 3] - t0).astype(np.float64) / 100.0
+    w1 = (tr[:, 1] - tr[:, 0]).astype(np.float64) / 100.0   # start -> first window complete
+    core = (tr[:, 2] - tr[:, 1]).astype(np.float64) / 100.0  # op application (incl. plane loads, stores issued)
+    epi = (tr[:, 3] - tr[:, 2]).astype(np.float64) / 100.0
+    dsc = (tr[:, 4] - tr[:, 1]).astype(np.float64) / 100.0   # window1 done -> op descriptor decoded
+    sel_ = (tr[:, 5] - tr[:, 4]).astype(np.float64) / 100.0  # descriptor -> selection masks built
+    print(f"   core split (us): descriptor fetch mean {dsc.mean():.2f} p90 {np.percentile(dsc,90):.2f} | selection ingest mean {sel_.mean():.2f}")
     life = en - st
     ops = on[K - 1]
     print(f"rep {rep}: first start 0, last start {st.max():.2f} us, last end {en.max():.2f} us; lifetime mean {life.mean():.2f} "
           f"p50 {np.median(life):.2f} p90 {np.percentile(life,90):.2f} max {life.max():.2f}")
     print("   start percentiles (us): " + " ".join(f"p{q}={np.percentile(st,q):.2f}" for q in (10, 50, 90, 99)))
     print("   end   percentiles (us): " + " ".join(f"p{q}={np.percentile(en,q):.2f}" for q in (10, 50, 90, 99)))
+    print(f"   phases (us): window1 mean {w1.mean():.2f} p90 {np.percentile(w1,90):.2f} | core mean {core.mean():.2f} p90 {np.percentile(core,90):.2f} | epilogue mean {epi.mean():.2f}")
     for k, r in cls.items():
         m = np.isin(ops, list(r))
-        print(f"   {k:10s} n={m.sum():5d} lifetime mean {life[m].mean():5.2f} p90 {np.percentile(life[m],90):5.2f}  end mean {en[m].mean():5.2f} max {en[m].max():5.2f}")
+        print(f"   {k:10s} n={m.sum():5d} lifetime mean {life[m].mean():5.2f} p90 {np.percentile(life[m],90):5.2f}  end mean {en[m].mean():5.2f} max {en[m].max():5.2f}  | win1 {w1[m].mean():4.2f} core {core[m].mean():4.2f} epi {epi[m].mean():4.2f}")
