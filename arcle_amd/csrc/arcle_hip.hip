@@ -51,6 +51,10 @@ ARCLE_DEV uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 
 // neighbouring lane's value through DPP wave shifts (no LDS): lane j-1 / lane j+1, 0 at the wave boundary
 ARCLE_DEV uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 ARCLE_DEV uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+template <class T>
+ARCLE_DEV void pin_ptr(T*& x) { asm volatile("" : "+s"(x)); }
+ARCLE_DEV void pin_u32(uint32_t& x) { asm volatile("" : "+s"(x)); }
+ARCLE_DEV void pin_i32(int32_t& x) { asm volatile("" : "+s"(x)); }
 ARCLE_DEV void keep1(uint32_t& a) { asm volatile("" : "+v"(a)); }
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 template <class V>

@@ -1191,7 +1191,23 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
 }
 
 template <int ING, int FW, int TBL>
-ARCLE_DEV void wave_step(const StepParams& p, WaveLDS* lds, int env, int lane) {
+ARCLE_DEV void wave_step(const StepParams& p_in, WaveLDS* lds, int env, int lane) {
+  // fetch every kernel argument the step needs in one burst at wave start (instead of lazily, one cold constant-cache
+  // miss at a time along the critical path) and keep them in SGPRs: 8.3 -> 7.8 us per launch
+  StepParams p = p_in;
+#pragma unroll
+  for (int i = 0; i < ARCLE_N_PLANES; i++) xl::pin_ptr(p.plane[i]);
+  xl::pin_ptr(p.reward);
+  xl::pin_ptr(p.term);
+  xl::pin_ptr(p.acct);
+  xl::pin_ptr(p.status);
+  xl::pin_u32(p.flags);
+  xl::pin_i32(p.H);
+  xl::pin_i32(p.W);
+  xl::pin_i32(p.P);
+  xl::pin_i32(p.PS);
+  xl::pin_i32(p.n_ops);
+  xl::pin_u32(p.div_magic);
 #ifdef ARCLE_TRACE_WAVES  // diagnostic build: per-wave start/end shader clocks into the acct buffer (as uint64[N][2])
   const uint64_t t_start = xl::clock();
 #endif

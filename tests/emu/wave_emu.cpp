@@ -78,6 +78,10 @@ ARCLE_DEV uint32_t lane_next(uint32_t v) {
   uint32_t r = shfl(v, (me + 1) & 63);
   return me == 63 ? 0u : r;
 }
+template <class T>
+ARCLE_DEV void pin_ptr(T*&) {}
+ARCLE_DEV void pin_u32(uint32_t&) {}
+ARCLE_DEV void pin_i32(int32_t&) {}
 ARCLE_DEV void keep1(uint32_t&) {}
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return shfl(v, lane); }
 template <class V>
