@@ -13,11 +13,11 @@ LIB_PATH = os.environ.get("ARCLE_HIP_LIB") or os.path.join(_CSRC, "libarcle_hip.
 SOURCES = [os.path.join(_CSRC, "arcle_hip.hip"), os.path.join(_CSRC, "arcle_wave.h"),
            os.path.join(_CSRC, "..", "..", "include", "arcle_hip.h")]
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 N_PLANES = 8
 MAX_OPS = 64
 EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buffers", "arcle_set_op_table",
-           "arcle_can_elide_selected", "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table", "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_flat_obs_size", "arcle_flatten_obs", "arcle_get_status",
+           "arcle_can_elide_selected", "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table", "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation", "arcle_flat_obs_size", "arcle_flatten_obs", "arcle_get_status",
            "arcle_enable_accounting", "arcle_get_accounting", "arcle_last_error"]
 
 
@@ -27,7 +27,7 @@ class ArcleHipError(RuntimeError):
 
 class Config(ctypes.Structure):
     _fields_ = [("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
-                ("max_trial", ctypes.c_int32), ("device", ctypes.c_int32)]
+                ("max_trial", ctypes.c_int32), ("device", ctypes.c_int32), ("plane_stride", ctypes.c_int32)]
 
 
 class Buffers(ctypes.Structure):
@@ -74,7 +74,8 @@ def lib():
     L.arcle_reset_from_table.argtypes = [vp, vp, vp, vp]
     for name in ("arcle_step_mask", "arcle_step_bbox", "arcle_step_point"):
         getattr(L, name).argtypes = [vp, vp, vp, vp, vp, u32, vp]
-    for name in ("arcle_rollout_bbox", "arcle_rollout_point"):
+    L.arcle_set_truncation.argtypes = [vp, vp, i32]
+    for name in ("arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask"):
         getattr(L, name).argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
     L.arcle_flat_obs_size.argtypes = [vp]
     L.arcle_flatten_obs.argtypes = [vp, vp, vp]

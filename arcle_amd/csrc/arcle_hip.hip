@@ -16,8 +16,13 @@
 #include <new>
 
 #define ARCLE_DEV __device__ __forceinline__
+#define ARCLE_HD __host__ __device__ __forceinline__
 
-namespace xl {  // cross-lane primitives of one 64-lane wavefront
+namespace xl {  // cross-lane / memory primitives of one 64-lane wavefront
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+#define ARCLE_AS_GLOBAL __attribute__((address_space(1)))
+#define ARCLE_AS_CONST __attribute__((address_space(4)))
 ARCLE_DEV uint32_t shfl(uint32_t v, int src_lane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
@@ -29,38 +34,54 @@ ARCLE_DEV void lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+ARCLE_DEV void wg_barrier() { __syncthreads(); }
+// a wavefront executes in lock step: nothing to do (the CPU emulator runs lanes as fibers and needs a rendezvous here)
+ARCLE_DEV void lanes_converged() {}
 ARCLE_DEV void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 // LDS reads outside the workgroup's allocation return 0 and reads inside it but outside this wave's tile
 // return bytes every caller masks away, so tile indices are not clamped on the GPU
 ARCLE_DEV int lds_idx(int i, int /*n*/) { return i; }
+// Wave-uniform loads of per-env scalars (record, op index, counters, bbox / point payload): the address is uniform and
+// the location is not written by anyone else during the launch, so they go through the scalar cache straight into
+// SGPRs (s_load_dword[x2|x4]) — no VGPRs, no v_readfirstlane, handled by the scalar ALU afterwards.
+ARCLE_DEV uint32_t uload1(const void* p) { return *reinterpret_cast<const ARCLE_AS_CONST uint32_t*>((uintptr_t)p); }
+ARCLE_DEV U2 uload2(const void* p) { return *reinterpret_cast<const ARCLE_AS_CONST U2*>((uintptr_t)p); }
+ARCLE_DEV U4 uload4(const void* p) { return *reinterpret_cast<const ARCLE_AS_CONST U4*>((uintptr_t)p); }
+// 16 B plane load: SGPR base + 32-bit VGPR byte offset (global_load_dwordx4 v, v_off, s[base])
+ARCLE_DEV U4 load16(const int8_t* base, uint32_t off) {
+  return *reinterpret_cast<const ARCLE_AS_GLOBAL U4*>((uintptr_t)base + off);
+}
 // 16 B plane store, write-through (`sc1`): the planes written by a step are only read again by the NEXT launch,
 // and per-XCD L2s are written back at every kernel boundary anyway; writing through lets that traffic overlap
-// the kernel instead of being flushed at its end.  Measured on the C3 mix (profiles/round1_store_policy_ab.txt):
-// plain 11.46 us, nt 11.08, sc0 11.40, sc1 9.98, sc0 sc1 10.03, sc1 nt 11.80 per launch.
+// the kernel instead of being flushed at its end (profiles/round1_store_policy_ab.txt: plain 11.46 us, nt 11.08,
+// sc1 9.98 per launch of the C3 mix).  For state far beyond the 256 MiB Infinity Cache `nt` streams better
+// (tools/membench.hip, N = 131072: nt 43 us vs sc1 62 us), selectable at build time.
 // The trailing s_nop covers the ">64-bit VMEM store data" hazard: hipcc's hazard recogniser does not see into
 // inline asm and may overwrite the data VGPRs in the very next instruction (it did: parity caught it).
 #ifndef ARCLE_STORE_POLICY
 #define ARCLE_STORE_POLICY "sc1"
 #endif
-template <class V>
-ARCLE_DEV void store16(int8_t* ptr, const V& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off " ARCLE_STORE_POLICY "\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+// The leading s_nop 4 covers "VALU writes an SGPR (v_readlane of a spilled pointer, v_readfirstlane) -> VMEM reads it as
+// saddr" (5 wait states on gfx9): for its own instructions the compiler inserts them, inside inline asm it cannot — the
+// register-starved rollout instantiations reloaded the plane pointer with v_readlane right before the store and wrote to
+// a stale address (GPU memory fault; tools/dbg_rollout.py).  It only idles this wave's issue slot.
+ARCLE_DEV void store16(int8_t* base, uint32_t off, const U4& v) {
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 " ARCLE_STORE_POLICY "\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
-// pins independent loads above the first branch so that they share one latency window
 ARCLE_DEV uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz constant clock
 // neighbouring lane's value through DPP wave shifts (no LDS): lane j-1 / lane j+1, 0 at the wave boundary
 ARCLE_DEV uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 ARCLE_DEV uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
-template <class T>
-ARCLE_DEV void pin_ptr(T*& x) { asm volatile("" : "+s"(x)); }
-ARCLE_DEV void pin_u32(uint32_t& x) { asm volatile("" : "+s"(x)); }
-ARCLE_DEV void pin_i32(int32_t& x) { asm volatile("" : "+s"(x)); }
-ARCLE_DEV void keep1(uint32_t& a) { asm volatile("" : "+v"(a)); }
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
-template <class V>
-ARCLE_DEV void keep(V& a, V& b, uint32_t& c, int32_t& d) {
-  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }  // full-rate 24-bit multiply
+ARCLE_DEV uint32_t opaque(uint32_t v) {  // hides a value's origin from the optimiser (no instruction)
+  asm volatile("" : "+v"(v));
+  return v;
 }
+// "these scalar-loaded values are needed now": one s_waitcnt for all of them instead of one per first use, and it keeps
+// the compiler from sinking some of the loads below a branch on another (a second dependent latency)
+ARCLE_DEV void arrived(U4& a, U2& b, uint32_t& c, U4& d) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)); }
+ARCLE_DEV void arrived3(U4& a, U2& b, uint32_t& c) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c)); }
 }  // namespace xl
 
 #include "arcle_wave.h"
@@ -72,57 +93,86 @@ using arcle::WaveLDS;
 #define ARCLE_WAVES_PER_WG 4
 #endif
 static constexpr int WAVES_PER_WG = ARCLE_WAVES_PER_WG;
+typedef arcle::BlockLDS<WAVES_PER_WG> BlockLDS;
 
-__device__ __forceinline__ int env_of_wave(const StepParams& p) {
-  const uint32_t nb = gridDim.x, b = blockIdx.x;          // nb is a multiple of 8
-  const uint32_t vb = (b & 7u) * (nb >> 3) + (b >> 3);    // XCD-contiguous env ranges
-  const int env = (int)(vb * WAVES_PER_WG + (threadIdx.x >> 6));
-  return __builtin_amdgcn_readfirstlane(env);
+// wave index of the launch with XCD-contiguous ranges: workgroup b runs on XCD b%8 (observed), so
+// vb = (b&7)*(nb/8) + (b>>3) gives each XCD one contiguous range of waves (affinity only)
+__device__ __forceinline__ int wave_of_launch() {
+  const uint32_t nb = gridDim.x, b = blockIdx.x;  // nb is a multiple of 8
+  const uint32_t vb = (b & 7u) * (nb >> 3) + (b >> 3);
+  return __builtin_amdgcn_readfirstlane((int)(vb * WAVES_PER_WG + (threadIdx.x >> 6)));
 }
 
-// ING: selection ingress form; FW: 1 = launched only for 16 <= W <= 32 (fast rectangle masks), 0 = any W
-// TBL: arcle::TBL_O2ARC / _ARC / _RAW when the installed op table is the canonical one of that env class (descriptor
-//      computed in registers), arcle::TBL_LOOKUP for any other table
-template <int ING, int FW, int TBL>
+// ING: selection ingress form; FW: arcle::FW_* grid-width class; TBL: arcle::TBL_O2ARC when the installed op table is
+// the canonical O2ARCv2Env one (descriptor computed in registers), arcle::TBL_LOOKUP for any other table;
+// ACCT: 1 = add the step's algorithmic bytes to p.acct[env]
+template <int ING, int FW, int TBL, int ACCT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(80))) void arcle_step_kernel(const StepParams p) {
-  __shared__ WaveLDS lds[WAVES_PER_WG];
-  const int env = env_of_wave(p);
-  if (env >= p.n_envs) return;
-  arcle::wave_step<ING, FW, TBL>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  __shared__ BlockLDS lds;
+#ifdef ARCLE_TRACE_WAVES
+  const uint64_t t_entry = xl::clock();
+#endif
+  const int wv = wave_of_launch();
+  const bool valid = wv < p.n_envs;  // (every wave of the workgroup reaches the barrier below)
+  const int env = valid ? wv : 0;
+  arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false);
+  arcle::StepInputs in = arcle::load_inputs<ING>(w, env);  // in flight while the expansion table is built
+  arcle::lut_init(lds.lut, (int)threadIdx.x, 64 * WAVES_PER_WG);
+  xl::wg_barrier();
+  if (!valid) return;
+#ifdef ARCLE_TRACE_WAVES
+  arcle::wave_step<ING, FW, TBL, ACCT>(w, env, in, t_entry, xl::clock());
+#else
+  arcle::wave_step<ING, FW, TBL, ACCT>(w, env, in);
+#endif
 }
 
 template <int ING, int FW, int TBL>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams p) {
-  __shared__ WaveLDS lds[WAVES_PER_WG];
-  const int env = env_of_wave(p);
+  __shared__ BlockLDS lds;
+  arcle::lut_init(lds.lut, (int)threadIdx.x, 64 * WAVES_PER_WG);
+  xl::wg_barrier();
+  const int env = wave_of_launch();
   if (env >= p.n_envs) return;
-  arcle::wave_rollout<ING, FW, TBL>(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_rollout<ING, FW, TBL>(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_flatten_kernel(const StepParams p) {
-  __shared__ WaveLDS lds[WAVES_PER_WG];
-  const int env = env_of_wave(p);
+  __shared__ BlockLDS lds;
+  const int env = wave_of_launch();
   if (env >= p.n_envs) return;
-  arcle::wave_flatten(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_flatten(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const StepParams p) {
-  __shared__ WaveLDS lds[WAVES_PER_WG];
-  const int env = env_of_wave(p);
+  __shared__ BlockLDS lds;
+  const int env = wave_of_launch();
   if (env >= p.n_envs) return;
-  arcle::wave_reset(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_reset(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_table_kernel(const StepParams p) {
-  __shared__ WaveLDS lds[WAVES_PER_WG];
-  const int env = env_of_wave(p);
+  __shared__ BlockLDS lds;
+  const int env = wave_of_launch();
   if (env >= p.n_envs) return;
-  arcle::wave_reset_table(p, &lds[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_reset_table(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side: the C ABI
 // ------------------------------------------------------------------------------------------------
+// entry points run on the handle's device and leave the caller's current device untouched
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 struct arcle_env {
   arcle_config cfg;
   arcle_buffers bufs;
@@ -161,7 +211,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   *out = nullptr;
   if (cfg->n_envs <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->H > 127 || cfg->W > 127 ||
       cfg->H * cfg->W > ARCLE_MAX_CELLS || cfg->max_trial < -128 || cfg->max_trial > 127 ||
-      (uint64_t)cfg->n_envs * (uint64_t)((cfg->H * cfg->W + 15) & ~15) >= (1ull << 32))  // 32-bit plane offsets
+      (uint64_t)cfg->n_envs * (uint64_t)ARCLE_MAX_CELLS >= (1ull << 32))  // 32-bit plane offsets
     return ARCLE_ERR_CONFIG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ARCLE_ERR_NO_DEVICE;
@@ -169,19 +219,24 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   if (!e) return ARCLE_ERR_ARG;
   memset(e, 0, sizeof(*e));
   e->cfg = *cfg;
-  if (cfg->device >= 0) {
-    if (cfg->device >= ndev || hipSetDevice(cfg->device) != hipSuccess) {
-      delete e;
-      return ARCLE_ERR_NO_DEVICE;
-    }
+  int caller_dev = 0;
+  (void)hipGetDevice(&caller_dev);
+  e->device = cfg->device >= 0 ? cfg->device : caller_dev;
+  if (e->device >= ndev) {
+    delete e;
+    return ARCLE_ERR_NO_DEVICE;
   }
-  hipGetDevice(&e->device);
+  DeviceGuard guard(e->device);  // allocations below land on the handle's device; the caller's device is restored
   StepParams& b = e->base;
   b.n_envs = cfg->n_envs;
   b.H = cfg->H;
   b.W = cfg->W;
   b.P = cfg->H * cfg->W;
-  b.PS = (b.P + 15) & ~15;
+  b.PS = cfg->plane_stride ? cfg->plane_stride : ARCLE_DEFAULT_PLANE_STRIDE(b.P);
+  if ((b.PS & 15) || b.PS < b.P || b.PS > ARCLE_MAX_CELLS) {
+    delete e;
+    return ARCLE_ERR_CONFIG;
+  }
   b.max_trial = cfg->max_trial;
   b.div_magic = 65536u / (uint32_t)cfg->W + 1u;
   for (uint32_t n = 0; n < ARCLE_MAX_CELLS + 16; n++)  // flat cell indices the kernel divides
@@ -243,6 +298,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
 
 extern "C" int arcle_destroy(arcle_env* e) {
   if (!e) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
   if (e->owns_bufs) {
     for (int i = 0; i < ARCLE_N_PLANES; i++)
       if (e->bufs.plane[i]) (void)hipFree(e->bufs.plane[i]);
@@ -262,38 +318,17 @@ extern "C" int arcle_get_buffers(const arcle_env* e, arcle_buffers* out) {
   return ARCLE_OK;
 }
 
-// which canonical table (if any) the descriptors are: must match arcle::decode_op<> exactly
+// is the table the canonical O2ARCv2Env one (o2arcenv.py:88-113)?  Must match arcle::decode_op<TBL_O2ARC> exactly.
 static int canonical_table(const uint32_t* d, int n) {
-  auto D = [](int k, int a, int f) { return ARCLE_OP_DESC(k, a, f); };
-  const uint32_t R = ARCLE_OPF_RESET_SEL;
-  bool colors_r = n >= 20, colors = n >= 10, floods = n >= 20;
-  for (int i = 0; i < 10 && i < n; i++) {
-    colors_r = colors_r && d[i] == D(ARCLE_OP_COLOR, i, R);
-    colors = colors && d[i] == D(ARCLE_OP_COLOR, i, 0);
-  }
-  for (int i = 10; i < 20 && i < n; i++) {
-    colors_r = colors_r && d[i] == D(ARCLE_OP_FLOODFILL, i - 10, R);
-    floods = floods && d[i] == D(ARCLE_OP_FLOODFILL, i - 10, 0);
-  }
-  if (n == 35 && colors_r) {
-    const uint32_t t[15] = {D(ARCLE_OP_MOVE, 0, 0), D(ARCLE_OP_MOVE, 1, 0), D(ARCLE_OP_MOVE, 2, 0), D(ARCLE_OP_MOVE, 3, 0),
-                            D(ARCLE_OP_ROTATE, 1, 0), D(ARCLE_OP_ROTATE, 3, 0), D(ARCLE_OP_FLIP, 0, 0), D(ARCLE_OP_FLIP, 1, 0),
-                            D(ARCLE_OP_COPY, 0, R), D(ARCLE_OP_COPY, 1, R), D(ARCLE_OP_PASTE, 1, R),
-                            D(ARCLE_OP_COPY_FROM_INPUT, 0, R), D(ARCLE_OP_RESET_GRID, 0, R), D(ARCLE_OP_RESIZE_GRID, 0, R),
-                            D(ARCLE_OP_SUBMIT, 0, 0)};
-    if (!memcmp(d + 20, t, sizeof t)) return arcle::TBL_O2ARC;
-  }
-  if (n == 27 && colors && floods) {
-    const uint32_t t[7] = {D(ARCLE_OP_COPY, 0, 0), D(ARCLE_OP_COPY, 1, 0), D(ARCLE_OP_PASTE, 1, 0), D(ARCLE_OP_COPY_FROM_INPUT, 0, 0),
-                           D(ARCLE_OP_RESET_GRID, 0, 0), D(ARCLE_OP_RESIZE_GRID, 0, 0), D(ARCLE_OP_SUBMIT, 0, 0)};
-    if (!memcmp(d + 20, t, sizeof t)) return arcle::TBL_ARC;
-  }
-  if (n == 12 && colors && d[10] == D(ARCLE_OP_RESIZE_TO_ANSWER, 0, 0) && d[11] == D(ARCLE_OP_SUBMIT, 0, 0)) return arcle::TBL_RAW;
-  return arcle::TBL_LOOKUP;
+  if (n != 35) return arcle::TBL_LOOKUP;
+  for (int i = 0; i < n; i++)
+    if (d[i] != arcle::o2arc_desc(i)) return arcle::TBL_LOOKUP;
+  return arcle::TBL_O2ARC;
 }
 
 extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n_ops) {
   if (!e || !descs) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
   if (n_ops <= 0 || n_ops > ARCLE_MAX_OPS) return fail(e, ARCLE_ERR_CONFIG, "n_ops out of range");
   for (int i = 0; i < n_ops; i++) {
     const uint32_t k = ARCLE_OP_KIND(descs[i]), f = ARCLE_OP_FLAGS(descs[i]), a = ARCLE_OP_ARG(descs[i]);
@@ -344,6 +379,7 @@ static dim3 grid_for(int n_envs);
 
 extern "C" int arcle_reset_from_table(arcle_env* e, const int32_t* task_idx, const uint8_t* mask, void* stream) {
   if (!e || !task_idx) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
   if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
   StepParams p = e->base;
   p.rmask = mask;
@@ -361,6 +397,7 @@ static dim3 grid_for(int n_envs) {
 
 extern "C" int arcle_reset(arcle_env* e, const uint8_t* mask, void* stream) {
   if (!e) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.rmask = mask;
   hipLaunchKernelGGL(arcle_reset_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
@@ -368,10 +405,45 @@ extern "C" int arcle_reset(arcle_env* e, const uint8_t* mask, void* stream) {
   return ARCLE_OK;
 }
 
+// ---- instantiation dispatch: (ingress, width class, table, accounting) -> kernel ----------------------------------
+static int width_class(const StepParams& p) {
+  if (p.W < 16 || p.W > 32) return arcle::FW_GENERIC;
+  return p.PS == ARCLE_MAX_CELLS ? arcle::FW_FULL : arcle::FW_FAST;
+}
+#ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiation exists (seconds instead of a minute)
+template <int ING>
+static int launch_step_ing(int, int, bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL) return ARCLE_ERR_CONFIG;
+  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 1>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 0>), g, b, 0, st, p);
+  return ARCLE_OK;
+}
+#else
+template <int ING, int FW, int TBL>
+static void launch_step_acct(bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 1>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 0>), g, b, 0, st, p);
+}
+template <int ING, int FW>
+static void launch_step_tbl(int tbl, bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (tbl == arcle::TBL_O2ARC) launch_step_acct<ING, FW, arcle::TBL_O2ARC>(acct, g, b, st, p);
+  else launch_step_acct<ING, FW, arcle::TBL_LOOKUP>(acct, g, b, st, p);
+}
+template <int ING>
+static int launch_step_ing(int fw, int tbl, bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (fw == arcle::FW_FULL) launch_step_tbl<ING, arcle::FW_FULL>(tbl, acct, g, b, st, p);
+  else if (fw == arcle::FW_FAST) launch_step_tbl<ING, arcle::FW_FAST>(tbl, acct, g, b, st, p);
+  else launch_step_tbl<ING, arcle::FW_GENERIC>(tbl, acct, g, b, st, p);
+  return ARCLE_OK;
+}
+#endif
+
 static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t* op, int32_t* reward, uint8_t* term,
                        uint32_t flags, void* stream) {
   if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
+  if ((flags & ARCLE_STEP_TRUNCATE) && !e->base.trunc) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_TRUNCATE without arcle_set_truncation");
+  DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.ingress = ingress;
   p.sel = sel;
@@ -381,33 +453,15 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.flags = flags;
   p.acct = e->d_acct;
   p.rmask = nullptr;
-  const bool fw = p.W >= 16 && p.W <= 32;
   const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
   hipStream_t st = (hipStream_t)stream;
-#define ARCLE_LAUNCH2(ING, FWV)                                                                      \
-  do {                                                                                               \
-    switch (e->canonical) {                                                                          \
-      case arcle::TBL_O2ARC: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_O2ARC>), g, b, 0, st, p); break; \
-      case arcle::TBL_ARC: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_ARC>), g, b, 0, st, p); break;     \
-      case arcle::TBL_RAW: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_RAW>), g, b, 0, st, p); break;     \
-      default: hipLaunchKernelGGL((arcle_step_kernel<ING, FWV, arcle::TBL_LOOKUP>), g, b, 0, st, p); break;              \
-    }                                                                                                \
-  } while (0)
-#define ARCLE_LAUNCH(ING)        \
-  do {                           \
-    if (fw)                      \
-      ARCLE_LAUNCH2(ING, 1);     \
-    else                         \
-      ARCLE_LAUNCH2(ING, 0);     \
-  } while (0)
-  if (ingress == arcle::INGRESS_BBOX)
-    ARCLE_LAUNCH(arcle::INGRESS_BBOX);
-  else if (ingress == arcle::INGRESS_POINT)
-    ARCLE_LAUNCH(arcle::INGRESS_POINT);
-  else
-    ARCLE_LAUNCH(arcle::INGRESS_MASK);
-#undef ARCLE_LAUNCH2
-#undef ARCLE_LAUNCH
+  const int fw = width_class(p), tbl = e->canonical;
+  const bool acct = e->d_acct != nullptr;
+  int rc;
+  if (ingress == arcle::INGRESS_BBOX) rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, tbl, acct, g, b, st, p);
+  else if (ingress == arcle::INGRESS_POINT) rc = launch_step_ing<arcle::INGRESS_POINT>(fw, tbl, acct, g, b, st, p);
+  else rc = launch_step_ing<arcle::INGRESS_MASK>(fw, tbl, acct, g, b, st, p);
+  if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
   return ARCLE_OK;
@@ -426,11 +480,31 @@ extern "C" int arcle_step_point(arcle_env* e, const int32_t* xy, const int32_t* 
   return launch_step(e, arcle::INGRESS_POINT, xy, op, reward, term, flags, stream);
 }
 
+#ifdef ARCLE_FAST_BUILD
+template <int ING>
+static int launch_rollout_ing(int, int, dim3, dim3, hipStream_t, const StepParams&) { return ARCLE_ERR_CONFIG; }
+#else
+template <int ING, int FW>
+static void launch_rollout_tbl(int tbl, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (tbl == arcle::TBL_O2ARC) hipLaunchKernelGGL((arcle_rollout_kernel<ING, FW, arcle::TBL_O2ARC>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_rollout_kernel<ING, FW, arcle::TBL_LOOKUP>), g, b, 0, st, p);
+}
+template <int ING>
+static int launch_rollout_ing(int fw, int tbl, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  // (the rollout keeps planes in registers: lane predication does not matter, FW_FULL shares FW_FAST's code)
+  if (fw != arcle::FW_GENERIC) launch_rollout_tbl<ING, arcle::FW_FAST>(tbl, g, b, st, p);
+  else launch_rollout_tbl<ING, arcle::FW_GENERIC>(tbl, g, b, st, p);
+  return ARCLE_OK;
+}
+#endif
+
 static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
                           uint8_t* term, uint32_t flags, void* stream) {
   if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
   if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
+  if (flags & ~(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED)) return fail(e, ARCLE_ERR_ARG, "flag not supported by the rollout kernels");
+  DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.ingress = ingress;
   p.sel = sel;
@@ -441,23 +515,14 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   p.acct = nullptr;
   p.rmask = nullptr;
   p.n_steps = n_steps;
-  const bool fw = p.W >= 16 && p.W <= 32;
   const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
   hipStream_t st = (hipStream_t)stream;
-  const bool o2 = e->canonical == arcle::TBL_O2ARC;  // the other tables use the lookup instantiation here
-#define ARCLE_RL(ING, FWV)                                                                                     \
-  do {                                                                                                         \
-    if (o2) hipLaunchKernelGGL((arcle_rollout_kernel<ING, FWV, arcle::TBL_O2ARC>), g, b, 0, st, p);            \
-    else hipLaunchKernelGGL((arcle_rollout_kernel<ING, FWV, arcle::TBL_LOOKUP>), g, b, 0, st, p);              \
-  } while (0)
-  if (ingress == arcle::INGRESS_BBOX) {
-    if (fw) ARCLE_RL(arcle::INGRESS_BBOX, 1);
-    else ARCLE_RL(arcle::INGRESS_BBOX, 0);
-  } else {
-    if (fw) ARCLE_RL(arcle::INGRESS_POINT, 1);
-    else ARCLE_RL(arcle::INGRESS_POINT, 0);
-  }
-#undef ARCLE_RL
+  const int fw = width_class(p), tbl = e->canonical;
+  int rc;
+  if (ingress == arcle::INGRESS_BBOX) rc = launch_rollout_ing<arcle::INGRESS_BBOX>(fw, tbl, g, b, st, p);
+  else if (ingress == arcle::INGRESS_POINT) rc = launch_rollout_ing<arcle::INGRESS_POINT>(fw, tbl, g, b, st, p);
+  else rc = launch_rollout_ing<arcle::INGRESS_MASK>(fw, tbl, g, b, st, p);
+  if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no rollout kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   return ARCLE_OK;
 }
@@ -469,6 +534,18 @@ extern "C" int arcle_rollout_bbox(arcle_env* e, int32_t n_steps, const int32_t* 
 extern "C" int arcle_rollout_point(arcle_env* e, int32_t n_steps, const int32_t* xy, const int32_t* op, int32_t* reward,
                                    uint8_t* term, uint32_t flags, void* stream) {
   return launch_rollout(e, arcle::INGRESS_POINT, n_steps, xy, op, reward, term, flags, stream);
+}
+extern "C" int arcle_rollout_mask(arcle_env* e, int32_t n_steps, const int8_t* sel, const int32_t* op, int32_t* reward,
+                                  uint8_t* term, uint32_t flags, void* stream) {
+  return launch_rollout(e, arcle::INGRESS_MASK, n_steps, sel, op, reward, term, flags, stream);
+}
+
+extern "C" int arcle_set_truncation(arcle_env* e, uint8_t* trunc_out, int32_t step_limit) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (trunc_out && step_limit <= 0) return fail(e, ARCLE_ERR_ARG, "step_limit must be positive");
+  e->base.trunc = trunc_out;
+  e->base.step_limit = step_limit;
+  return ARCLE_OK;
 }
 
 extern "C" int arcle_flat_obs_size(const arcle_env* e) {
@@ -484,9 +561,10 @@ extern "C" int arcle_flat_obs_size(const arcle_env* e) {
 
 extern "C" int arcle_flatten_obs(arcle_env* e, int8_t* out, void* stream) {
   if (!e || !out) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.flat_out = out;
-  p.flat_len = arcle_flat_obs_size(e);
+  p.flat_stride = arcle_flat_obs_size(e);
   hipLaunchKernelGGL(arcle_flatten_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
   HIP_TRY(e, hipGetLastError());
   return ARCLE_OK;
@@ -494,6 +572,7 @@ extern "C" int arcle_flatten_obs(arcle_env* e, int8_t* out, void* stream) {
 
 extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void* stream) {
   if (!e || !status) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
   HIP_TRY(e, hipMemcpyAsync(status, e->d_status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
   if (clear) HIP_TRY(e, hipMemsetAsync(e->d_status, 0, 4, (hipStream_t)stream));
   HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
@@ -502,6 +581,7 @@ extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void*
 
 extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   if (!e) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
   if (on && !e->d_acct) {
     HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 64));
     HIP_TRY(e, hipMemset(e->d_acct, 0, (size_t)e->cfg.n_envs * 64));
@@ -526,6 +606,7 @@ extern "C" int arcle_debug_copy_trace(arcle_env* e, uint64_t* host_out) {  // di
 extern "C" int arcle_get_accounting(arcle_env* e, uint64_t* bytes, uint64_t* steps, int clear, void* stream) {
   if (!e || !bytes || !steps) return ARCLE_ERR_ARG;
   if (!e->d_acct) return fail(e, ARCLE_ERR_CONFIG, "accounting is not enabled");
+  DeviceGuard guard(e->device);
   const size_t n = (size_t)e->cfg.n_envs;
   uint32_t* h = (uint32_t*)malloc(n * 4);
   if (!h) return ARCLE_ERR_ARG;

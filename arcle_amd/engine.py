@@ -5,6 +5,7 @@ layout include/arcle_hip.h declares and hands their raw pointers to the C ABI.  
 in the HIP kernels; this file contains no grid arithmetic.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -36,14 +37,16 @@ def _ptr(t):
 class EnvBatch:
     """n_envs envs of one kind on one GPU."""
 
-    def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None):
+    def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None, plane_stride=None):
         if not torch.cuda.is_available():
             raise ArcleHipError("no HIP device visible (torch.cuda.is_available() is False); "
                                 "arcle_amd has no CPU fallback")
         self.L = _lib.lib()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.N, self.H, self.W, self.P = int(n_envs), int(H), int(W), int(H) * int(W)
-        self.PS = (self.P + 15) & ~15  # plane stride: one aligned dwordx4 per lane
+        if plane_stride is None:
+            plane_stride = int(os.environ.get("ARCLE_PLANE_STRIDE", "0")) or ((self.P + 127) & ~127)  # ARCLE_DEFAULT_PLANE_STRIDE
+        self.PS = int(plane_stride)  # plane stride: one aligned dwordx4 per lane
         self.max_trial, self.kind = int(max_trial), kind
         # 16 B alignment of every plane/record row comes from torch's >=256 B allocation alignment
         self.planes = {k: torch.zeros((self.N, self.PS), dtype=torch.int8, device=self.device)
@@ -52,7 +55,7 @@ class EnvBatch:
         self.cnt = torch.zeros((self.N, 2), dtype=torch.int32, device=self.device)
         self.reward = torch.zeros(self.N, dtype=torch.int32, device=self.device)
         self.term = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
-        cfg = _lib.Config(self.N, self.H, self.W, self.max_trial, self.device.index or 0)
+        cfg = _lib.Config(self.N, self.H, self.W, self.max_trial, self.device.index or 0, self.PS)
         bufs = _lib.Buffers()
         for k, i in PLANE_ID.items():
             bufs.plane[i] = self.planes[k].data_ptr() if k in self.planes else None

@@ -22,7 +22,10 @@
  *     single-threaded as well).
  *
  * State layout in HBM (structure of arrays, all int8, one row per env):
- *   plane[p]  : int8 [n_envs][H*W]   contiguous, row-major (env, row, col); p in arcle_plane
+ *   plane[p]  : int8 [n_envs][PS]    env e's H x W cells are the first H*W bytes (row-major: row, col) of row e; the
+ *                                    row stride PS = arcle_config.plane_stride (default: H*W rounded up to 128 B,
+ *                                    e.g. 1024 for 30x30); bytes [H*W, PS) of every row are zero padding.
+ *                                    p in arcle_plane
  *   rec       : int8 [n_envs][16]    packed per-env scalars, byte offsets ARCLE_REC_*
  *   cnt       : int32[n_envs][2]     {action_steps, submit_count}
  */
@@ -35,9 +38,12 @@
 extern "C" {
 #endif
 
-#define ARCLE_ABI_VERSION 1
+#define ARCLE_ABI_VERSION 2
 #define ARCLE_MAX_OPS 64
 #define ARCLE_MAX_CELLS 1024 /* H*W <= 1024 (one 64-lane wavefront x 16 cells) */
+/* default per-env plane stride: H*W rounded up to a whole number of 128-byte lines (30x30 -> 1024 B), so that no two
+ * envs share a cache line of a plane and every plane store writes full lines */
+#define ARCLE_DEFAULT_PLANE_STRIDE(P) (((P) + 127) & ~127)
 
 /* ---- planes: keys of the reference state dict (o2arcenv.py:16-34, base.py:155-166) ---- */
 enum arcle_plane {
@@ -110,6 +116,9 @@ enum arcle_op_kind {
  * for states written from outside (e.g. a state dict uploaded for transition()) that may violate the invariant;
  * arcle_set_op_table() reports through arcle_can_elide_selected() whether the installed table permits it. */
 #define ARCLE_STEP_ELIDE_SELECTED 2u
+/* also writes truncated[env] = (action_steps >= step_limit) into the array installed with arcle_set_truncation
+ * (gymnasium TimeLimit(max_episode_steps) as the reference's training script applies it, agents/train.py:67) */
+#define ARCLE_STEP_TRUNCATE 4u
 
 /* ---- sticky device status bits (arcle_get_status) ---- */
 #define ARCLE_ST_BAD_OP 1u       /* operation index out of range / empty slot: step skipped
@@ -132,6 +141,8 @@ typedef struct arcle_config {
   int32_t H, W;      /* max_grid_size (base.py:49); H*W <= ARCLE_MAX_CELLS               */
   int32_t max_trial; /* base.py:51; stored as int8 in trials_remain                      */
   int32_t device;    /* HIP device ordinal, -1 = current device                          */
+  int32_t plane_stride; /* bytes between consecutive envs of a plane (PS): 0 = default (ARCLE_DEFAULT_PLANE_STRIDE(H*W));
+                           otherwise a multiple of 16 with H*W <= PS <= 1024                */
 } arcle_config;
 
 typedef struct arcle_buffers {
@@ -164,7 +175,7 @@ int arcle_can_elide_selected(const arcle_env* env);
 int arcle_reset(arcle_env* env, const uint8_t* mask, void* stream);
 
 /* Device task table: n_tasks (input, answer) pairs, already zero-padded to the plane stride PS = H*W rounded up
- * to 16: in_planes / ans_planes int8 [n_tasks][PS], in_dims / ans_dims int8 [n_tasks][2] (device pointers, owned
+ * (arcle_config.plane_stride): in_planes / ans_planes int8 [n_tasks][PS], in_dims / ans_dims int8 [n_tasks][2] (device pointers, owned
  * by the caller, must stay alive).  It is the packed form of what Loader.parse yields (loader.py:89-113), one entry
  * per (task, pair). */
 int arcle_set_task_table(arcle_env* env, const int8_t* in_planes, const int8_t* in_dims, const int8_t* ans_planes,
@@ -200,6 +211,14 @@ int arcle_rollout_bbox(arcle_env* env, int32_t n_steps, const int32_t* bbox, con
                        uint8_t* term, uint32_t flags, void* stream);
 int arcle_rollout_point(arcle_env* env, int32_t n_steps, const int32_t* xy, const int32_t* op, int32_t* reward,
                         uint8_t* term, uint32_t flags, void* stream);
+/* the same with full selection masks: sel device int8 [n_steps][n_envs][H*W] (the O2ARC trace replayer's form,
+ * tests/o2arc_check.py:139-199 of the reference) */
+int arcle_rollout_mask(arcle_env* env, int32_t n_steps, const int8_t* sel, const int32_t* op, int32_t* reward,
+                       uint8_t* term, uint32_t flags, void* stream);
+
+/* Installs the output of ARCLE_STEP_TRUNCATE: trunc_out device uint8[n_envs], step_limit = max_episode_steps.
+ * trunc_out == NULL removes it. */
+int arcle_set_truncation(arcle_env* env, uint8_t* trunc_out, int32_t step_limit);
 
 /* Flattened observation: out int8 [n_envs][arcle_flat_obs_size()] (device), one row per env holding the state dict in
  * Gymnasium FlattenObservation order (keys sorted, nested object_states in place) — what the reference's policies

@@ -83,18 +83,24 @@ class OracleBackend:
 
 
 # ---- wave emulator (tests/emu/wave_emu.cpp: the kernel body of arcle_wave.h run lock-step on the CPU) ----
-class _StepParams(ctypes.Structure):
+class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/csrc/arcle_wave.h)
     _fields_ = [("plane", ctypes.c_void_p * 8), ("rec", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
                 ("op", ctypes.c_void_p), ("sel", ctypes.c_void_p), ("reward", ctypes.c_void_p),
-                ("term", ctypes.c_void_p), ("status", ctypes.c_void_p), ("acct", ctypes.c_void_p),
-                ("rmask", ctypes.c_void_p), ("task_idx", ctypes.c_void_p), ("tbl_in", ctypes.c_void_p),
-                ("tbl_ans", ctypes.c_void_p), ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p),
-                ("n_tasks", ctypes.c_int32), ("n_steps", ctypes.c_int32),
-                ("flat_out", ctypes.c_void_p), ("flat_len", ctypes.c_int32),
+                ("term", ctypes.c_void_p),
                 ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32),
                 ("ingress", ctypes.c_int32), ("flags", ctypes.c_uint32), ("div_magic", ctypes.c_uint32),
-                ("nseg", ctypes.c_int32), ("d_ops", ctypes.c_void_p)]
+                ("nseg", ctypes.c_int32), ("n_steps", ctypes.c_int32), ("env_stride", ctypes.c_int32),
+                ("step_limit", ctypes.c_int32),
+                ("status", ctypes.c_void_p), ("acct", ctypes.c_void_p), ("d_ops", ctypes.c_void_p),
+                ("trunc", ctypes.c_void_p), ("dense", ctypes.c_void_p), ("flat_out", ctypes.c_void_p),
+                ("flat_stride", ctypes.c_int32), ("flat_filter", ctypes.c_int32),
+                ("rmask", ctypes.c_void_p), ("task_idx", ctypes.c_void_p), ("tbl_in", ctypes.c_void_p),
+                ("tbl_ans", ctypes.c_void_p), ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p),
+                ("n_tasks", ctypes.c_int32), ("aug_flags", ctypes.c_uint32), ("seed", ctypes.c_uint64),
+                ("env_base", ctypes.c_int64), ("episode", ctypes.c_void_p), ("cur_task", ctypes.c_void_p),
+                ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p), ("n_problems", ctypes.c_int32),
+                ("pad_", ctypes.c_int32)]
 
 
 _emu = None
@@ -118,10 +124,12 @@ class EmuBackend:
     name = "emu"
     INGRESS = {"mask": 0, "bbox": 1, "point": 2}
 
+    PLANE_STRIDE = None  # override: bytes between envs of a plane (default = the library's: H*W rounded up to 128)
+
     def __init__(self, N, H, W, max_trial, kind, ops):
         self.N, self.H, self.W, self.kind = N, H, W, kind
         self.P = H * W
-        self.PS = (self.P + 15) & ~15
+        self.PS = self.PLANE_STRIDE or ((self.P + 127) & ~127)
         self.max_trial = max_trial
         self.buf = {k: np.zeros((N, self.PS), np.int8) for k in O.KIND_PLANES[kind]}
         self.rec = np.zeros((N, 16), np.int8)
@@ -140,6 +148,7 @@ class EmuBackend:
         p.reward, p.term = self.reward.ctypes.data, self.term.ctypes.data
         p.status, p.acct = self.stat.ctypes.data, self.acct.ctypes.data
         p.n_envs, p.H, p.W, p.max_trial, p.n_ops = self.N, self.H, self.W, self.max_trial, len(self.ops)
+        p.PS = self.PS
         self._ops_arr = np.zeros(64, np.uint32)  # the "device" op table
         self._ops_arr[:len(self.ops)] = self.ops
         p.d_ops = self._ops_arr.ctypes.data

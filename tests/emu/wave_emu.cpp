@@ -18,6 +18,7 @@
 #include <initializer_list>
 
 #define ARCLE_DEV inline
+#define ARCLE_HD inline
 
 namespace xl {
 static int cur_lane;
@@ -78,59 +79,78 @@ ARCLE_DEV uint32_t lane_next(uint32_t v) {
   uint32_t r = shfl(v, (me + 1) & 63);
   return me == 63 ? 0u : r;
 }
-template <class T>
-ARCLE_DEV void pin_ptr(T*&) {}
-ARCLE_DEV void pin_u32(uint32_t&) {}
-ARCLE_DEV void pin_i32(int32_t&) {}
-ARCLE_DEV void keep1(uint32_t&) {}
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return shfl(v, lane); }
-template <class V>
-ARCLE_DEV void keep(V&, V&, uint32_t&, int32_t&) {}
-template <class V>
-ARCLE_DEV void store16(int8_t* ptr, const V& v) { memcpy(ptr, &v, 16); }
+typedef uint32_t U4 __attribute__((vector_size(16)));
+typedef uint32_t U2 __attribute__((vector_size(8)));
+// wave-uniform scalar loads: every lane reads the same address
+ARCLE_DEV uint32_t uload1(const void* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+ARCLE_DEV U2 uload2(const void* p) { U2 v; memcpy(&v, p, 8); return v; }
+ARCLE_DEV U4 uload4(const void* p) { U4 v; memcpy(&v, p, 16); return v; }
+ARCLE_DEV U4 load16(const int8_t* base, uint32_t off) { U4 v; memcpy(&v, base + off, 16); return v; }
+ARCLE_DEV void store16(int8_t* base, uint32_t off, const U4& v) { memcpy(base + off, &v, 16); }
+ARCLE_DEV void wg_barrier() { yield(8); }
+ARCLE_DEV void lanes_converged() { yield(9); }
+ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+ARCLE_DEV uint32_t opaque(uint32_t v) { return v; }
+ARCLE_DEV void arrived(U4&, U2&, uint32_t&, U4&) {}
+ARCLE_DEV void arrived3(U4&, U2&, uint32_t&) {}
 }  // namespace xl
 
 #include "../../arcle_amd/csrc/arcle_wave.h"
 
 namespace {
 const arcle::StepParams* g_p;
-arcle::WaveLDS g_lds;
+arcle::BlockLDS<1> g_lds;
 int g_env, g_kind;
 char* g_stacks;
 const size_t STACK = 256 * 1024;
 
 int g_tbl;  // arcle::TBL_* of the installed table (emu_run compares it with the canonical decoders)
 
-#define RUN_STEP(I, F)                                                                        \
-  do {                                                                                        \
-    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_step<I, F, arcle::TBL_O2ARC>(*g_p, &g_lds, g_env, lane);   \
-    else if (g_tbl == arcle::TBL_ARC) arcle::wave_step<I, F, arcle::TBL_ARC>(*g_p, &g_lds, g_env, lane);  \
-    else if (g_tbl == arcle::TBL_RAW) arcle::wave_step<I, F, arcle::TBL_RAW>(*g_p, &g_lds, g_env, lane);  \
-    else arcle::wave_step<I, F, arcle::TBL_LOOKUP>(*g_p, &g_lds, g_env, lane);                            \
+#define RUN_STEP(I, F)                                                                      \
+  do {                                                                                      \
+    arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, I, F, false);                      \
+    arcle::StepInputs in = arcle::load_inputs<I>(w, g_env);                                 \
+    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_step<I, F, arcle::TBL_O2ARC, 1>(w, g_env, in); \
+    else arcle::wave_step<I, F, arcle::TBL_LOOKUP, 1>(w, g_env, in);                        \
   } while (0)
-#define RUN_ROLL(I, F)                                                                        \
-  do {                                                                                        \
-    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_rollout<I, F, arcle::TBL_O2ARC>(*g_p, &g_lds, g_env, lane); \
-    else arcle::wave_rollout<I, F, arcle::TBL_LOOKUP>(*g_p, &g_lds, g_env, lane);                          \
+#define RUN_ROLL(I, F)                                                                                          \
+  do {                                                                                                          \
+    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_rollout<I, F, arcle::TBL_O2ARC>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane); \
+    else arcle::wave_rollout<I, F, arcle::TBL_LOOKUP>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);                          \
   } while (0)
+
+// the same width classes the HIP library launches: FW_FULL when 16 <= W <= 32 and the plane stride is 1024
+int width_class() {
+  if (g_p->W < 16 || g_p->W > 32) return arcle::FW_GENERIC;
+  return g_p->PS == 1024 ? arcle::FW_FULL : arcle::FW_FAST;
+}
 
 void lane_main(int lane) {
   xl::cur_lane = lane;
-  const bool fw = g_p->W >= 16 && g_p->W <= 32;
+  const int fw = width_class();
+  arcle::lut_init(g_lds.lut, lane, 64);
+  xl::wg_barrier();
   if (g_kind == 0) {
-    switch (g_p->ingress * 2 + (fw ? 1 : 0)) {  // the same instantiations the HIP library launches
+    switch (g_p->ingress * 3 + fw) {
       case 0: RUN_STEP(0, 0); break;
       case 1: RUN_STEP(0, 1); break;
-      case 2: RUN_STEP(1, 0); break;
-      case 3: RUN_STEP(1, 1); break;
-      case 4: RUN_STEP(2, 0); break;
-      default: RUN_STEP(2, 1); break;
+      case 2: RUN_STEP(0, 2); break;
+      case 3: RUN_STEP(1, 0); break;
+      case 4: RUN_STEP(1, 1); break;
+      case 5: RUN_STEP(1, 2); break;
+      case 6: RUN_STEP(2, 0); break;
+      case 7: RUN_STEP(2, 1); break;
+      default: RUN_STEP(2, 2); break;
     }
   }
   else if (g_kind == 2)
-    arcle::wave_reset_table(*g_p, &g_lds, g_env, lane);
+    arcle::wave_reset_table(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
   else if (g_kind == 3) {
-    switch (g_p->ingress * 2 + (fw ? 1 : 0)) {
+    const int f = fw ? 1 : 0;  // (the library launches FW_FAST rollouts for FW_FULL too)
+    switch (g_p->ingress * 2 + f) {
+      case 0: RUN_ROLL(0, 0); break;
+      case 1: RUN_ROLL(0, 1); break;
       case 2: RUN_ROLL(1, 0); break;
       case 3: RUN_ROLL(1, 1); break;
       case 4: RUN_ROLL(2, 0); break;
@@ -138,7 +158,7 @@ void lane_main(int lane) {
     }
   }
   else
-    arcle::wave_reset(*g_p, &g_lds, g_env, lane);
+    arcle::wave_reset(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
   xl::finished[lane] = true;
   // returning resumes uc_link (the scheduler)
 }
@@ -187,29 +207,22 @@ void run_wave() {
 }
 }  // namespace
 
-// kind: 0 = step, 1 = reset, 2 = reset from the task table, 3 = rollout.  Fills derived fields (P, PS, div_magic, nseg) like arcle_create does.
+// kind: 0 = step, 1 = reset, 2 = reset from the task table, 3 = rollout.  Fills derived fields (P, div_magic, nseg) like
+// arcle_create does; PS (plane stride) comes from the caller (0 = default).
 extern "C" int emu_run(int kind, arcle::StepParams* p) {
   p->P = p->H * p->W;
-  p->PS = (p->P + 15) & ~15;
+  if (p->PS == 0) p->PS = ARCLE_DEFAULT_PLANE_STRIDE(p->P);
   p->div_magic = 65536u / (uint32_t)p->W + 1u;
   p->nseg = (p->W >= 16) ? 2 : 1 + (15 + p->W - 1) / p->W;
   if (!g_stacks) g_stacks = (char*)malloc(64 * STACK);
   g_p = p;
   g_kind = kind;
-  // canonical-table detection, the same rule libarcle_hip uses: the table must equal what decode_op<TBL> computes
+  // canonical-table detection, the same rule libarcle_hip uses: the table must equal what o2arc_desc computes
   g_tbl = arcle::TBL_LOOKUP;
-  if (p->d_ops) {
-    for (int t : {arcle::TBL_O2ARC, arcle::TBL_ARC, arcle::TBL_RAW}) {
-      const int n = t == arcle::TBL_O2ARC ? 35 : t == arcle::TBL_ARC ? 27 : 12;
-      bool same = p->n_ops == n;
-      for (int i = 0; same && i < n; i++) {
-        uint32_t d = t == arcle::TBL_O2ARC ? arcle::decode_op<arcle::TBL_O2ARC>(*p, i)
-                   : t == arcle::TBL_ARC   ? arcle::decode_op<arcle::TBL_ARC>(*p, i)
-                                           : arcle::decode_op<arcle::TBL_RAW>(*p, i);
-        same = d == p->d_ops[i];
-      }
-      if (same) g_tbl = t;
-    }
+  if (p->d_ops && p->n_ops == 35) {
+    bool same = true;
+    for (int i = 0; same && i < 35; i++) same = arcle::o2arc_desc(i) == p->d_ops[i];
+    if (same) g_tbl = arcle::TBL_O2ARC;
   }
   xl::error_flag = 0;
   for (int env = 0; env < p->n_envs; env++) {

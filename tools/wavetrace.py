@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic (needs gpurun_lib_trace.so built with -DARCLE_TRACE_WAVES, ARCLE_HIP_LIB pointing at it): per-wave
-start/end timestamps (100 MHz realtime clock) of ONE launch of the C3 mix -> dispatch ramp, per-op lifetimes, tail."""
+"""Diagnostic (needs a -DARCLE_TRACE_WAVES build, ARCLE_HIP_LIB pointing at it): per-wave timestamps (100 MHz realtime
+clock) of ONE launch of the C3 mix -> dispatch ramp, per-phase and per-op lifetimes, tail.
+  tr[0] kernel entry  tr[1] expansion table built + barrier passed  tr[2] scalar inputs landed
+  tr[3] op applied (stores issued)  tr[4] epilogue stores issued"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +10,7 @@ import bench
 from arcle_amd import actions, _lib
 from arcle_amd.engine import EnvBatch
 from arcle_amd.envs import O2ARCv2Env
-dev = torch.device("cuda:0"); n = 8192; K = 40
+dev = torch.device("cuda:0"); n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192; K = 40
 b = EnvBatch(n, 30, 30, -1, "o2arc", dev)
 b.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
 b.set_tasks_padded(*bench.make_tasks(n, 1)); b.reset()
@@ -17,7 +19,6 @@ bb, oo = torch.from_numpy(bn).to(dev), torch.from_numpy(on).to(dev)
 b.enable_accounting(True)
 L = _lib.lib()
 L.arcle_debug_copy_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-names = ["".join(map(str.capitalize, o.__name__.split("_"))) for o in O2ARCv2Env.default_operations()]
 cls = {"color": range(0, 10), "floodfill": range(10, 20), "move": range(20, 24), "rot/flip": range(24, 28),
        "copy/paste": range(28, 31), "critical": range(31, 34), "submit": [34]}
 for rep in range(3):
@@ -28,21 +29,17 @@ for rep in range(3):
     tr = np.zeros((n, 8), np.uint64)
     assert L.arcle_debug_copy_trace(b._h, tr.ctypes.data) == 0
     t0 = tr[:, 0].min()
-    st = (tr[:, 0] - t0).astype(np.float64) / 100.0  # us
-    en = (tr[:, 3] - t0).astype(np.float64) / 100.0
-    w1 = (tr[:, 1] - tr[:, 0]).astype(np.float64) / 100.0   # start -> first window complete
-    core = (tr[:, 2] - tr[:, 1]).astype(np.float64) / 100.0  # op application (incl. plane loads, stores issued)
-    epi = (tr[:, 3] - tr[:, 2]).astype(np.float64) / 100.0
-    dsc = (tr[:, 4] - tr[:, 1]).astype(np.float64) / 100.0   # window1 done -> op descriptor decoded
-    sel_ = (tr[:, 5] - tr[:, 4]).astype(np.float64) / 100.0  # descriptor -> selection masks built
-    print(f"   core split (us): descriptor fetch mean {dsc.mean():.2f} p90 {np.percentile(dsc,90):.2f} | selection ingest mean {sel_.mean():.2f}")
+    T = (tr[:, :5] - t0).astype(np.float64) / 100.0  # us
+    st, en = T[:, 0], T[:, 4]
+    ph = np.diff(T, axis=1)  # lut, inputs, core, epilogue
     life = en - st
     ops = on[K - 1]
-    print(f"rep {rep}: first start 0, last start {st.max():.2f} us, last end {en.max():.2f} us; lifetime mean {life.mean():.2f} "
+    print(f"rep {rep}: last start {st.max():.2f} us, last end {en.max():.2f} us; lifetime mean {life.mean():.2f} "
           f"p50 {np.median(life):.2f} p90 {np.percentile(life,90):.2f} max {life.max():.2f}")
     print("   start percentiles (us): " + " ".join(f"p{q}={np.percentile(st,q):.2f}" for q in (10, 50, 90, 99)))
     print("   end   percentiles (us): " + " ".join(f"p{q}={np.percentile(en,q):.2f}" for q in (10, 50, 90, 99)))
-    print(f"   phases (us): window1 mean {w1.mean():.2f} p90 {np.percentile(w1,90):.2f} | core mean {core.mean():.2f} p90 {np.percentile(core,90):.2f} | epilogue mean {epi.mean():.2f}")
+    print("   phases mean (us): table+barrier %.2f | inputs landed %.2f | op %.2f | epilogue %.2f" % tuple(ph.mean(0)))
     for k, r in cls.items():
         m = np.isin(ops, list(r))
-        print(f"   {k:10s} n={m.sum():5d} lifetime mean {life[m].mean():5.2f} p90 {np.percentile(life[m],90):5.2f}  end mean {en[m].mean():5.2f} max {en[m].max():5.2f}  | win1 {w1[m].mean():4.2f} core {core[m].mean():4.2f} epi {epi[m].mean():4.2f}")
+        print(f"   {k:10s} n={m.sum():5d} life mean {life[m].mean():5.2f} p90 {np.percentile(life[m],90):5.2f}  end mean {en[m].mean():5.2f} max {en[m].max():5.2f}"
+              f" | lut {ph[m,0].mean():4.2f} in {ph[m,1].mean():4.2f} op {ph[m,2].mean():4.2f} epi {ph[m,3].mean():4.2f}")
