@@ -90,9 +90,12 @@ using arcle::StepParams;
 using arcle::WaveLDS;
 
 #ifndef ARCLE_WAVES_PER_WG
-#define ARCLE_WAVES_PER_WG 4
+#define ARCLE_WAVES_PER_WG 8  // 512-thread workgroups: 7.3 vs 7.7 us per launch of the C3 mix against 256 (in-box A/B, round 2)
 #endif
 static constexpr int WAVES_PER_WG = ARCLE_WAVES_PER_WG;
+#ifndef ARCLE_SGPR_CAP
+#define ARCLE_SGPR_CAP 80  // 256-thread workgroups: 8 per CU need <= 80 SGPRs per wave (MI355X_MICROARCH.md, residency)
+#endif
 typedef arcle::BlockLDS<WAVES_PER_WG> BlockLDS;
 
 // wave index of the launch with XCD-contiguous ranges: workgroup b runs on XCD b%8 (observed), so
@@ -107,7 +110,7 @@ __device__ __forceinline__ int wave_of_launch() {
 // the canonical O2ARCv2Env one (descriptor computed in registers), arcle::TBL_LOOKUP for any other table;
 // ACCT: 1 = add the step's algorithmic bytes to p.acct[env]
 template <int ING, int FW, int TBL, int ACCT>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(80))) void arcle_step_kernel(const StepParams p) {
+__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_entry = xl::clock();

@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the non-headline legs (kernel A/B runs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -237,7 +238,7 @@ def main():
                        "parallelism": f"env-shard x{world} (no data-path collective)"},
             "roofline": roofline,
         }
-        if world == 1:
+        if world == 1 and not a.no_extras:
             out["extras"] = {"rollout": rollout_leg(batch, bbox, op, Wm, dev)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(1000)
