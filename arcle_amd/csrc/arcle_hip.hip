@@ -147,6 +147,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_flatten_kernel(const 
   arcle::wave_flatten(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_pack_kernel(const StepParams p) {
+  __shared__ BlockLDS lds;
+  const int env = wave_of_launch();
+  if (env >= p.n_envs) return;
+  arcle::wave_pack_obs(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
+}
+
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
   const int env = wave_of_launch();
@@ -569,6 +576,25 @@ extern "C" int arcle_flatten_obs(arcle_env* e, int8_t* out, void* stream) {
   p.flat_out = out;
   p.flat_stride = arcle_flat_obs_size(e);
   hipLaunchKernelGGL(arcle_flatten_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_packed_obs_size(const arcle_env* e) {
+  if (!e) return ARCLE_ERR_ARG;
+  return (e->base.P + 7 + 15) & ~15;
+}
+
+extern "C" int arcle_pack_obs(arcle_env* e, const int32_t* reward, const uint8_t* term, uint8_t* out, void* stream) {
+  if (!e || !reward || !term || !out) return ARCLE_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(out) & 15) return fail(e, ARCLE_ERR_ARG, "packed observation rows must be 16-byte aligned");
+  DeviceGuard guard(e->device);
+  StepParams p = e->base;
+  p.reward = const_cast<int32_t*>(reward);
+  p.term = const_cast<uint8_t*>(term);
+  p.flat_out = reinterpret_cast<int8_t*>(out);
+  p.flat_stride = arcle_packed_obs_size(e);
+  hipLaunchKernelGGL(arcle_pack_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
   HIP_TRY(e, hipGetLastError());
   return ARCLE_OK;
 }

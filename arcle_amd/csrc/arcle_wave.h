@@ -1434,4 +1434,37 @@ ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, in
   flat_scalar(w, row, off, rec, ARCLE_REC_TRIALS, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// packed minimal observation of one env, what a central learner gathers per step:
+//   row = grid (H*W bytes) | grid_dim (2) | reward int32 LE (4) | terminated (1) | zero padding to a multiple of 16
+// one aligned 16 B store per lane; p.flat_out / p.flat_stride name the destination, p.reward / p.term the step outputs
+// ------------------------------------------------------------------------------------------------
+ARCLE_DEV void wave_pack_obs(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
+  Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
+  w.set_env(env);
+  const int P = p.P;
+  if (16 * lane >= p.flat_stride) return;
+  U4 v = w.load_hbm(ARCLE_PL_GRID);  // (bytes >= P of the plane row are zero padding)
+  if (16 * lane + 16 > P) {          // this lane's window holds the metadata bytes
+    const Rec r = load_rec(p, env);
+    const uint32_t rew = (uint32_t)p.reward[env];
+    uint8_t meta[7];
+    meta[0] = (uint8_t)r.gh();
+    meta[1] = (uint8_t)r.gw();
+    meta[2] = (uint8_t)rew;
+    meta[3] = (uint8_t)(rew >> 8);
+    meta[4] = (uint8_t)(rew >> 16);
+    meta[5] = (uint8_t)(rew >> 24);
+    meta[6] = p.term[env];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int b = 16 * lane + k - P;
+      uint32_t byte = (v[k >> 2] >> (8 * (k & 3))) & 0xffu;
+      if (b >= 0) byte = b < 7 ? meta[b] : 0u;
+      v[k >> 2] = (v[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (byte << (8 * (k & 3)));
+    }
+  }
+  *reinterpret_cast<U4*>(p.flat_out + (size_t)env * p.flat_stride + 16 * lane) = v;
+}
+
 }  // namespace arcle

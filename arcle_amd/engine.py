@@ -224,6 +224,36 @@ class EnvBatch:
         self._check(self.L.arcle_flatten_obs(self._h, _ptr(out), self._stream()), "arcle_flatten_obs")
         return out
 
+    def packed_obs_size(self):
+        return int(self.L.arcle_packed_obs_size(self._h))
+
+    def packed_obs(self, out=None):
+        """[N, R] uint8 rows = grid | grid_dim | reward (int32 LE) | terminated | padding, R = arcle_packed_obs_size()
+        (912 for 30x30): the record a central learner gathers per step (one all-gather, arcle_amd.dist)."""
+        R = self.L.arcle_packed_obs_size(self._h)
+        if out is None:
+            out = torch.empty((self.N, R), dtype=torch.uint8, device=self.device)
+        assert out.shape == (self.N, R) and out.dtype == torch.uint8 and out.is_contiguous() and out.device == self.device
+        self._check(self.L.arcle_pack_obs(self._h, _ptr(self.reward), _ptr(self.term), _ptr(out), self._stream()),
+                    "arcle_pack_obs")
+        return out
+
+    def packed_obs_ptr(self, out_ptr, stream=0):
+        """Lowest-overhead form for rollout loops: raw device address of the [N, packed_obs_size()] uint8 output."""
+        rc = self.L.arcle_pack_obs(self._h, self._reward_ptr, self._term_ptr, out_ptr, stream)
+        if rc != 0:
+            self._check(rc, "arcle_pack_obs")
+
+    @staticmethod
+    def unpack_obs(rows, H, W):
+        """(grid int8 [M,H,W], grid_dim int8 [M,2], reward int32 [M], terminated bool [M]) views/copies of packed rows."""
+        P = H * W
+        grid = rows[:, :P].view(torch.int8).reshape(-1, H, W)
+        gdim = rows[:, P:P + 2].view(torch.int8)
+        rew = rows[:, P + 2:P + 6].contiguous().view(torch.int32).reshape(-1)
+        term = rows[:, P + 6] != 0
+        return grid, gdim, rew, term
+
     # ---- status / accounting ------------------------------------------------------------------
     def status(self, clear=True):
         s = ctypes.c_uint32(0)

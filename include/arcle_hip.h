@@ -228,6 +228,13 @@ int arcle_set_truncation(arcle_env* env, uint8_t* trunc_out, int32_t step_limit)
 int arcle_flat_obs_size(const arcle_env* env);
 int arcle_flatten_obs(arcle_env* env, int8_t* out, void* stream);
 
+/* Packed minimal observation for a central learner (what the multi-GPU gather moves): one row per env,
+ *   grid (H*W bytes) | grid_dim (2) | reward int32 little-endian (4) | terminated (1) | zero padding
+ * of arcle_packed_obs_size() bytes (H*W + 7 rounded up to 16; 912 for 30x30).  reward / term are the arrays the last step
+ * wrote; out is a device buffer uint8 [n_envs][arcle_packed_obs_size()], 16-byte aligned. */
+int arcle_packed_obs_size(const arcle_env* env);
+int arcle_pack_obs(arcle_env* env, const int32_t* reward, const uint8_t* term, uint8_t* out, void* stream);
+
 /* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*). Synchronises
  * the stream. */
 int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);
