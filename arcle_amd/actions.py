@@ -6,13 +6,15 @@ returns the list (base.py:140-142).  Here every generator returns an `Operation`
 `__name__` (so `op_names` come out identical, base.py:66) plus the uint32 descriptor the HIP step kernel
 dispatches on (include/arcle_hip.h).  Tables may be re-ordered, truncated, wrapped (`reset_sel`,
 `keep_sel`) or have slots swapped exactly like user code does with the reference
-(agents/env.py:23-28, agents/wrapper.py:53-57).  Arbitrary Python callables cannot run inside the
-kernel: putting one in the table raises `TypeError` when the env is constructed.
+(agents/env.py:23-28, agents/wrapper.py:53-57).  An arbitrary Python callable `op(state, action)` in the table
+cannot run inside the kernel: its slot becomes a device no-op (`OP_HOST`: the step is counted, nothing else
+happens) and the env applies the callable on the host to a fetched state (envs/base.py, envs/vec.py) — the
+SURVEY.md §8(b) "custom ops" contract; it is the slow path by construction.
 """
 
 # op kinds / flags — include/arcle_hip.h
 (OP_NONE, OP_COLOR, OP_FLOODFILL, OP_MOVE, OP_ROTATE, OP_FLIP, OP_COPY, OP_PASTE, OP_COPY_FROM_INPUT,
- OP_RESET_GRID, OP_RESIZE_GRID, OP_CROP_GRID, OP_RESIZE_TO_ANSWER, OP_SUBMIT) = range(14)
+ OP_RESET_GRID, OP_RESIZE_GRID, OP_CROP_GRID, OP_RESIZE_TO_ANSWER, OP_SUBMIT, OP_HOST) = range(15)
 OPF_RESET_SEL, OPF_KEEP_SEL = 1, 2
 
 
@@ -90,14 +92,26 @@ def keep_sel(op):  # object.py:28-41
     return Operation(op.kind, op.arg, op.flags | OPF_KEEP_SEL, op.__name__)
 
 
+def is_submit(op):
+    """`self.submit` bound method, as the reference's tables use it (o2arcenv.py:112)."""
+    return getattr(op, "__self__", None) is not None and getattr(op, "__name__", "") == "submit"
+
+
+def host_slots(operations):
+    """Indices of table slots holding arbitrary Python callables (applied on the host)."""
+    return [i for i, op in enumerate(operations) if not isinstance(op, Operation) and not is_submit(op)]
+
+
 def table_descs(operations):
-    """List[Operation] -> list of uint32 descriptors; rejects anything the kernel cannot dispatch."""
+    """List[Operation | callable] -> list of uint32 descriptors for the HIP step kernel."""
     out = []
     for i, op in enumerate(operations):
-        if getattr(op, "__self__", None) is not None and getattr(op, "__name__", "") == "submit":
-            op = submit  # `self.submit` bound method, as the reference's tables use it
-        if not isinstance(op, Operation):
-            raise TypeError(f"operation table slot {i} ({op!r}) is not an arcle_amd Operation: arbitrary Python "
-                            "callables cannot be dispatched by the HIP step kernel")
-        out.append(op.desc)
+        if is_submit(op):
+            op = submit
+        if isinstance(op, Operation):
+            out.append(op.desc)
+        elif callable(op):
+            out.append(OP_HOST)  # device no-op slot; the env applies the callable on the host
+        else:
+            raise TypeError(f"operation table slot {i} ({op!r}) is neither an arcle_amd Operation nor a callable")
     return out

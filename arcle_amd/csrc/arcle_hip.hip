@@ -140,11 +140,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const 
   arcle::wave_rollout<ING, FW, TBL>(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_flatten_kernel(const StepParams p) {
-  __shared__ BlockLDS lds;
-  const int env = wave_of_launch();
+// one LDS row buffer per wave: 7 planes of <= 1024 B + 14 scalars, rounded up
+static constexpr int FLAT_ROW_LDS = 7 * ARCLE_MAX_CELLS + 32;
+static constexpr int FLAT_WAVES = 4;
+__global__ __launch_bounds__(64 * FLAT_WAVES) void arcle_flatten_kernel(const StepParams p) {
+  __shared__ arcle::WaveLDS tiles[FLAT_WAVES];
+  __shared__ __attribute__((aligned(16))) uint8_t rows[FLAT_WAVES][FLAT_ROW_LDS];
+  const int env = (int)(blockIdx.x * FLAT_WAVES + (threadIdx.x >> 6));
   if (env >= p.n_envs) return;
-  arcle::wave_flatten(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
+  arcle::wave_flatten(p, &tiles[threadIdx.x >> 6], nullptr, rows[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_pack_kernel(const StepParams p) {
@@ -163,6 +167,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const St
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_table_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
+  arcle::lut_init(lds.lut, (int)threadIdx.x, 64 * WAVES_PER_WG);
+  xl::wg_barrier();
   const int env = wave_of_launch();
   if (env >= p.n_envs) return;
   arcle::wave_reset_table(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
@@ -192,6 +198,9 @@ struct arcle_env {
   uint32_t* d_ops;
   uint32_t ops_host[ARCLE_MAX_OPS];
   int canonical;  // arcle::TBL_*: the installed table equals a canonical one
+  int8_t* flat_out;  // ARCLE_STEP_FLAT_OBS destination (arcle_set_flat_output)
+  int32_t flat_stride;
+  int flat_filtered;
   uint32_t* d_acct;
   uint64_t acct_steps;
   int device;
@@ -415,6 +424,8 @@ extern "C" int arcle_reset(arcle_env* e, const uint8_t* mask, void* stream) {
   return ARCLE_OK;
 }
 
+static int launch_flatten(arcle_env* e, int8_t* out, int32_t out_stride, int filtered, hipStream_t st);
+
 // ---- instantiation dispatch: (ingress, width class, table, accounting) -> kernel ----------------------------------
 static int width_class(const StepParams& p) {
   if (p.W < 16 || p.W > 32) return arcle::FW_GENERIC;
@@ -453,6 +464,10 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
   if ((flags & ARCLE_STEP_TRUNCATE) && !e->base.trunc) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_TRUNCATE without arcle_set_truncation");
+  if ((flags & ARCLE_STEP_RESAMPLE) && e->base.n_problems <= 0) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_RESAMPLE without arcle_set_sampler");
+  if ((flags & ARCLE_STEP_DENSE) && (!e->base.dense || !e->bufs.plane[ARCLE_PL_ANSWER])) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_DENSE without arcle_set_dense_output");
+  if ((flags & ARCLE_STEP_CONTINUE_RULE) && (ingress != arcle::INGRESS_MASK || !e->bufs.plane[ARCLE_PL_SELECTED]))
+    return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_CONTINUE_RULE needs mask ingress and the `selected` plane");
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.ingress = ingress;
@@ -474,6 +489,10 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
+  if (flags & ARCLE_STEP_FLAT_OBS) {  // the observation rows of the state this step produced, same stream, no host round trip
+    if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
+    return launch_flatten(e, e->flat_out, e->flat_stride, e->flat_filtered, st);
+  }
   return ARCLE_OK;
 }
 
@@ -513,7 +532,9 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
   if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
-  if (flags & ~(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED)) return fail(e, ARCLE_ERR_ARG, "flag not supported by the rollout kernels");
+  if (flags & ~(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT))
+    return fail(e, ARCLE_ERR_ARG, "flag not supported by the rollout kernels");
+  if ((flags & ARCLE_STEP_CONTINUE_RULE) && ingress != arcle::INGRESS_MASK) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_CONTINUE_RULE needs mask ingress");
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.ingress = ingress;
@@ -550,6 +571,56 @@ extern "C" int arcle_rollout_mask(arcle_env* e, int32_t n_steps, const int8_t* s
   return launch_rollout(e, arcle::INGRESS_MASK, n_steps, sel, op, reward, term, flags, stream);
 }
 
+extern "C" int arcle_set_sampler(arcle_env* e, const int32_t* pair_off, const int32_t* pair_cnt, int32_t n_problems, uint64_t seed,
+                                 int64_t env_base, int32_t* episode, int32_t* cur_task, uint32_t aug_flags) {
+  if (!e || !pair_off || !pair_cnt || !episode) return ARCLE_ERR_ARG;
+  if (n_problems <= 0) return fail(e, ARCLE_ERR_CONFIG, "the sampler needs at least one problem with a pair");
+  if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
+  if (aug_flags & ~(ARCLE_AUG_PERMUTE | ARCLE_AUG_ROT90)) return fail(e, ARCLE_ERR_ARG, "unknown augmentation flag");
+  e->base.pair_off = pair_off;
+  e->base.pair_cnt = pair_cnt;
+  e->base.n_problems = n_problems;
+  e->base.seed = seed;
+  e->base.env_base = env_base;
+  e->base.episode = episode;
+  e->base.cur_task = cur_task;
+  e->base.aug_flags = aug_flags;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_reset_sampled(arcle_env* e, const uint8_t* mask, void* stream) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (e->base.n_problems <= 0) return fail(e, ARCLE_ERR_CONFIG, "no sampler installed (arcle_set_sampler)");
+  DeviceGuard guard(e->device);
+  StepParams p = e->base;
+  p.rmask = mask;
+  p.task_idx = nullptr;
+  hipLaunchKernelGGL(arcle_reset_table_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_reset_from_table_aug(arcle_env* e, const int32_t* task_idx, const uint8_t* mask, const uint8_t* aug_k,
+                                          const uint8_t* aug_perm, void* stream) {
+  if (!e || !task_idx) return ARCLE_ERR_ARG;
+  if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
+  DeviceGuard guard(e->device);
+  StepParams p = e->base;
+  p.rmask = mask;
+  p.task_idx = task_idx;
+  p.aug_k = aug_k;
+  p.aug_perm = aug_perm;
+  hipLaunchKernelGGL(arcle_reset_table_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_set_dense_output(arcle_env* e, int32_t* dense_out) {
+  if (!e) return ARCLE_ERR_ARG;
+  e->base.dense = dense_out;
+  return ARCLE_OK;
+}
+
 extern "C" int arcle_set_truncation(arcle_env* e, uint8_t* trunc_out, int32_t step_limit) {
   if (!e) return ARCLE_ERR_ARG;
   if (trunc_out && step_limit <= 0) return fail(e, ARCLE_ERR_ARG, "step_limit must be positive");
@@ -558,25 +629,43 @@ extern "C" int arcle_set_truncation(arcle_env* e, uint8_t* trunc_out, int32_t st
   return ARCLE_OK;
 }
 
-extern "C" int arcle_flat_obs_size(const arcle_env* e) {
+extern "C" int arcle_flat_obs_size(const arcle_env* e, int filtered) {
   if (!e) return ARCLE_ERR_ARG;
-  int n = 0;
-  const int P = e->base.P;
-  const bool o2 = e->bufs.plane[ARCLE_PL_SELECTED] != nullptr, clip = e->bufs.plane[ARCLE_PL_CLIP] != nullptr;
-  n += 2 * P + 4 + 2;  // grid, grid_dim, input, input_dim, terminated, trials_remain
-  if (clip) n += P + 2;
-  if (o2) n += 4 * P + 6;  // background, object, object_sel, selected + active, object_dim, object_pos, parity
-  return n;
+  if (filtered && !(e->bufs.plane[ARCLE_PL_SELECTED] && e->bufs.plane[ARCLE_PL_CLIP])) return ARCLE_ERR_CONFIG;
+  return arcle::flat_obs_len(e->base, filtered);
 }
 
-extern "C" int arcle_flatten_obs(arcle_env* e, int8_t* out, void* stream) {
-  if (!e || !out) return ARCLE_ERR_ARG;
-  DeviceGuard guard(e->device);
+static int launch_flatten(arcle_env* e, int8_t* out, int32_t out_stride, int filtered, hipStream_t st) {
+  const int len = arcle_flat_obs_size(e, filtered);
+  if (len < 0) return fail(e, ARCLE_ERR_CONFIG, "the FilterO2ARC subset needs the O2ARCv2Env state planes");
+  if (out_stride < len || (out_stride & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return fail(e, ARCLE_ERR_ARG, "flat observation rows: 16-byte aligned, stride a multiple of 16 >= arcle_flat_obs_size()");
   StepParams p = e->base;
   p.flat_out = out;
-  p.flat_stride = arcle_flat_obs_size(e);
-  hipLaunchKernelGGL(arcle_flatten_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
+  p.flat_stride = out_stride;
+  p.flat_filter = filtered ? 1 : 0;
+  hipLaunchKernelGGL(arcle_flatten_kernel, dim3((unsigned)((p.n_envs + FLAT_WAVES - 1) / FLAT_WAVES)), dim3(64 * FLAT_WAVES), 0, st, p);
   HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_flatten_obs(arcle_env* e, int8_t* out, int32_t out_stride, int filtered, void* stream) {
+  if (!e || !out) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
+  return launch_flatten(e, out, out_stride, filtered, (hipStream_t)stream);
+}
+
+extern "C" int arcle_set_flat_output(arcle_env* e, int8_t* out, int32_t out_stride, int filtered) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (out) {
+    const int len = arcle_flat_obs_size(e, filtered);
+    if (len < 0) return fail(e, ARCLE_ERR_CONFIG, "the FilterO2ARC subset needs the O2ARCv2Env state planes");
+    if (out_stride < len || (out_stride & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+      return fail(e, ARCLE_ERR_ARG, "flat observation rows: 16-byte aligned, stride a multiple of 16 >= arcle_flat_obs_size()");
+  }
+  e->flat_out = out;
+  e->flat_stride = out_stride;
+  e->flat_filtered = filtered ? 1 : 0;
   return ARCLE_OK;
 }
 

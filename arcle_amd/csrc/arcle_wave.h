@@ -79,6 +79,8 @@ struct StepParams {
   int32_t* episode;    // int32 [N] episodes started so far per env (RNG stream position); may be NULL
   int32_t* cur_task;   // int32 [N] task-table index currently loaded per env; may be NULL
   const int32_t *pair_off, *pair_cnt;  // resample: per-task first table entry / number of entries, int32 [n_problems]
+  const uint8_t* aug_k;     // explicit augmentation (ARCLE_AUG_EXPLICIT): rot90 count per env, uint8 [N]
+  const uint8_t* aug_perm;  // explicit colour permutation per env, uint8 [N][16] (perm[c], c < 10)
   int32_t n_problems;
   int32_t pad_;
 };
@@ -810,12 +812,148 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
   ARCLE_ACCT(p.P);
 }
 
+// dst[:nh,:nw] = src[ai*i + bj*j + c0] (flat index into the staged plane), rest 0: rot90 / transposes of a whole plane
+ARCLE_DEV U4 plane_transform(const Wave& w, const U4& v, int nh, int nw, int ai, int bj, int c0) {
+  const int W = w.p.W;
+  w.stage(w.lds->a, v);
+  const uint8_t* ta = reinterpret_cast<const uint8_t*>(w.lds->a);
+  U4 o = u4_zero();
+  int i = w.r0, j = w.c0;
+  int src = ai * i + bj * j + c0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (i < nh && j < nw) o[k >> 2] |= (uint32_t)ta[imin(imax(src, 0), 1023)] << (8 * (k & 3));
+    j++;
+    src += bj;
+    if (j == W) {
+      j = 0;
+      i++;
+      src += ai - bj * W;
+    }
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// task draw + augmentation at reset (device side of Loader.pick / base.py:95-108 and of the research env's
+// augmentation, agents/env.py:31-42), keyed by (seed, GLOBAL env id, episode) so that a trajectory does not depend on
+// how the batch is sharded over GPUs
+// ------------------------------------------------------------------------------------------------
+ARCLE_HD uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct TaskDraw {
+  int problem, sub;  // index into pair_off / pair_cnt, pair within the problem
+  int rot_k;         // np.rot90 count 0..3
+  uint64_t perm;     // colour permutation, nibble c = perm[c] (c < 10); identity = 0x9876543210
+};
+#define ARCLE_PERM_IDENTITY 0x9876543210ull
+ARCLE_HD TaskDraw draw_task(uint64_t seed, uint64_t gid, uint32_t episode, int n_problems, const int32_t* pair_cnt,
+                            uint32_t aug_flags) {
+  const uint64_t G = 0x9E3779B97F4A7C15ull;
+  TaskDraw d;
+  uint64_t z = mix64(seed + gid * G + (uint64_t)episode * 0xD1B54A32D192ED03ull);
+  d.problem = (int)((uint32_t)(z >> 32) % (uint32_t)n_problems);
+  z = mix64(z + G);
+  d.sub = (int)((uint32_t)(z >> 32) % (uint32_t)pair_cnt[d.problem]);
+  z = mix64(z + G);
+  d.rot_k = (aug_flags & ARCLE_AUG_ROT90) ? (int)(z & 3u) : 0;
+  d.perm = ARCLE_PERM_IDENTITY;
+  if (aug_flags & ARCLE_AUG_PERMUTE) {  // Fisher-Yates over the ten colours
+    for (int i = 9; i > 0; i--) {
+      z = mix64(z + G);
+      const int j = (int)((uint32_t)(z >> 32) % (uint32_t)(i + 1));
+      const uint64_t a = (d.perm >> (4 * i)) & 15u, b = (d.perm >> (4 * j)) & 15u;
+      d.perm = (d.perm & ~((15ull << (4 * i)) | (15ull << (4 * j)))) | (b << (4 * i)) | (a << (4 * j));
+    }
+  }
+  return d;
+}
+ARCLE_DEV U4 permute_colours(const U4& v, uint64_t perm) {  // byte c < 10 -> perm[c]; other values unchanged
+  U4 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t x = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t c = (v[i] >> (8 * b)) & 0xffu;
+      const uint32_t m = c < 10u ? (uint32_t)(perm >> (4 * c)) & 15u : c;
+      x |= m << (8 * b);
+    }
+    o[i] = x;
+  }
+  return o;
+}
+// np.rot90(plane[:h,:w], k) zero-padded; updates (h, w)
+ARCLE_DEV U4 rot90_plane(const Wave& w, const U4& v, int& h, int& wd, int k) {
+  const int W = w.p.W;
+  if (k == 1) {
+    const U4 o = plane_transform(w, v, wd, h, -1, W, wd - 1);
+    const int t = h; h = wd; wd = t;
+    return o;
+  }
+  if (k == 2) return plane_transform(w, v, h, wd, -W, -1, (h - 1) * W + wd - 1);
+  if (k == 3) {
+    const U4 o = plane_transform(w, v, wd, h, 1, -W, (h - 1) * W);
+    const int t = h; h = wd; wd = t;
+    return o;
+  }
+  return v;
+}
+
+// Copies table entry `t` (augmented by perm / rot_k) into the env's input + answer planes and the record's dims.
+// Returns false (nothing written) when a rot90 does not fit the H x W plane (non-square max_grid_size).
+ARCLE_DEV bool load_task(const Wave& w, Rec& r, int t, int rot_k, uint64_t perm, U4& input_out) {
+  const StepParams& p = w.p;
+  U4 in = u4_zero(), an = u4_zero();
+  if (w.live) {
+    in = *reinterpret_cast<const U4*>(p.tbl_in + (size_t)t * p.PS + 16 * w.lane);
+    an = *reinterpret_cast<const U4*>(p.tbl_ans + (size_t)t * p.PS + 16 * w.lane);
+  }
+  int ih = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_in_dim[2 * t]), iw = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_in_dim[2 * t + 1]);
+  int ah = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_ans_dim[2 * t]), aw = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_ans_dim[2 * t + 1]);
+  if (perm != ARCLE_PERM_IDENTITY) {  // the reference permutes the un-padded grids: the padding stays 0
+    in = u4_and(permute_colours(in, perm), w.expand16(w.rect16(0, ih - 1, 0, iw - 1)));
+    an = u4_and(permute_colours(an, perm), w.expand16(w.rect16(0, ah - 1, 0, aw - 1)));
+  }
+  if (rot_k & 1) {
+    if (iw > p.H || ih > p.W || aw > p.H || ah > p.W) return false;
+  }
+  if (rot_k) {
+    in = rot90_plane(w, in, ih, iw, rot_k);
+    an = rot90_plane(w, an, ah, aw, rot_k);
+  }
+  w.store(ARCLE_PL_INPUT, in);
+  w.store(ARCLE_PL_ANSWER, an);
+  input_out = in;
+  r.w[0] = (r.w[0] & 0xffff0000u) | (uint32_t)ih | ((uint32_t)iw << 8);
+  r.w[3] = (r.w[3] & 0x0000ffffu) | ((uint32_t)ah << 16) | ((uint32_t)aw << 24);
+  return true;
+}
+
+// A new episode for `env` with a task drawn on the device: bumps the env's episode counter, records the table index.
+ARCLE_DEV bool load_sampled_task(const Wave& w, Rec& r, int env, U4& input_out) {
+  const StepParams& p = w.p;
+  const uint32_t ep = xl::uniform((uint32_t)p.episode[env]);
+  const TaskDraw d = draw_task(p.seed, (uint64_t)(p.env_base + env), ep, p.n_problems, p.pair_cnt, p.aug_flags);
+  const int t = p.pair_off[d.problem] + d.sub;
+  xl::lanes_converged();
+  if (w.lane == 0) {
+    p.episode[env] = (int32_t)(ep + 1u);
+    if (p.cur_task) p.cur_task[env] = t;
+  }
+  return load_task(w, r, t, d.rot_k, d.perm, input_out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // init_state (base.py:155-166 + o2arcenv.py:16-34 / arcenv.py:81-89), counters as in reset (base.py:73-79)
 // ------------------------------------------------------------------------------------------------
-ARCLE_DEV void init_state(const Wave& w, Rec& r, I2& cnt) {
+// `input`: the input plane when the caller just wrote it (a fresh task), else it is loaded
+ARCLE_DEV void init_state(const Wave& w, Rec& r, I2& cnt, const U4* input = nullptr) {
   const StepParams& p = w.p;
-  U4 in = w.load(ARCLE_PL_INPUT);
+  const U4 in = input ? *input : w.load(ARCLE_PL_INPUT);
   w.store(ARCLE_PL_GRID, in);
   U4 z = u4_zero();
   if (p.plane[ARCLE_PL_SELECTED]) w.store(ARCLE_PL_SELECTED, z);
@@ -925,11 +1063,20 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   StepOut out;
   out.reward = 0;
   out.bytes = 0;
-  if ((p.flags & ARCLE_STEP_AUTORESET) && r.term() != 0) {
-    init_state(w, r, cnt0);
-    out.term = 0;
-    out.bytes = (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
-    return out;
+  if (p.flags & (ARCLE_STEP_AUTORESET | ARCLE_STEP_RESAMPLE)) {
+    // next-step autoreset: an env whose episode ended (terminated, or — with ARCLE_STEP_TRUNCATE — out of steps) is
+    // re-initialised instead of executing the action; ARCLE_STEP_RESAMPLE first draws a new task on the device
+    const bool ended = r.term() != 0 || ((p.flags & ARCLE_STEP_TRUNCATE) && cnt0.x >= p.step_limit);
+    if (ended) {
+      bool ok = true;
+      U4 in = u4_zero();
+      if (p.flags & ARCLE_STEP_RESAMPLE) ok = load_sampled_task(w, r, w.env, in);
+      if (ok) init_state(w, r, cnt0, (p.flags & ARCLE_STEP_RESAMPLE) ? &in : nullptr);
+      else if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+      out.term = 0;
+      out.bytes = (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
+      return out;
+    }
   }
   bool bad_op = (uint32_t)op >= (uint32_t)p.n_ops;
   const uint32_t desc = bad_op ? 0u : decode_op<TBL>(p, op);
@@ -953,6 +1100,21 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   Sel sel;
   ingest_selection(w, sel, payload);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
+  if (ING == INGRESS_MASK && (p.flags & ARCLE_STEP_CONTINUE_RULE) &&
+      (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
+    // the O2ARC trace harness (tests/o2arc_check.py:169-170): an object op whose logged selection equals the env's
+    // current `selected` plane continues the active object, i.e. is sent with an empty selection
+    const U4 cur = w.load(ARCLE_PL_SELECTED);
+    const U4 vm = w.expand16(w.valid16);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) diff |= (cur[i] ^ sel.vals[i]) & vm[i];
+    if (!w.any(diff != 0)) {
+      sel.nz = sel.pos = 0;
+      sel.vals = u4_zero();
+      sel.any_nz = sel.any_pos = false;
+    }
+  }
 
   const Rec r_before = r;
   // reset_sel / keep_sel (object.py:10-41) set `selected` BEFORE the wrapped op runs; an object op that places its
@@ -1189,6 +1351,15 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
         trials = i8w(trials - 1);  // :174 int8 wrap
         r.put(ARCLE_REC_TRIALS, trials);
         submit_inc = 1;
+        if (p.flags & ARCLE_STEP_RESET_ON_SUBMIT) {
+          // base.py:179-180: init_state() rebinds current_state inside submit — the decrement, the `terminated` of a
+          // correct answer and the trials-exhausted check below all land on the discarded dict;
+          // what the caller sees is the re-initialised state, and reward() is evaluated on it
+          I2 keep = cnt0;
+          init_state(w, r, keep);
+          s.have_grid = false;
+          break;
+        }
         eq = grid_equals_answer<ACCT>(w, s, r) ? 1 : 0;
         if (eq) r.put(ARCLE_REC_TERMINATED, 1);
       }
@@ -1215,6 +1386,26 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   if (op == p.n_ops - 1) {
     if (eq < 0) eq = grid_equals_answer<ACCT>(w, s, r) ? 1 : 0;
     reward = eq;
+  }
+  if (p.flags & ARCLE_STEP_DENSE) {
+    // the research env's dense reward (agents/env.py:44-58) as an exact integer pair (correct cells, total cells);
+    // the host forms  sparse*100 - 1 + correct/total
+    need_grid<ACCT>(w, s);
+    const U4 a = w.load(ARCLE_PL_ANSWER);
+    const int gh = r.gh(), gw = r.gw(), ah = r.ah(), aw = r.aw();
+    const int mh = imin(gh, ah), mw = imin(gw, aw);
+    const U4 m = w.expand16(w.rect16(0, mh - 1, 0, mw - 1));
+    uint32_t same = 0;  // bit k: byte k of this lane matches inside the common rectangle
+#pragma unroll
+    for (int i = 0; i < 4; i++) same |= (flags2nib(nzflags((s.grid[i] ^ a[i]) | ~m[i])) ^ 0xfu) << (4 * i);
+    const int correct = w.wave_sum(__builtin_popcount(same & 0xffffu));
+    int total = mh * mw;
+    if ((gh <= ah) == (gw <= aw)) total += ah * aw > gh * gw ? ah * aw - gh * gw : gh * gw - ah * aw;
+    else total += (gh > ah ? gh - ah : ah - gh) * mw + (gw > aw ? gw - aw : aw - gw) * mh;
+    if (lane == 0) {
+      p.dense[2 * (size_t)w.env] = correct;
+      p.dense[2 * (size_t)w.env + 1] = total;
+    }
   }
   cnt0.x += 1;  // o2arcenv.py:142
   cnt0.y += submit_inc;
@@ -1354,84 +1545,119 @@ ARCLE_DEV void wave_reset(const StepParams& p, WaveLDS* lds, const U2* lut, int 
   store_cnt(p, env, lane, cnt);
 }
 
-// reset() with a caller-chosen task (base.py:95-108): the (input, answer) pair comes from the device task table
+// reset() with a caller-chosen task (base.py:95-108) or — task_idx == NULL — a task drawn on the device: the (input,
+// answer) pair comes from the device task table, optionally augmented (agents/env.py:31-42)
 ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
   if (p.rmask && !xl::uniform((uint32_t)p.rmask[env])) return;
-  const int t = (int)xl::uniform((uint32_t)p.task_idx[env]);
-  if (t < 0 || t >= p.n_tasks) {
-    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_TASK);
-    return;
-  }
   Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
   w.set_env(env);
-  U4 in = u4_zero(), an = u4_zero();
-  if (w.live) {
-    in = *reinterpret_cast<const U4*>(p.tbl_in + (size_t)t * p.PS + 16 * lane);
-    an = *reinterpret_cast<const U4*>(p.tbl_ans + (size_t)t * p.PS + 16 * lane);
-  }
-  w.store(ARCLE_PL_INPUT, in);
-  w.store(ARCLE_PL_ANSWER, an);
-  w.store(ARCLE_PL_GRID, in);
-  U4 z = u4_zero();
-  if (p.plane[ARCLE_PL_SELECTED]) w.store(ARCLE_PL_SELECTED, z);
-  if (p.plane[ARCLE_PL_CLIP]) w.store(ARCLE_PL_CLIP, z);
-  if (p.plane[ARCLE_PL_OBJECT]) w.store(ARCLE_PL_OBJECT, z);
-  if (p.plane[ARCLE_PL_OBJECT_SEL]) w.store(ARCLE_PL_OBJECT_SEL, z);
-  if (p.plane[ARCLE_PL_BACKGROUND]) w.store(ARCLE_PL_BACKGROUND, z);
   Rec r;
-  const uint32_t idim = (uint32_t)(uint8_t)p.tbl_in_dim[2 * t] | ((uint32_t)(uint8_t)p.tbl_in_dim[2 * t + 1] << 8);
-  const uint32_t adim = (uint32_t)(uint8_t)p.tbl_ans_dim[2 * t] | ((uint32_t)(uint8_t)p.tbl_ans_dim[2 * t + 1] << 8);
-  r.w[0] = idim | (idim << 16);
-  r.w[1] = 0;
-  r.w[2] = ((uint32_t)p.max_trial & 0xffu) << 16;
-  r.w[3] = adim << 16;
+  r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+  U4 in = u4_zero();
+  bool ok;
+  if (p.task_idx) {
+    const int t = (int)xl::uniform((uint32_t)p.task_idx[env]);
+    if (t < 0 || t >= p.n_tasks) {
+      if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_TASK);
+      return;
+    }
+    int k = 0;
+    uint64_t perm = ARCLE_PERM_IDENTITY;
+    if (p.aug_k) k = (int)xl::uniform((uint32_t)p.aug_k[env]) & 3;
+    if (p.aug_perm) {
+      perm = 0;
+      for (int c = 0; c < 10; c++) perm |= (uint64_t)(xl::uniform((uint32_t)p.aug_perm[16 * (size_t)env + c]) & 15u) << (4 * c);
+    }
+    ok = load_task(w, r, t, k, perm, in);
+    if (ok && p.cur_task && lane == 0) p.cur_task[env] = t;
+  } else {
+    ok = load_sampled_task(w, r, env, in);
+  }
+  if (!ok) {
+    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+    return;
+  }
   I2 cnt;
-  cnt.x = cnt.y = 0;
+  init_state(w, r, cnt, &in);
   store_rec(p, env, lane, r);
   store_cnt(p, env, lane, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
-// flattened observation row of one env (Gymnasium FlattenObservation key order; GPTPolicy.py:17-35)
+// flattened observation row of one env — what the reference's policies consume: gymnasium FlattenObservation of the
+// state dict (keys sorted, nested object_states in place; agents/models/GPTPolicy.py:17-35 `unflatten_vec`), or of its
+// FilterO2ARC subset (agents/env.py:109-126; agents/train.py:61-68 stacks FlattenObservation on it):
+//   full     clip clip_dim grid grid_dim input input_dim | active background object object_dim object_pos object_sel
+//            rotation_parity | selected terminated trials_remain                       = 7*H*W + 14 bytes (6314 at 30x30)
+//   filtered active clip clip_dim grid grid_dim object object_dim object_pos trials_remain = 3*H*W + 10 bytes (2710)
+// The segments start at arbitrary byte offsets, so the row is assembled byte-accurately in the wave's LDS row buffer and
+// then streamed out with aligned, fully coalesced 16 B stores (row stride = a multiple of 16 >= the logical length).
 // ------------------------------------------------------------------------------------------------
-ARCLE_DEV void flat_plane(const Wave& w, int8_t* row, int& off, int pl) {
+struct FlatRow {
+  uint8_t* buf;  // LDS, >= flat stride bytes
+  int off;
+};
+ARCLE_DEV void flat_plane(const Wave& w, FlatRow& fr, int pl) {
   if (!w.p.plane[pl]) return;
-  U4 v = w.load_hbm(pl);
-  int8_t* d = row + off + 16 * w.lane;
+  const U4 v = w.load_hbm(pl);
+  uint8_t* d = fr.buf + fr.off + 16 * w.lane;
 #pragma unroll
   for (int k = 0; k < 16; k++)
-    if ((w.valid16 >> k) & 1u) d[k] = (int8_t)u4_byte(v, k);
-  off += w.p.P;
+    if ((w.valid16 >> k) & 1u) d[k] = (uint8_t)u4_byte(v, k);
+  fr.off += w.p.P;
 }
-ARCLE_DEV void flat_scalar(const Wave& w, int8_t* row, int& off, const int8_t* rec, int field, int n) {
-  if (w.lane < n) row[off + w.lane] = rec[field + w.lane];
-  off += n;
+ARCLE_DEV void flat_scalar(const Wave& w, FlatRow& fr, const Rec& r, int field, int n) {
+  if (w.lane < n) fr.buf[fr.off + w.lane] = (uint8_t)r.ub(field + (w.lane < n ? w.lane : 0));
+  fr.off += n;
 }
-ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
+ARCLE_HD int flat_obs_len(const StepParams& p, int filtered) {
+  const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
+  if (filtered) return 3 * p.P + 10;
+  return 2 * p.P + 6 + (clip ? p.P + 2 : 0) + (o2 ? 4 * p.P + 6 : 0);
+}
+ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, uint8_t* rowbuf, int env, int lane) {
   Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
   w.set_env(env);
-  int8_t* row = p.flat_out + (size_t)env * p.flat_stride;
-  const int8_t* rec = p.rec + (size_t)env * ARCLE_REC_BYTES;
+  const Rec r = load_rec(p, env);
   const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
-  int off = 0;
-  flat_plane(w, row, off, ARCLE_PL_CLIP);
-  if (clip) flat_scalar(w, row, off, rec, ARCLE_REC_CLIP_DIM, 2);
-  flat_plane(w, row, off, ARCLE_PL_GRID);
-  flat_scalar(w, row, off, rec, ARCLE_REC_GRID_DIM, 2);
-  flat_plane(w, row, off, ARCLE_PL_INPUT);
-  flat_scalar(w, row, off, rec, ARCLE_REC_INPUT_DIM, 2);
-  if (o2) {
-    flat_scalar(w, row, off, rec, ARCLE_REC_ACTIVE, 1);
-    flat_plane(w, row, off, ARCLE_PL_BACKGROUND);
-    flat_plane(w, row, off, ARCLE_PL_OBJECT);
-    flat_scalar(w, row, off, rec, ARCLE_REC_OBJECT_DIM, 2);
-    flat_scalar(w, row, off, rec, ARCLE_REC_OBJECT_POS, 2);
-    flat_plane(w, row, off, ARCLE_PL_OBJECT_SEL);
-    flat_scalar(w, row, off, rec, ARCLE_REC_PARITY, 1);
-    flat_plane(w, row, off, ARCLE_PL_SELECTED);
+  FlatRow fr;
+  fr.buf = rowbuf;
+  fr.off = 0;
+  if (p.flat_filter) {
+    flat_scalar(w, fr, r, ARCLE_REC_ACTIVE, 1);
+    flat_plane(w, fr, ARCLE_PL_CLIP);
+    flat_scalar(w, fr, r, ARCLE_REC_CLIP_DIM, 2);
+    flat_plane(w, fr, ARCLE_PL_GRID);
+    flat_scalar(w, fr, r, ARCLE_REC_GRID_DIM, 2);
+    flat_plane(w, fr, ARCLE_PL_OBJECT);
+    flat_scalar(w, fr, r, ARCLE_REC_OBJECT_DIM, 2);
+    flat_scalar(w, fr, r, ARCLE_REC_OBJECT_POS, 2);
+    flat_scalar(w, fr, r, ARCLE_REC_TRIALS, 1);
+  } else {
+    flat_plane(w, fr, ARCLE_PL_CLIP);
+    if (clip) flat_scalar(w, fr, r, ARCLE_REC_CLIP_DIM, 2);
+    flat_plane(w, fr, ARCLE_PL_GRID);
+    flat_scalar(w, fr, r, ARCLE_REC_GRID_DIM, 2);
+    flat_plane(w, fr, ARCLE_PL_INPUT);
+    flat_scalar(w, fr, r, ARCLE_REC_INPUT_DIM, 2);
+    if (o2) {
+      flat_scalar(w, fr, r, ARCLE_REC_ACTIVE, 1);
+      flat_plane(w, fr, ARCLE_PL_BACKGROUND);
+      flat_plane(w, fr, ARCLE_PL_OBJECT);
+      flat_scalar(w, fr, r, ARCLE_REC_OBJECT_DIM, 2);
+      flat_scalar(w, fr, r, ARCLE_REC_OBJECT_POS, 2);
+      flat_plane(w, fr, ARCLE_PL_OBJECT_SEL);
+      flat_scalar(w, fr, r, ARCLE_REC_PARITY, 1);
+      flat_plane(w, fr, ARCLE_PL_SELECTED);
+    }
+    flat_scalar(w, fr, r, ARCLE_REC_TERMINATED, 1);
+    flat_scalar(w, fr, r, ARCLE_REC_TRIALS, 1);
   }
-  flat_scalar(w, row, off, rec, ARCLE_REC_TERMINATED, 1);
-  flat_scalar(w, row, off, rec, ARCLE_REC_TRIALS, 1);
+  if (lane < 16 && fr.off + lane < p.flat_stride) rowbuf[fr.off + lane] = 0;  // row padding up to the stride
+  xl::lds_fence();
+  int8_t* row = p.flat_out + (size_t)env * p.flat_stride;
+  for (int c = 16 * lane; c < p.flat_stride; c += 1024)
+    *reinterpret_cast<U4*>(row + c) = *reinterpret_cast<const U4*>(rowbuf + c);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,13 +1,16 @@
 """Multi-GPU: the env batch is partitioned across ranks (one process per GPU, torch.distributed; backend
 "nccl" is RCCL over xGMI on ROCm).  Envs are independent — `step` has no cross-env dependency
 (/root/reference/arcle/envs/o2arcenv.py:130-151 touches only `self`) — so the data path needs NO collective:
-rank g owns the contiguous global env ids [g*n, (g+1)*n).  The only exchange that ever happens is the optional
-gather of what a central learner consumes, `(obs, reward, done)`; it is a single all_gather_into_tensor per
-field (one-shot, every xGMI link carries one shard) and lives here, outside the step path.
+rank g owns the contiguous global env ids [g*n, (g+1)*n) and keys its device-side task draws by the GLOBAL env id
+(arcle_amd/sampling.py), so the trajectories do not depend on the number of GPUs.  The only exchange that ever happens
+is the optional gather of what a central learner consumes, (grid, grid_dim, reward, done): the step outputs are packed
+into one 912-byte record per env (arcle_pack_obs) and moved with ONE all_gather_into_tensor per step (one-shot, every
+xGMI link carries one shard).  It lives here, outside the step path.
 """
-import numpy as np
 import torch
 import torch.distributed as dist
+
+from .engine import EnvBatch
 
 
 def shard_range(global_envs, world_size, rank):
@@ -17,19 +20,10 @@ def shard_range(global_envs, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def shard_seed(seed, global_env_id):
-    """Per-env RNG substream keyed by the GLOBAL env id, so results do not depend on the number of GPUs
-    (splitmix64 finaliser)."""
-    z = (int(seed) ^ (int(global_env_id) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-    return z ^ (z >> 31)
-
-
 class ShardedVecEnv:
-    """Wraps this rank's local vector env (anything with the ARCVecEnv step/reset interface and `.N`) and adds
-    global bookkeeping + the (obs, reward, done) gather.  `local_env_factory(n_local, lo, hi)` builds the local
-    env for global ids [lo, hi)."""
+    """This rank's shard of a global batch of `global_envs` envs.  `local_env_factory(n_local, lo, hi)` builds the local
+    vector env for the global ids [lo, hi) — for the HIP path: `lambda n, lo, hi: ARCVecEnv(cls, n, loader, seed=S,
+    env_base=lo, ...)` (env_base makes the device-side task draws follow the global env id)."""
 
     def __init__(self, global_envs, local_env_factory, group=None):
         self.group = group
@@ -41,6 +35,7 @@ class ShardedVecEnv:
             raise ValueError("global_envs must be divisible by the number of ranks (all_gather_into_tensor needs equal shards)")
         self.local = local_env_factory(self.hi - self.lo, self.lo, self.hi)
         self.N = self.hi - self.lo
+        self._packed = self._full = None
 
     # local stepping: no communication
     def reset(self, **kw):
@@ -59,18 +54,15 @@ class ShardedVecEnv:
         """This rank's rows of a [global_envs, ...] tensor (e.g. actions produced by a central policy)."""
         return global_tensor[self.lo:self.hi]
 
-    def gather(self, obs, reward, terminated, keys=("grid", "grid_dim")):
-        """All ranks receive the [global_envs, ...] versions of the selected obs fields, reward and done.
-        One all_gather_into_tensor per field: shard i lands at rows [i*n, (i+1)*n) — i.e. global env order."""
-        out = {}
-        for k in keys:
-            out[k] = self._all_gather(obs[k])
-        return out, self._all_gather(reward), self._all_gather(terminated.to(torch.uint8)).bool()
-
-    def _all_gather(self, t):
-        t = t.contiguous()
-        if self.world == 1:
-            return t
-        full = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(full, t, group=self.group)
-        return full
+    def gather(self):
+        """All ranks receive (grid [G,H,W] int8, grid_dim [G,2] int8, reward [G] int32, terminated [G] bool) of the step
+        that just ran, G = global_envs, rows in global env order.  One packing launch + ONE all_gather_into_tensor."""
+        b = self.local.batch
+        if self._packed is None:
+            self._packed = torch.empty((self.N, b.packed_obs_size()), dtype=torch.uint8, device=b.device)
+            self._full = self._packed if self.world == 1 else torch.empty(
+                (self.world * self.N, self._packed.shape[1]), dtype=torch.uint8, device=b.device)
+        b.packed_obs(self._packed)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self._full, self._packed, group=self.group)  # shard i -> rows [i*n, (i+1)*n)
+        return EnvBatch.unpack_obs(self._full, b.H, b.W)

@@ -27,6 +27,13 @@ KIND_PLANES = {  # which planes each env kind's state dict holds (o2arcenv.py:16
 }
 STEP_AUTORESET = 1
 STEP_ELIDE_SELECTED = 2
+STEP_TRUNCATE = 4
+STEP_RESAMPLE = 8
+STEP_DENSE = 16
+STEP_CONTINUE_RULE = 32
+STEP_RESET_ON_SUBMIT = 64
+STEP_FLAT_OBS = 128
+AUG_PERMUTE, AUG_ROT90 = 1, 2
 ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK = 1, 2, 4
 
 
@@ -43,6 +50,8 @@ class EnvBatch:
                                 "arcle_amd has no CPU fallback")
         self.L = _lib.lib()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.index is None:  # "cuda" means torch's CURRENT device, not ordinal 0 (multi-GPU ranks)
+            self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
         self.N, self.H, self.W, self.P = int(n_envs), int(H), int(W), int(H) * int(W)
         if plane_stride is None:
             plane_stride = int(os.environ.get("ARCLE_PLANE_STRIDE", "0")) or ((self.P + 127) & ~127)  # ARCLE_DEFAULT_PLANE_STRIDE
@@ -55,7 +64,7 @@ class EnvBatch:
         self.cnt = torch.zeros((self.N, 2), dtype=torch.int32, device=self.device)
         self.reward = torch.zeros(self.N, dtype=torch.int32, device=self.device)
         self.term = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
-        cfg = _lib.Config(self.N, self.H, self.W, self.max_trial, self.device.index or 0, self.PS)
+        cfg = _lib.Config(self.N, self.H, self.W, self.max_trial, self.device.index, self.PS)
         bufs = _lib.Buffers()
         for k, i in PLANE_ID.items():
             bufs.plane[i] = self.planes[k].data_ptr() if k in self.planes else None
@@ -151,14 +160,54 @@ class EnvBatch:
                                                 _ptr(self._table[3]), T), "arcle_set_task_table")
         self.n_tasks = T
 
-    def reset_from_table(self, task_idx, mask=None):
-        """task_idx: int32 [N] (device) indices into the task table; mask: optional uint8/bool [N]."""
+    def reset_from_table(self, task_idx, mask=None, aug_k=None, aug_perm=None):
+        """task_idx: int32 [N] (device) indices into the task table; mask: optional uint8/bool [N].
+        aug_k uint8 [N] (np.rot90 count) / aug_perm uint8 [N,10] (colour permutation): explicit augmentation per env
+        (agents/env.py:31-42 of the reference)."""
         if task_idx.dtype != torch.int32 or task_idx.device != self.device or not task_idx.is_contiguous():
             task_idx = task_idx.to(device=self.device, dtype=torch.int32).contiguous()
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
-        self._check(self.L.arcle_reset_from_table(self._h, _ptr(task_idx), _ptr(m), self._stream()), "arcle_reset_from_table")
+        if aug_k is None and aug_perm is None:
+            self._check(self.L.arcle_reset_from_table(self._h, _ptr(task_idx), _ptr(m), self._stream()), "arcle_reset_from_table")
+            return
+        k = None if aug_k is None else torch.as_tensor(aug_k, device=self.device).to(torch.uint8).contiguous()
+        pm = None
+        if aug_perm is not None:
+            pm = torch.zeros((self.N, 16), dtype=torch.uint8, device=self.device)
+            pm[:, :10] = torch.as_tensor(aug_perm, device=self.device).to(torch.uint8)
+        self._check(self.L.arcle_reset_from_table_aug(self._h, _ptr(task_idx), _ptr(m), _ptr(k), _ptr(pm), self._stream()),
+                    "arcle_reset_from_table_aug")
+        torch.cuda.current_stream(self.device).synchronize()  # (k / pm are temporaries)
+
+    def set_sampler(self, pair_off, pair_cnt, seed, env_base=0, aug_flags=0):
+        """Device-side task choice (arcle_set_sampler): pair_off / pair_cnt = first table entry / number of entries of
+        every candidate problem.  Draws are keyed by (seed, env_base + env, episode)."""
+        self._pair = [torch.as_tensor(np.asarray(x, np.int32)).to(self.device) for x in (pair_off, pair_cnt)]  # keep alive
+        assert int(self._pair[1].min()) > 0, "every candidate problem needs at least one pair"
+        if not hasattr(self, "episode"):
+            self.episode = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+            self.cur_task = torch.full((self.N,), -1, dtype=torch.int32, device=self.device)
+        self._check(self.L.arcle_set_sampler(self._h, _ptr(self._pair[0]), _ptr(self._pair[1]), len(pair_cnt),
+                                             ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), ctypes.c_int64(int(env_base)),
+                                             _ptr(self.episode), _ptr(self.cur_task), int(aug_flags)), "arcle_set_sampler")
+
+    def reset_sampled(self, mask=None):
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        self._check(self.L.arcle_reset_sampled(self._h, _ptr(m), self._stream()), "arcle_reset_sampled")
+
+    def set_truncation(self, step_limit):
+        """ARCLE_STEP_TRUNCATE output: self.trunc[env] = action_steps >= step_limit (gymnasium TimeLimit)."""
+        self.trunc = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+        self._check(self.L.arcle_set_truncation(self._h, _ptr(self.trunc), int(step_limit)), "arcle_set_truncation")
+
+    def set_dense_output(self):
+        """ARCLE_STEP_DENSE output: self.dense int32 [N,2] = (matching cells, total cells) of agents/env.py:44-58."""
+        self.dense = torch.zeros((self.N, 2), dtype=torch.int32, device=self.device)
+        self._check(self.L.arcle_set_dense_output(self._h, _ptr(self.dense)), "arcle_set_dense_output")
 
     # ---- the hot path -------------------------------------------------------------------------
     def reset(self, mask=None):
@@ -200,29 +249,54 @@ class EnvBatch:
         if rc != 0:
             self._check(rc, "arcle_step_bbox")
 
-    def rollout(self, payload, op, flags=0, point=False):
-        """T steps in one launch.  payload int32 [T,N,4] (bbox) or [T,N,2] (point), op int32 [T,N];
-        returns (reward int32 [T,N], terminated uint8 [T,N]).  Same semantics as T step_bbox/step_point calls."""
+    def rollout(self, payload, op, flags=0, point=False, mask=False):
+        """T steps in one launch.  payload int32 [T,N,4] (bbox) / [T,N,2] (point) / int8 [T,N,H,W] (mask=True), op
+        int32 [T,N]; returns (reward int32 [T,N], terminated uint8 [T,N]).  Same semantics as T step_* calls."""
         T = int(op.shape[0])
-        payload = payload.to(device=self.device, dtype=torch.int32).contiguous()
         op = op.to(device=self.device, dtype=torch.int32).contiguous()
-        assert payload.shape == (T, self.N, 2 if point else 4) and op.shape == (T, self.N)
+        if mask:
+            payload = payload.to(device=self.device, dtype=torch.int8).contiguous()
+            assert payload.shape == (T, self.N, self.H, self.W)
+        else:
+            payload = payload.to(device=self.device, dtype=torch.int32).contiguous()
+            assert payload.shape == (T, self.N, 2 if point else 4)
+        assert op.shape == (T, self.N)
         reward = torch.empty((T, self.N), dtype=torch.int32, device=self.device)
         term = torch.empty((T, self.N), dtype=torch.uint8, device=self.device)
-        fn = self.L.arcle_rollout_point if point else self.L.arcle_rollout_bbox
+        fn = self.L.arcle_rollout_mask if mask else (self.L.arcle_rollout_point if point else self.L.arcle_rollout_bbox)
         self._check(fn(self._h, T, _ptr(payload), _ptr(op), _ptr(reward), _ptr(term), int(flags), self._stream()),
                     "arcle_rollout")
         return reward, term
 
-    def flat_obs(self, out=None):
+    def flat_obs_size(self, filtered=False):
+        """Logical row length of the flattened observation (7*H*W + 14 for O2ARCv2Env; 3*H*W + 10 filtered)."""
+        n = self.L.arcle_flat_obs_size(self._h, int(filtered))
+        if n < 0:
+            raise ArcleHipError("the FilterO2ARC subset needs the O2ARCv2Env state planes")
+        return n
+
+    def _flat_buffer(self, filtered):
+        L = self.flat_obs_size(filtered)
+        return torch.empty((self.N, (L + 15) & ~15), dtype=torch.int8, device=self.device), L
+
+    def flat_obs(self, out=None, filtered=False):
         """[N, L] int8 flattened observations in Gymnasium FlattenObservation key order (agents/models/GPTPolicy.py:
-        17-35 of the reference); L = 7*H*W + 14 for O2ARCv2Env.  One kernel, written into `out` if given."""
-        L = self.L.arcle_flat_obs_size(self._h)
+        17-35 of the reference), or the FilterO2ARC subset (agents/env.py:109-126).  Returned as a view of a [N, stride]
+        buffer (stride = L rounded up to 16) so that every row store is aligned; pass that buffer back as `out` to reuse it."""
+        L = self.flat_obs_size(filtered)
         if out is None:
-            out = torch.empty((self.N, L), dtype=torch.int8, device=self.device)
-        assert out.shape == (self.N, L) and out.dtype == torch.int8 and out.is_contiguous() and out.device == self.device
-        self._check(self.L.arcle_flatten_obs(self._h, _ptr(out), self._stream()), "arcle_flatten_obs")
-        return out
+            out, _ = self._flat_buffer(filtered)
+        assert out.dtype == torch.int8 and out.device == self.device and out.shape == (self.N, (L + 15) & ~15) and out.is_contiguous()
+        self._check(self.L.arcle_flatten_obs(self._h, _ptr(out), out.shape[1], int(filtered), self._stream()), "arcle_flatten_obs")
+        return out[:, :L]
+
+    def set_flat_output(self, filtered=False):
+        """Installs the destination of STEP_FLAT_OBS: every step call with that flag also refreshes `self.flat` ([N, L])."""
+        self._flat_buf, L = self._flat_buffer(filtered)
+        self._check(self.L.arcle_set_flat_output(self._h, _ptr(self._flat_buf), self._flat_buf.shape[1], int(filtered)),
+                    "arcle_set_flat_output")
+        self.flat = self._flat_buf[:, :L]
+        return self.flat
 
     def packed_obs_size(self):
         return int(self.L.arcle_packed_obs_size(self._h))

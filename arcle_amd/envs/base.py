@@ -12,20 +12,20 @@ import numpy as np
 import torch
 
 from .. import actions, spaces
-from ..engine import EnvBatch, ST_BAD_OP, ST_ROTATE_DOMAIN
+from ..engine import EnvBatch, ST_BAD_OP, ST_ROTATE_DOMAIN, STEP_RESET_ON_SUBMIT
 from ..loaders import Loader
 
 
 class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
     """Abstract ARC environment (base.py:15-66).  Subclasses define KIND, STATE_KEYS and create_operations()."""
 
-    ansi256arc = [0, 12, 9, 10, 11, 8, 13, 208, 14, 52]
-    metadata = {"render_modes": ["ansi"], "render_fps": 5}
+    metadata = {"render_modes": [], "render_fps": 5}
     KIND = "raw"
 
     def __init__(self, data_loader: Loader, max_grid_size, colors, max_trial=-1, render_mode=None, render_size=None,
                  device=None):
-        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        if render_mode is not None:
+            raise NotImplementedError("rendering is outside the ported hot path (SURVEY.md §2 row 1)")
         self.loader = data_loader
         self.H, self.W = int(max_grid_size[0]), int(max_grid_size[1])
         self.colors = colors
@@ -62,7 +62,8 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self._batch = self._new_batch(1)
         return self._batch
 
-    def _state_from_device(self, b, n=0):
+    @staticmethod
+    def _state_from_device(b, n=0):
         """Builds the reference's obs dict (numpy int8 arrays) for env n of batch b."""
         rec = b.rec[n].cpu().numpy()
         f = lambda name: rec[slice(*_span(name))].copy()  # noqa: E731
@@ -81,7 +82,8 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
                 "rotation_parity": f("rotation_parity")}
         return st
 
-    def _state_to_device(self, b, state, n=0):
+    @staticmethod
+    def _state_to_device(b, state, n=0):
         dev = b.device
         put = lambda name, arr: b.plane(name)[n].copy_(torch.as_tensor(np.asarray(arr, np.int8), device=dev))  # noqa: E731
         put("input", state["input"])
@@ -120,8 +122,8 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self.adaptation = True if _ad is None else bool(_ad)
             _ros = options.get("reset_on_submit")
             self.reset_on_submit = False if _ros is None else _ros
-        if self.reset_on_submit:
-            raise NotImplementedError("reset_on_submit=True (base.py:179-180, SURVEY.md A.6-7) is not supported on device")
+        if spaces.HAVE_GYMNASIUM:
+            super().reset(seed=seed)  # seeds np_random like the reference's super().reset (base.py:70)
         ex_in, ex_out, tt_in, tt_out, desc = self.loader.pick(data_index=self.prob_index)
         src_in, src_out = (ex_in, ex_out) if self.adaptation else (tt_in, tt_out)
         if self.subprob_index is None:
@@ -145,15 +147,26 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
                 "answer": np.pad(self.answer, [(0, self.H - osize[0]), (0, self.W - osize[1])], constant_values=0),
                 "answer_dim": osize}
 
+    def _step_flags(self):
+        return STEP_RESET_ON_SUBMIT if self.reset_on_submit else 0
+
     def _device_step(self, b, action):
         op = int(action["operation"])
-        if not 0 <= op < len(self.operations):
+        if not -len(self.operations) <= op < len(self.operations):
             raise IndexError("list index out of range")  # what self.operations[op] raises in the reference
+        op %= len(self.operations)  # (a negative index counts from the end, like the Python list of the reference)
         sel = np.asarray(action["selection"])
         if sel.shape != (self.H, self.W):
             raise ValueError(f"selection must have shape {(self.H, self.W)}")
+        fn = self.operations[op]
+        if not isinstance(fn, actions.Operation) and not actions.is_submit(fn):
+            # an arbitrary Python callable in the table (base.py:140-142 allows it; agents/wrapper.py:53-57): applied on the
+            # host to the fetched state, written back, and the step's bookkeeping done by a device no-op slot
+            state = self._state_from_device(b)
+            fn(state, action)
+            self._state_to_device(b, state)
         sel_t = torch.as_tensor(sel.astype(np.int8, copy=False), device=b.device).reshape(1, self.H, self.W)
-        reward, term = b.step_mask(sel_t, torch.tensor([op], dtype=torch.int32, device=b.device))
+        reward, term = b.step_mask(sel_t, torch.tensor([op], dtype=torch.int32, device=b.device), self._step_flags())
         st = b.status()
         if st & ST_ROTATE_DOMAIN:
             raise ValueError("Rotate/Flip outside its domain (the reference raises here too: object.py:45 / int8 overflow)")
@@ -164,31 +177,49 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
     def step(self, action):
         """o2arcenv.py:130-147 / arcenv.py:60-76,155-172."""
         b = self.batch
-        dev_reward, term = self._device_step(b, action)
-        self.last_action_op = int(action["operation"])
-        self.last_action = action
-        self.current_state = self._state_from_device(b)
-        cnt = b.cnt[0].cpu().numpy()
-        self.action_steps, self.submit_count = int(cnt[0]), int(cnt[1])
-        # a subclass that overrides reward() (e.g. the dense reward of agents/env.py:44-58) is evaluated on the host
-        reward = dev_reward if type(self).reward is AbstractARCEnv.reward else self.reward(self.current_state)
+        if type(self).transition is not AbstractARCEnv.transition:
+            # a subclass overrides transition() (the reference's step calls self.transition(self.current_state, action),
+            # o2arcenv.py:134): run it on the state dict, then write the dict back and do the bookkeeping here
+            self.transition(self.current_state, action)
+            self._state_to_device(b, self.current_state)
+            self.action_steps += 1
+            b.cnt[0, 0] = self.action_steps
+            b.cnt[0, 1] = self.submit_count
+            self.last_action_op = int(action["operation"])
+            self.last_action = action
+            reward = self.reward(self.current_state)
+            term = bool(self.current_state["terminated"][0])
+        else:
+            dev_reward, term = self._device_step(b, action)
+            self.last_action_op = int(action["operation"]) % len(self.operations)
+            self.last_action = action
+            self.current_state = self._state_from_device(b)
+            cnt = b.cnt[0].cpu().numpy()
+            self.action_steps, self.submit_count = int(cnt[0]), int(cnt[1])
+            # a subclass that overrides reward() (e.g. the dense reward of agents/env.py:44-58) is evaluated on the host;
+            # so is the reward of a host-applied last op
+            host_reward = type(self).reward is not AbstractARCEnv.reward or not isinstance(
+                self.operations[self.last_action_op], actions.Operation) and not actions.is_submit(self.operations[self.last_action_op])
+            reward = self.reward(self.current_state) if host_reward else dev_reward
         self.last_reward = reward
         self.info["steps"] = self.action_steps
         if "submit_count" in self.info:
             self.info["submit_count"] = self.submit_count
-        self.render()
         return self.current_state, reward, term, self.truncated, self.info
 
     def transition(self, state, action):
         """o2arcenv.py:149-151 — applies one operation to `state` IN PLACE (README usage:
         `env.transition(deepcopy(state), action)`).  The given dict is uploaded into a scratch env,
-        stepped by the kernel and written back; the env's own counters are untouched."""
+        stepped by the kernel and written back.  Like the reference, a Submit routed through here counts
+        (`self.submit_count`, base.py:175); `action_steps` does not move."""
         if self._scratch is None:
             self._scratch = self._new_batch(1)
         s = self._scratch
         s.set_tasks([self.input_], [self.answer])
         self._state_to_device(s, state)
+        s.cnt.zero_()
         self._device_step(s, action)
+        self.submit_count += int(s.cnt[0, 1])
         new = self._state_from_device(s)
         for k, v in new.items():
             if k == "object_states":
@@ -232,31 +263,8 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
     def create_operations(self):
         pass
 
-    # ---- rendering (base.py:185-224): ANSI only ----------------------------------------------------
     def render(self):
-        if self.render_mode == "ansi":
-            self.render_ansi()
-
-    def render_ansi(self):
-        if self.rendering is None:
-            self.rendering = True
-            print("\033[2J", end="")
-        print(f"\033[{self.H + 3}A\033[K", end="")
-        print("Problem Description:")
-        print(self.description, "\033[K")
-        grid, grid_dim = self.current_state["grid"], self.current_state["grid_dim"]
-        sel = self.current_state.get("selected")
-        for i in range(self.H):
-            for j in range(self.W):
-                st = "[]" if sel is not None and sel[i, j] else "  "
-                if i >= grid_dim[0] or j >= grid_dim[1]:
-                    print(f"\033[47m{st}", end="")
-                else:
-                    print("\033[48;5;" + str(self.ansi256arc[grid[i, j] % 10]) + f"m{st}", end="")
-            print("\033[0m")
-        print("Dimension : " + str(grid_dim), end=" ")
-        print("Action : " + str(self.op_names[self.last_action_op] if self.last_action_op is not None else ""), end=" ")
-        print("Reward : " + str(self.last_reward) + "\033[K")
+        """Rendering (base.py:185-224) is outside the ported path: no-op."""
 
 
 def _span(name):

@@ -7,20 +7,39 @@ reference, `obs` IS the live state — o2arcenv.py:147), actions are device tens
     obs, reward, terminated, truncated, info = venv.step_bbox(bbox_i32[N,4], op_i32[N])     # BBoxWrapper form
     obs, reward, terminated, truncated, info = venv.step_point(xy_i32[N,2], op_i32[N])      # PointWrapper form
     obs, reward, terminated, truncated, info = venv.step({"selection": m[N,H,W], "operation": op[N]})
+
+Everything a rollout needs stays on the device: the task table (Loader.parse's output, uploaded once), the task choice
+at reset / auto-reset (keyed by the GLOBAL env id, so a sharded batch walks the same tasks — arcle_amd/sampling.py), the
+research env's epilogues (agents/env.py: dense reward, colour-permutation + rot90 augmentation; agents/train.py:67
+TimeLimit truncation).
 """
 import numpy as np
 import torch
 
 from .. import actions
-from ..engine import EnvBatch, STEP_AUTORESET
+from ..engine import (AUG_PERMUTE, AUG_ROT90, EnvBatch, STEP_AUTORESET, STEP_DENSE, STEP_RESAMPLE, STEP_RESET_ON_SUBMIT,
+                      STEP_TRUNCATE, ST_BAD_OP, ST_BAD_TASK, ST_ROTATE_DOMAIN)
+
+
+def _table_of(env_cls):
+    """The class's operation table: `create_operations()` is the reference's plugin point (base.py:140-142), so an
+    override of it is honoured even though no env instance (and no device batch of one) is built here."""
+    probe = object.__new__(env_cls)
+    return list(probe.create_operations())
 
 
 class ARCVecEnv:
     def __init__(self, env_cls, num_envs, data_loader=None, max_grid_size=(30, 30), colors=10, max_trial=None,
-                 device=None, autoreset=False, operations=None, rng=None):
-        """env_cls: RawARCEnv / ARCEnv / O2ARCv2Env or a subclass (its `create_operations` / `default_operations`
-        and KIND define the op table and the state planes).  `operations` overrides the table.
-        autoreset=True gives Gymnasium next-step autoreset semantics on device (ARCLE_STEP_AUTORESET)."""
+                 device=None, autoreset=False, operations=None, rng=None, seed=None, env_base=0,
+                 max_episode_steps=None, dense_reward=False, augment=()):
+        """env_cls: RawARCEnv / ARCEnv / O2ARCv2Env or a subclass (its `create_operations` and KIND define the op table
+        and the state planes); `operations` overrides the table.
+        autoreset: False | True (Gymnasium next-step autoreset onto the SAME task, inside the step kernel) |
+                   "resample" (the same, onto a NEW task drawn on the device from the loader's tasks).
+        seed / env_base: key of the device-side task draws (global env id = env_base + local index).
+        max_episode_steps: TimeLimit — `truncated` turns True once an env has taken that many steps (agents/train.py:67).
+        dense_reward: the research env's reward, sparse*100 - 1 + correct/total (agents/env.py:44-58), as float32.
+        augment: subset of ("permute", "rot90") — task augmentation at every (re)start (agents/env.py:31-42)."""
         self.env_cls, self.N = env_cls, int(num_envs)
         self.H, self.W = int(max_grid_size[0]), int(max_grid_size[1])
         self.colors = colors
@@ -28,22 +47,35 @@ class ARCVecEnv:
             max_trial = 3 if env_cls.KIND == "arc" else -1  # the classes' defaults (arcenv.py:79, o2arcenv.py:14)
         self.max_trial = max_trial
         self.loader = data_loader
-        self.operations = list(operations) if operations is not None else env_cls.default_operations()
+        self.operations = list(operations) if operations is not None else _table_of(env_cls)
         self.op_names = ["".join(map(str.capitalize, op.__name__.split("_"))) for op in self.operations]
+        self._host_slots = actions.host_slots(self.operations)
         self.batch = EnvBatch(self.N, self.H, self.W, max_trial, env_cls.KIND, device)
         self.batch.set_op_table(actions.table_descs(self.operations))
         self.device = self.batch.device
-        self.rng = rng if rng is not None else np.random.default_rng()
-        # autoreset: False | True (Gymnasium next-step autoreset of the SAME task, inside the step kernel)
-        #            | "resample" (same-step autoreset with a NEW random task from the device task table)
+        self.rng = rng if rng is not None else np.random.default_rng(seed)
+        self.seed = int(seed) if seed is not None else int(self.rng.integers(0, 2**63))
+        self.env_base = int(env_base)
         self.autoreset = autoreset
+        self.aug_flags = (AUG_PERMUTE if "permute" in augment else 0) | (AUG_ROT90 if "rot90" in augment else 0)
         # the vector env's state only evolves through the kernels, so redundant zero-fills of `selected` can be elided
-        self.flags = (STEP_AUTORESET if autoreset is True else 0) | self.batch.elide_flag
-        self._gen = torch.Generator(device=self.batch.device)
-        self._gen.manual_seed(int(self.rng.integers(0, 2**31)))
-        self.task_index = np.zeros(self.N, np.int64)
-        self.subprob_index = np.zeros(self.N, np.int64)
-        self._truncated = torch.zeros(self.N, dtype=torch.bool, device=self.device)
+        self.flags = self.batch.elide_flag
+        if autoreset is True:
+            self.flags |= STEP_AUTORESET
+        elif autoreset == "resample":
+            self.flags |= STEP_RESAMPLE
+        elif autoreset:
+            raise ValueError("autoreset must be False, True or 'resample'")
+        self.max_episode_steps = max_episode_steps
+        if max_episode_steps is not None:
+            self.batch.set_truncation(int(max_episode_steps))
+            self.flags |= STEP_TRUNCATE
+        self.dense_reward = bool(dense_reward)
+        if self.dense_reward:
+            self.batch.set_dense_output()
+            self.flags |= STEP_DENSE
+        self.adaptation = True
+        self._no_trunc = torch.zeros(self.N, dtype=torch.bool, device=self.device)
         self._obs = self._build_obs()
 
     # ---- observation = live device state -------------------------------------------------------------
@@ -65,19 +97,21 @@ class ARCVecEnv:
 
     def _info(self):
         b = self.batch
-        return {"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
-                "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1],
-                # host copies of the last explicit reset()'s choice; `table_index` (device, entry of the task table)
-                # also follows autoreset="resample"
-                "task_index": self.task_index, "subprob_index": self.subprob_index,
-                "table_index": getattr(self, "table_index", None)}
+        info = {"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
+                "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1]}
+        if hasattr(b, "cur_task"):  # device tensors: which task-table entry / problem / pair every env runs right now
+            t = b.cur_task.long().clamp_min(0)
+            info["table_index"] = b.cur_task
+            info["task_index"] = self._entry_problem[t]
+            info["subprob_index"] = self._entry_sub[t]
+        return info
 
-    # ---- reset: task choice vectorised on the host (no per-env Python), grids come from the device task table ----
+    # ---- task table: Loader.parse's output, uploaded once -----------------------------------------------
     def _build_task_table(self):
         """Flattens Loader.data (loader.py:89-113) into one device table: all demo pairs, then all test pairs;
         per-task offsets/counts let `reset` turn (prob_index, subprob_index) into a table index."""
         data = self.loader.data
-        ins, outs = [], []
+        ins, outs, eprob, esub = [], [], [], []
         self._off = {True: np.zeros(len(data), np.int64), False: np.zeros(len(data), np.int64)}
         self._cnt = {True: np.zeros(len(data), np.int64), False: np.zeros(len(data), np.int64)}
         for adaptation, (ii, oi) in ((True, (0, 1)), (False, (2, 3))):
@@ -86,26 +120,49 @@ class ARCVecEnv:
                 self._cnt[adaptation][t] = len(task[ii])
                 ins.extend(task[ii])
                 outs.extend(task[oi])
+                eprob.extend([t] * len(task[ii]))
+                esub.extend(range(len(task[ii])))
         self.batch.set_task_table(ins, outs)
-        self._dev_off = {k: torch.from_numpy(v).to(self.device) for k, v in self._off.items()}
-        self._dev_cnt = {k: torch.from_numpy(v).to(self.device) for k, v in self._cnt.items()}
+        self._entry_problem = torch.as_tensor(np.asarray(eprob, np.int64), device=self.device)
+        self._entry_sub = torch.as_tensor(np.asarray(esub, np.int64), device=self.device)
+        self._sampler_mode = None
+
+    def _install_sampler(self, adaptation):
+        """Candidates of the device-side draw: the problems that have at least one pair of the requested kind."""
+        if self._sampler_mode == adaptation:
+            return
+        valid = np.nonzero(self._cnt[adaptation] > 0)[0]
+        if valid.size == 0:
+            raise ValueError("no task has a pair of the requested kind")
+        self.sampler_problems = valid  # sampler index -> loader problem index
+        self.batch.set_sampler(self._off[adaptation][valid], self._cnt[adaptation][valid], self.seed, self.env_base,
+                               self.aug_flags)
+        self._sampler_mode = adaptation
 
     def reset(self, seed=None, options=None, env_mask=None):
-        """options as base.py:87-93 (prob_index / subprob_index may be ints or per-env sequences; adaptation).
-        env_mask (bool [N], host or device) restricts the reset to some envs (they get NEW tasks)."""
-        if seed is not None:
-            self.rng = np.random.default_rng(seed)
+        """options as base.py:87-93 (prob_index / subprob_index may be ints or per-env sequences; adaptation;
+        reset_on_submit).  Without prob_index / subprob_index the tasks are drawn on the device (keyed by the global env
+        id and the env's episode count).  env_mask (bool [N], host or device) restricts the reset to some envs."""
         options = options or {}
-        if options.get("reset_on_submit"):
-            raise NotImplementedError("reset_on_submit=True is not supported on device (SURVEY.md A.6-7)")
+        self.flags = (self.flags | STEP_RESET_ON_SUBMIT) if options.get("reset_on_submit") else (self.flags & ~STEP_RESET_ON_SUBMIT)
         adaptation = True if options.get("adaptation") is None else bool(options.get("adaptation"))
         self.adaptation = adaptation
         if self.loader is None:
             raise ValueError("ARCVecEnv needs a data_loader (or write tasks with batch.set_tasks and call batch.reset)")
         if not hasattr(self, "_off"):
             self._build_task_table()
-        n_tasks = len(self.loader.data)
+        if seed is not None:
+            self.seed = int(seed)
+            self.rng = np.random.default_rng(seed)
+            self._sampler_mode = None
+            self.batch.__dict__.pop("episode", None)  # a new seed restarts the per-env draw streams
+        self._install_sampler(adaptation)
+        mask = None if env_mask is None else torch.as_tensor(env_mask, device=self.device).to(torch.uint8)
         pidx, sidx = options.get("prob_index"), options.get("subprob_index")
+        if pidx is None and sidx is None:
+            self.batch.reset_sampled(mask)
+            return self._obs, self._info()
+        n_tasks = len(self.loader.data)
         p = self.rng.integers(0, n_tasks, self.N) if pidx is None else np.broadcast_to(np.asarray(pidx, np.int64), (self.N,))
         if ((p < 0) | (p >= n_tasks)).any():
             raise AssertionError(f"Problem indices should be in [0, {n_tasks}).")  # loader.py:55
@@ -116,70 +173,83 @@ class ARCVecEnv:
         if ((s_ < 0) | (s_ >= cnt)).any():
             raise IndexError("subprob_index out of range")
         idx = torch.from_numpy((self._off[adaptation][p] + s_).astype(np.int32)).to(self.device)
-        mask = None
-        if env_mask is not None:
-            mask = torch.as_tensor(env_mask, device=self.device).to(torch.uint8)
-            keep = ~(mask.bool().cpu().numpy())
-            p = np.where(keep, self.task_index, p)
-            s_ = np.where(keep, self.subprob_index, s_)
-        self.task_index, self.subprob_index = np.asarray(p).copy(), np.asarray(s_).copy()
-        prev = getattr(self, "table_index", None)
-        self.table_index = idx if (mask is None or prev is None) else torch.where(mask.bool(), idx, prev)
         self.batch.reset_from_table(idx, mask)
+        m = slice(None) if mask is None else mask.bool()
+        self.batch.cur_task[m] = idx[m]
         return self._obs, self._info()
 
-    def _resample_terminated(self, term):
-        """autoreset='resample': envs that just terminated get a NEW random task, entirely on device."""
-        ad = getattr(self, "adaptation", True)
-        n_tasks = len(self.loader.data)
-        p = torch.randint(0, n_tasks, (self.N,), device=self.device, generator=self._gen)
-        cnt = self._dev_cnt[ad][p]
-        s_ = (torch.rand(self.N, device=self.device, generator=self._gen) * cnt).long()
-        s_ = torch.minimum(s_, cnt - 1)
-        idx = (self._dev_off[ad][p] + s_).int()
-        self.table_index = torch.where(term.bool(), idx, self.table_index)
-        self.batch.reset_from_table(idx, term)
-
     # ---- step ------------------------------------------------------------------------------------------
-    def _ret(self, reward, term):
-        if self.autoreset == "resample":
-            term = term.clone()  # the step outputs are overwritten by the next launch
-            self._resample_terminated(term)
-        return self._obs, reward, term.bool(), self._truncated, self._info()
+    def _apply_host_ops(self, operation, action_of):
+        """Table slots holding arbitrary Python callables (SURVEY.md §8b "custom ops"): the kernel counted the step, the
+        callable now runs on the host on the fetched state of every env that chose such a slot.  Slow path."""
+        op = operation.to("cpu").numpy()
+        from .base import AbstractARCEnv
+        for n in np.nonzero(np.isin(op, self._host_slots))[0]:
+            state = AbstractARCEnv._state_from_device(self.batch, int(n))
+            self.operations[int(op[n])](state, action_of(int(n)))
+            AbstractARCEnv._state_to_device(self.batch, state, int(n))
+
+    def _ret(self, reward, term, operation=None, action_of=None):
+        b = self.batch
+        if self._host_slots and operation is not None:
+            self._apply_host_ops(operation, action_of)
+        if self.dense_reward:
+            d = b.dense.to(torch.float32)
+            reward = reward.to(torch.float32) * 100.0 - 1.0 + d[:, 0] / d[:, 1]
+        trunc = b.trunc.bool() if self.max_episode_steps is not None else self._no_trunc
+        return self._obs, reward, term.bool(), trunc, self._info()
 
     def step_bbox(self, bbox, operation):
-        return self._ret(*self.batch.step_bbox(bbox, operation, self.flags))
+        def action_of(n):  # BBoxWrapper.action (bbox.py:22-30) for one env, only needed by host-applied ops
+            x1, y1, x2, y2 = (int(v) for v in bbox[n].tolist())
+            sel = np.zeros((self.H, self.W), np.int8)
+            sel[min(x1, x2):max(x1, x2) + 1, min(y1, y2):max(y1, y2) + 1] = 1
+            return {"selection": sel, "operation": int(operation[n])}
+        return self._ret(*self.batch.step_bbox(bbox, operation, self.flags), operation, action_of)
 
     def step_point(self, xy, operation):
-        return self._ret(*self.batch.step_point(xy, operation, self.flags))
+        def action_of(n):
+            sel = np.zeros((self.H, self.W), np.int8)
+            sel[int(xy[n, 0]), int(xy[n, 1])] = 1
+            return {"selection": sel, "operation": int(operation[n])}
+        return self._ret(*self.batch.step_point(xy, operation, self.flags), operation, action_of)
 
     def step(self, action):
-        return self._ret(*self.batch.step_mask(action["selection"], action["operation"], self.flags))
+        sel, operation = action["selection"], action["operation"]
+        return self._ret(*self.batch.step_mask(sel, operation, self.flags), operation,
+                         lambda n: {"selection": sel[n].cpu().numpy(), "operation": int(operation[n])})
 
     def rollout_bbox(self, bbox, operation):
         """T steps in ONE launch: bbox int32 [T,N,4], operation int32 [T,N] -> (obs, reward [T,N], terminated [T,N]).
         For callers that already hold the action sequence (trace replay, scripted policies); the state is only
         observable after the last step."""
-        reward, term = self.batch.rollout(bbox, operation, self.flags)
+        reward, term = self.batch.rollout(bbox, operation, self._rollout_flags())
         return self._obs, reward, term.bool(), self._info()
 
     def rollout_point(self, xy, operation):
-        reward, term = self.batch.rollout(xy, operation, self.flags, point=True)
+        reward, term = self.batch.rollout(xy, operation, self._rollout_flags(), point=True)
         return self._obs, reward, term.bool(), self._info()
 
-    def flat_obs(self, out=None):
+    def _rollout_flags(self):
+        if self._host_slots or self.flags & (STEP_RESAMPLE | STEP_TRUNCATE | STEP_DENSE):
+            raise NotImplementedError("rollouts support plain and same-task autoreset envs with device-only op tables")
+        return self.flags
+
+    def flat_obs(self, out=None, filtered=False):
         """The observation as one [N, L] int8 tensor in FlattenObservation key order (what the reference's policies
-        consume, agents/models/GPTPolicy.py:17-35)."""
-        return self.batch.flat_obs(out)
+        consume, agents/models/GPTPolicy.py:17-35); filtered=True: the FilterO2ARC subset (agents/env.py:109-126)."""
+        return self.batch.flat_obs(out, filtered)
 
     def check_errors(self):
-        """Raises if any env saw an out-of-range op / out-of-domain Rotate since the last check
+        """Raises if any env saw an out-of-range op / out-of-domain Rotate / bad task index since the last check
         (the reference raises IndexError / ValueError at the offending step)."""
         st = self.batch.status()
-        if st & 1:
+        if st & ST_BAD_OP:
             raise IndexError("an env received an operation index outside its table")
-        if st & 2:
+        if st & ST_ROTATE_DOMAIN:
             raise ValueError("Rotate/Flip outside its domain (object.py:45 / int8 overflow of object_pos)")
+        if st & ST_BAD_TASK:
+            raise IndexError("a reset named a task-table index outside the table")
 
     def close(self):
         self.batch = None

@@ -93,7 +93,9 @@ enum arcle_op_kind {
   ARCLE_OP_CROP_GRID = 11,       /* crop_grid             critical.py:48-66                 */
   ARCLE_OP_RESIZE_TO_ANSWER = 12,/* RawARCEnv resize_to_answer  arcenv.py:31-35             */
   ARCLE_OP_SUBMIT = 13,          /* AbstractARCEnv.submit base.py:172-183                   */
-  ARCLE_N_OP_KINDS = 14
+  ARCLE_OP_HOST = 14,            /* slot of an arbitrary host callable (base.py:140-142): a device no-op — the step is
+                                    counted, the host layer applies the callable to the fetched state               */
+  ARCLE_N_OP_KINDS = 15
 };
 #define ARCLE_OPF_RESET_SEL 1u /* wrapped by reset_sel  object.py:10-26 */
 #define ARCLE_OPF_KEEP_SEL 2u  /* wrapped by keep_sel   object.py:28-41 */
@@ -119,6 +121,27 @@ enum arcle_op_kind {
 /* also writes truncated[env] = (action_steps >= step_limit) into the array installed with arcle_set_truncation
  * (gymnasium TimeLimit(max_episode_steps) as the reference's training script applies it, agents/train.py:67) */
 #define ARCLE_STEP_TRUNCATE 4u
+/* like ARCLE_STEP_AUTORESET, but the env starts its next episode on a NEW task drawn on the device from the task table
+ * (arcle_set_task_table + arcle_set_sampler): problem and pair uniform, optional colour-permutation / rot90
+ * augmentation (agents/env.py:31-42), all keyed by (seed, global env id, episode number) */
+#define ARCLE_STEP_RESAMPLE 8u
+/* also writes dense[env] = (cells of grid that match the answer inside the common rectangle, total cells as in
+ * agents/env.py:44-58) into the int32 [n_envs][2] array installed with arcle_set_dense_output: the research env's dense
+ * reward is  sparse*100 - 1 + dense[0]/dense[1]  (formed by the host, exact integers on the device) */
+#define ARCLE_STEP_DENSE 16u
+/* mask ingress only: an object op (Move/Rotate/Flip) whose selection equals the env's current `selected` plane is
+ * executed with an empty selection, i.e. continues the active object — the rule of the reference's O2ARC trace harness
+ * (tests/o2arc_check.py:169-170) */
+#define ARCLE_STEP_CONTINUE_RULE 32u
+/* reset(options={'reset_on_submit': True}) (base.py:87-93,179-180): a Submit with trials left
+ * re-initialises the env from its input inside the op; the caller sees the fresh state, terminated stays 0 */
+#define ARCLE_STEP_RESET_ON_SUBMIT 64u
+/* the step call also emits the flattened observation rows (arcle_set_flat_output) of the state it produced */
+#define ARCLE_STEP_FLAT_OBS 128u
+
+/* ---- augmentation of a task at reset (arcle_set_sampler / ARCLE_STEP_RESAMPLE / arcle_reset_sampled) ---- */
+#define ARCLE_AUG_PERMUTE 1u /* random permutation of the colours 0..9 (applied to input and answer) */
+#define ARCLE_AUG_ROT90 2u   /* np.rot90(., k) with k uniform in 0..3                                 */
 
 /* ---- sticky device status bits (arcle_get_status) ---- */
 #define ARCLE_ST_BAD_OP 1u       /* operation index out of range / empty slot: step skipped
@@ -216,17 +239,42 @@ int arcle_rollout_point(arcle_env* env, int32_t n_steps, const int32_t* xy, cons
 int arcle_rollout_mask(arcle_env* env, int32_t n_steps, const int8_t* sel, const int32_t* op, int32_t* reward,
                        uint8_t* term, uint32_t flags, void* stream);
 
+/* Device-side task choice.  pair_off / pair_cnt: device int32 [n_problems] — first task-table entry and number of
+ * entries (pairs) of every problem that has at least one (Loader.pick's candidates for the current adaptation mode);
+ * episode: device int32 [n_envs] episodes started so far (the RNG stream position; the library increments it);
+ * cur_task: device int32 [n_envs] or NULL, receives the table index each env currently runs; env_base: global id of
+ * this handle's env 0 (multi-GPU shards), aug_flags: ARCLE_AUG_*.  The draw is a pure function of
+ * (seed, env_base + env, episode[env]) — see arcle::draw_task. */
+int arcle_set_sampler(arcle_env* env, const int32_t* pair_off, const int32_t* pair_cnt, int32_t n_problems, uint64_t seed,
+                      int64_t env_base, int32_t* episode, int32_t* cur_task, uint32_t aug_flags);
+/* reset() of the masked envs (mask NULL = all) onto device-drawn tasks (arcle_set_sampler). */
+int arcle_reset_sampled(arcle_env* env, const uint8_t* mask, void* stream);
+/* arcle_reset_from_table with an explicit augmentation per env: aug_k device uint8 [n_envs] (np.rot90 count) and/or
+ * aug_perm device uint8 [n_envs][16] (perm[c] for colour c < 10); NULL = none. */
+int arcle_reset_from_table_aug(arcle_env* env, const int32_t* task_idx, const uint8_t* mask, const uint8_t* aug_k,
+                               const uint8_t* aug_perm, void* stream);
+/* Installs the output of ARCLE_STEP_DENSE: dense_out device int32 [n_envs][2]; NULL removes it. */
+int arcle_set_dense_output(arcle_env* env, int32_t* dense_out);
+
 /* Installs the output of ARCLE_STEP_TRUNCATE: trunc_out device uint8[n_envs], step_limit = max_episode_steps.
  * trunc_out == NULL removes it. */
 int arcle_set_truncation(arcle_env* env, uint8_t* trunc_out, int32_t step_limit);
 
-/* Flattened observation: out int8 [n_envs][arcle_flat_obs_size()] (device), one row per env holding the state dict in
- * Gymnasium FlattenObservation order (keys sorted, nested object_states in place) — what the reference's policies
- * consume (agents/models/GPTPolicy.py:17-35 `unflatten_vec`):  clip, clip_dim, grid, grid_dim, input, input_dim,
- * active, background, object, object_dim, object_pos, object_sel, rotation_parity, selected, terminated, trials_remain
- * = 7*H*W + 14 bytes for O2ARCv2Env (6314 at 30x30); env kinds without some keys simply omit them. */
-int arcle_flat_obs_size(const arcle_env* env);
-int arcle_flatten_obs(arcle_env* env, int8_t* out, void* stream);
+/* Flattened observation — what the reference's policies consume.  One row per env holding the state dict in Gymnasium
+ * FlattenObservation order (keys sorted, nested object_states in place; agents/models/GPTPolicy.py:17-35
+ * `unflatten_vec`):  clip, clip_dim, grid, grid_dim, input, input_dim, active, background, object, object_dim,
+ * object_pos, object_sel, rotation_parity, selected, terminated, trials_remain = 7*H*W + 14 bytes for O2ARCv2Env (6314 at
+ * 30x30; env kinds without some keys omit them), or — filtered != 0 — the FilterO2ARC subset the reference's training
+ * script flattens (agents/env.py:109-126, agents/train.py:61-68): active, clip, clip_dim, grid, grid_dim, object,
+ * object_dim, object_pos, trials_remain = 3*H*W + 10 bytes (2710).
+ * arcle_flat_obs_size() is that logical row length; `out` is a device buffer int8 [n_envs][out_stride], 16-byte aligned,
+ * out_stride a multiple of 16 >= the length (the tail of every row is zero).  Rows are written with aligned, fully
+ * coalesced 16-byte stores. */
+int arcle_flat_obs_size(const arcle_env* env, int filtered);
+int arcle_flatten_obs(arcle_env* env, int8_t* out, int32_t out_stride, int filtered, void* stream);
+/* Destination of ARCLE_STEP_FLAT_OBS: every step call carrying that flag also writes the observation rows of the state it
+ * produced (same stream, one ABI call per step, no host round trip).  out == NULL removes it. */
+int arcle_set_flat_output(arcle_env* env, int8_t* out, int32_t out_stride, int filtered);
 
 /* Packed minimal observation for a central learner (what the multi-GPU gather moves): one row per env,
  *   grid (H*W bytes) | grid_dim (2) | reward int32 little-endian (4) | terminated (1) | zero padding

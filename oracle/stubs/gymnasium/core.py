@@ -44,4 +44,10 @@ class ActionWrapper(Wrapper):
 
 
 class ObservationWrapper(Wrapper):
-    pass
+    def reset(self, **kw):
+        obs, info = self.env.reset(**kw)
+        return self.observation(obs), info
+
+    def step(self, action):
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        return self.observation(obs), reward, terminated, truncated, info

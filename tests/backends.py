@@ -99,7 +99,8 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("tbl_ans", ctypes.c_void_p), ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p),
                 ("n_tasks", ctypes.c_int32), ("aug_flags", ctypes.c_uint32), ("seed", ctypes.c_uint64),
                 ("env_base", ctypes.c_int64), ("episode", ctypes.c_void_p), ("cur_task", ctypes.c_void_p),
-                ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p), ("n_problems", ctypes.c_int32),
+                ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p), ("aug_k", ctypes.c_void_p),
+                ("aug_perm", ctypes.c_void_p), ("n_problems", ctypes.c_int32),
                 ("pad_", ctypes.c_int32)]
 
 
@@ -192,19 +193,80 @@ class EmuBackend:
             self.tbl[2][j, :self.P].reshape(self.H, self.W)[:b.shape[0], :b.shape[1]] = b
             self.tbl[1][j], self.tbl[3][j] = a.shape, b.shape
 
-    def reset_from_table(self, idx, mask=None):
+    def reset_from_table(self, idx, mask=None, aug_k=None, aug_perm=None):
         p = self._params()
+        self._extras(p)
         idx = np.ascontiguousarray(idx, np.int32)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         p.rmask = None if m is None else m.ctypes.data
         p.task_idx = idx.ctypes.data
-        p.tbl_in, p.tbl_in_dim, p.tbl_ans, p.tbl_ans_dim = [t.ctypes.data for t in self.tbl]
-        p.n_tasks = len(self.tbl[0])
+        if aug_k is not None:
+            k8 = np.ascontiguousarray(aug_k, np.uint8)
+            p.aug_k = k8.ctypes.data
+        if aug_perm is not None:
+            pm = np.zeros((self.N, 16), np.uint8)
+            pm[:, :10] = aug_perm
+            p.aug_perm = pm.ctypes.data
         rc = emu_lib().emu_run(2, ctypes.byref(p))
         assert rc == 0, f"wave emulator reported error {rc}"
 
+    # ---- round-2 features (same kernels, the emulator runs them lock-step) ------------------------------
+    def _extras(self, p):
+        """Optional per-step outputs / sampler state shared by the step and reset kernels."""
+        for name in ("trunc", "dense", "episode", "cur_task"):
+            arr = getattr(self, name, None)
+            if arr is not None:
+                setattr(p, name, arr.ctypes.data)
+        p.step_limit = getattr(self, "step_limit", 0)
+        if getattr(self, "_sampler", None):
+            off, cnt, seed, base, aug = self._sampler
+            p.pair_off, p.pair_cnt, p.n_problems = off.ctypes.data, cnt.ctypes.data, len(cnt)
+            p.seed, p.env_base, p.aug_flags = seed, base, aug
+        if getattr(self, "tbl", None) is not None:
+            p.tbl_in, p.tbl_in_dim, p.tbl_ans, p.tbl_ans_dim = [t.ctypes.data for t in self.tbl]
+            p.n_tasks = len(self.tbl[0])
+
+    def set_truncation(self, limit):
+        self.trunc, self.step_limit = np.zeros(self.N, np.uint8), int(limit)
+
+    def set_dense_output(self):
+        self.dense = np.zeros((self.N, 2), np.int32)
+
+    def set_sampler(self, pair_off, pair_cnt, seed, env_base=0, aug_flags=0):
+        self._sampler = (np.ascontiguousarray(pair_off, np.int32), np.ascontiguousarray(pair_cnt, np.int32), int(seed), int(env_base), int(aug_flags))
+        if getattr(self, "episode", None) is None:
+            self.episode, self.cur_task = np.zeros(self.N, np.int32), np.full(self.N, -1, np.int32)
+
+    def reset_sampled(self, mask=None):
+        p = self._params()
+        self._extras(p)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rmask = None if m is None else m.ctypes.data
+        rc = emu_lib().emu_run(2, ctypes.byref(p))
+        assert rc == 0, f"wave emulator reported error {rc}"
+
+    def flat_obs(self, filtered=False):
+        p = self._params()
+        o2, clip = "selected" in self.buf, "clip" in self.buf
+        L = 3 * self.P + 10 if filtered else 2 * self.P + 6 + (self.P + 2 if clip else 0) + (4 * self.P + 6 if o2 else 0)
+        out = np.full((self.N, (L + 15) & ~15), 0x55, np.int8)
+        p.flat_out, p.flat_stride, p.flat_filter = out.ctypes.data, out.shape[1], int(filtered)
+        rc = emu_lib().emu_run(4, ctypes.byref(p))
+        assert rc == 0 and not out[:, L:].any()
+        return out[:, :L].copy()
+
+    def packed_obs(self):
+        p = self._params()
+        R = (self.P + 7 + 15) & ~15
+        out = np.full((self.N, R), 0x55, np.uint8)
+        p.flat_out, p.flat_stride = out.ctypes.data, R
+        rc = emu_lib().emu_run(5, ctypes.byref(p))
+        assert rc == 0
+        return out
+
     def step(self, ingress, payload, op, flags=0):
         p = self._params()
+        self._extras(p)
         if ingress == "mask":
             pay = np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(self.N, self.P)
         else:
@@ -279,13 +341,50 @@ class HipBackend:
     def set_task_table(self, inputs, answers):
         self.b.set_task_table(inputs, answers)
 
-    def reset_from_table(self, idx, mask=None):
+    def reset_from_table(self, idx, mask=None, aug_k=None, aug_perm=None):
         t = self.torch
         self.b.reset_from_table(t.as_tensor(np.ascontiguousarray(idx, np.int32), device=self.b.device),
-                                None if mask is None else t.as_tensor(np.ascontiguousarray(mask, np.uint8), device=self.b.device))
+                                None if mask is None else t.as_tensor(np.ascontiguousarray(mask, np.uint8), device=self.b.device),
+                                None if aug_k is None else t.as_tensor(np.ascontiguousarray(aug_k, np.uint8)),
+                                None if aug_perm is None else t.as_tensor(np.ascontiguousarray(aug_perm, np.uint8)))
 
     def padding_is_zero(self):
         return all(not bool(p[:, self.b.P:].any()) for p in self.b.planes.values())
+
+    # ---- round-2 features -------------------------------------------------------------------------------
+    def set_truncation(self, limit):
+        self.b.set_truncation(limit)
+
+    def set_dense_output(self):
+        self.b.set_dense_output()
+
+    def set_sampler(self, pair_off, pair_cnt, seed, env_base=0, aug_flags=0):
+        self.b.set_sampler(pair_off, pair_cnt, seed, env_base, aug_flags)
+
+    def reset_sampled(self, mask=None):
+        self.b.reset_sampled(None if mask is None else self.torch.as_tensor(np.ascontiguousarray(mask, np.uint8), device=self.b.device))
+
+    def flat_obs(self, filtered=False):
+        return self.b.flat_obs(filtered=filtered).cpu().numpy().copy()
+
+    def packed_obs(self):
+        return self.b.packed_obs().cpu().numpy().copy()
+
+    @property
+    def trunc(self):
+        return self.b.trunc.cpu().numpy()
+
+    @property
+    def dense(self):
+        return self.b.dense.cpu().numpy()
+
+    @property
+    def episode(self):
+        return self.b.episode.cpu().numpy()
+
+    @property
+    def cur_task(self):
+        return self.b.cur_task.cpu().numpy()
 
     def counters(self):
         return self.b.cnt.cpu().numpy().copy()
@@ -299,7 +398,8 @@ BACKENDS = {"oracle": OracleBackend, "emu": EmuBackend, "hip": HipBackend}
 
 # ---- golden fixtures ------------------------------------------------------------------------------------
 def fixture_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """Trace fixtures of tests/golden/make_golden.py (research.npz has its own layout, tests/features.py)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "research.npz")
 
 
 def load_fixture(name):

@@ -105,6 +105,7 @@ int g_env, g_kind;
 char* g_stacks;
 const size_t STACK = 256 * 1024;
 
+alignas(16) uint8_t g_row[7 * ARCLE_MAX_CELLS + 32];  // the flatten kernel's LDS row buffer
 int g_tbl;  // arcle::TBL_* of the installed table (emu_run compares it with the canonical decoders)
 
 #define RUN_STEP(I, F)                                                                      \
@@ -157,6 +158,10 @@ void lane_main(int lane) {
       default: RUN_ROLL(2, 1); break;
     }
   }
+  else if (g_kind == 4)
+    arcle::wave_flatten(*g_p, &g_lds.wave[0], g_lds.lut, g_row, g_env, lane);
+  else if (g_kind == 5)
+    arcle::wave_pack_obs(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
   else
     arcle::wave_reset(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
   xl::finished[lane] = true;
@@ -207,7 +212,7 @@ void run_wave() {
 }
 }  // namespace
 
-// kind: 0 = step, 1 = reset, 2 = reset from the task table, 3 = rollout.  Fills derived fields (P, div_magic, nseg) like
+// kind: 0 = step, 1 = reset, 2 = reset from the task table (task_idx NULL: device-drawn), 3 = rollout, 4 = flatten, 5 = pack.  Fills derived fields (P, div_magic, nseg) like
 // arcle_create does; PS (plane stride) comes from the caller (0 = default).
 extern "C" int emu_run(int kind, arcle::StepParams* p) {
   p->P = p->H * p->W;

@@ -41,7 +41,7 @@ def test_no_cpu_fallback_without_device():
         EnvBatch(4, 5, 5)
     # the C entry point itself reports the missing device instead of computing anything
     L = _lib.lib()
-    cfg = _lib.Config(4, 5, 5, -1, -1)
+    cfg = _lib.Config(4, 5, 5, -1, -1, 0)
     h = ctypes.c_void_p()
     assert L.arcle_create(ctypes.byref(cfg), None, ctypes.byref(h)) == -4  # ARCLE_ERR_NO_DEVICE
     assert not h.value

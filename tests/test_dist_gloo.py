@@ -17,6 +17,28 @@ from oracle import oracle as O
 G, H, W, S = 12, 10, 10, 24
 
 
+class _PackedRows:
+    """The slice of the EnvBatch interface ShardedVecEnv.gather uses (packed_obs_size / packed_obs / device / H / W), over
+    the oracle's arrays; the row layout is arcle_pack_obs's (include/arcle_hip.h)."""
+    device = torch.device("cpu")
+
+    def __init__(self, env):
+        self.env, self.H, self.W = env, H, W
+
+    def packed_obs_size(self):
+        return (H * W + 7 + 15) & ~15
+
+    def packed_obs(self, out):
+        be, n = self.env.be, self.env.N
+        rows = np.zeros((n, self.packed_obs_size()), np.uint8)
+        rows[:, :H * W] = be.get("grid").reshape(n, -1).view(np.uint8)
+        rows[:, H * W:H * W + 2] = be.get("grid_dim").view(np.uint8)
+        rows[:, H * W + 2:H * W + 6] = self.env.last[0].astype("<i4").view(np.uint8).reshape(n, 4)
+        rows[:, H * W + 6] = self.env.last[1]
+        out.copy_(torch.from_numpy(rows))
+        return out
+
+
 class OracleVecEnv:
     """ARCVecEnv-shaped adapter over the oracle for global env ids [lo, hi)."""
 
@@ -26,12 +48,14 @@ class OracleVecEnv:
         inp, idim, ans, adim = tasks
         self.be.set_tasks(inp[lo:hi], idim[lo:hi], ans[lo:hi], adim[lo:hi])
         self.be.reset()
+        self.batch = _PackedRows(self)
 
     def _obs(self):
         return {"grid": torch.from_numpy(self.be.get("grid")), "grid_dim": torch.from_numpy(self.be.get("grid_dim"))}
 
     def step_bbox(self, bbox, op):
         r, t = self.be.step("bbox", bbox.numpy(), op.numpy())
+        self.last = (r, t)
         return self._obs(), torch.from_numpy(r), torch.from_numpy(t).bool(), torch.zeros(self.N, dtype=torch.bool), {}
 
 
@@ -56,9 +80,9 @@ def _worker(rank, world, port, out_q):
     grids, rewards = [], []
     for s in range(S):
         obs, r, t, _, _ = env.step_bbox(env.local_slice(bbox[s]), env.local_slice(op[s]))  # local, no comm
-        gobs, gr, gt = env.gather(obs, r, t)                                              # the only collective
-        assert gobs["grid"].shape == (G, H, W) and gr.shape == (G,) and gt.dtype == torch.bool
-        grids.append(gobs["grid"].numpy().copy())
+        ggrid, gdim, gr, gt = env.gather()                                               # the only collective: ONE all-gather
+        assert ggrid.shape == (G, H, W) and gdim.shape == (G, 2) and gr.shape == (G,) and gt.dtype == torch.bool
+        grids.append(ggrid.numpy().copy())
         rewards.append(gr.numpy().copy())
     if rank == 0:
         out_q.put((np.stack(grids), np.stack(rewards)))
@@ -93,12 +117,11 @@ def test_two_shards_equal_one_process():
         assert np.array_equal(r.numpy(), rewards[s])
 
 
-def test_shard_ranges_and_seeds():
-    from arcle_amd.dist import shard_range, shard_seed
+def test_shard_ranges():
+    from arcle_amd.dist import shard_range
     for g, w in ((65536, 8), (8192, 1), (10, 4), (7, 8)):
         spans = [shard_range(g, w, r) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == g
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
     assert shard_range(65536, 8, 3) == (24576, 32768)
-    # per-env streams depend on the global id only, not on the sharding
-    assert shard_seed(7, 12345) == shard_seed(7, 12345) and shard_seed(7, 1) != shard_seed(7, 2)
+    # (that the device-side task draws follow the GLOBAL env id is tested with the kernels: tests/features.py sampler)

@@ -35,8 +35,11 @@ def test_descriptor_encoding_and_wrappers():
                 lambda: A.gen_copy("Z")):
         with pytest.raises(AssertionError):  # the reference asserts too (object.py:175,226,261,289)
             bad()
+    # an arbitrary callable becomes a device no-op slot that the env applies on the host (base.py:140-142)
+    table = [A.gen_color(1), lambda s, a: None]
+    assert A.table_descs(table) == [A.gen_color(1).desc, A.OP_HOST] and A.host_slots(table) == [1]
     with pytest.raises(TypeError):
-        A.table_descs([A.gen_color(1), lambda s, a: None])
+        A.table_descs([A.gen_color(1), 42])
     with pytest.raises(TypeError):
         A.gen_color(1)({}, {})  # descriptors are not host callables
 
