@@ -299,7 +299,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
       return ARCLE_ERR_HIP;
     }
   }
-  if (hipMalloc((void**)&e->d_status, 4) != hipSuccess || hipMemset(e->d_status, 0, 4) != hipSuccess ||
+  if (hipMalloc((void**)&e->d_status, 8) != hipSuccess || hipMemset(e->d_status, 0, 8) != hipSuccess ||
       hipMalloc((void**)&e->d_ops, sizeof(uint32_t) * ARCLE_MAX_OPS) != hipSuccess ||
       hipMemset(e->d_ops, 0, sizeof(uint32_t) * ARCLE_MAX_OPS) != hipSuccess) {
     arcle_destroy(e);
@@ -365,6 +365,7 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
         (k == ARCLE_OP_COPY && a > 1) || (k == ARCLE_OP_PASTE && a > 1))
       return fail(e, ARCLE_ERR_CONFIG, "op argument out of range");
   }
+  HIP_TRY(e, hipDeviceSynchronize());  // no launch of this handle may still read the old table
   memset(e->ops_host, 0, sizeof(e->ops_host));
   memcpy(e->ops_host, descs, sizeof(uint32_t) * (size_t)n_ops);
   HIP_TRY(e, hipMemcpy(e->d_ops, e->ops_host, sizeof(e->ops_host), hipMemcpyHostToDevice));  // synchronous
@@ -688,11 +689,16 @@ extern "C" int arcle_pack_obs(arcle_env* e, const int32_t* reward, const uint8_t
   return ARCLE_OK;
 }
 
+__global__ void arcle_status_kernel(uint32_t* status, uint32_t* out, int clear) {
+  *out = clear ? atomicExch(status, 0u) : atomicOr(status, 0u);
+}
+
 extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void* stream) {
   if (!e || !status) return ARCLE_ERR_ARG;
   DeviceGuard guard(e->device);
-  HIP_TRY(e, hipMemcpyAsync(status, e->d_status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  if (clear) HIP_TRY(e, hipMemsetAsync(e->d_status, 0, 4, (hipStream_t)stream));
+  hipLaunchKernelGGL(arcle_status_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->d_status, e->d_status + 1, clear);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(status, e->d_status + 1, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
   return ARCLE_OK;
 }

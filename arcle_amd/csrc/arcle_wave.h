@@ -476,7 +476,10 @@ ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
     const int bx1 = (int)payload[0], by1 = (int)payload[1], bx2 = (int)payload[2], by2 = (int)payload[3];
     int xa = imin(bx1, bx2), xb = imin(imax(bx1, bx2), p.H - 1);
     int ya = imin(by1, by2), yb = imin(imax(by1, by2), p.W - 1);
-    if ((xa | ya) < 0) xa = xb + 1;
+    if ((xa | ya) < 0) {
+      xa = xb + 1;
+      if (w.lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
+    }
     sel_from_rect(w, s, xa, xb, ya, yb);
     return;
   }
@@ -484,6 +487,7 @@ ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
     // PointWrapper.action (bbox.py:43-49)
     const int x = (int)payload[0], y = (int)payload[1];
     const bool ok = x >= 0 && x < p.H && y >= 0 && y < p.W;
+    if (!ok && w.lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
     sel_from_rect(w, s, x, ok ? x : x - 1, y, y);
     return;
   }

@@ -34,7 +34,7 @@ STEP_CONTINUE_RULE = 32
 STEP_RESET_ON_SUBMIT = 64
 STEP_FLAT_OBS = 128
 AUG_PERMUTE, AUG_ROT90 = 1, 2
-ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK = 1, 2, 4
+ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION = 1, 2, 4, 8
 
 
 def _ptr(t):

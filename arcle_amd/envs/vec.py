@@ -18,7 +18,7 @@ import torch
 
 from .. import actions
 from ..engine import (AUG_PERMUTE, AUG_ROT90, EnvBatch, STEP_AUTORESET, STEP_DENSE, STEP_RESAMPLE, STEP_RESET_ON_SUBMIT,
-                      STEP_TRUNCATE, ST_BAD_OP, ST_BAD_TASK, ST_ROTATE_DOMAIN)
+                      STEP_TRUNCATE, ST_BAD_OP, ST_BAD_SELECTION, ST_BAD_TASK, ST_ROTATE_DOMAIN)
 
 
 def _table_of(env_cls):
@@ -250,6 +250,9 @@ class ARCVecEnv:
             raise ValueError("Rotate/Flip outside its domain (object.py:45 / int8 overflow of object_pos)")
         if st & ST_BAD_TASK:
             raise IndexError("a reset named a task-table index outside the table")
+        if st & ST_BAD_SELECTION:
+            raise IndexError("a point outside the grid plane / a negative selection coordinate (the reference's wrappers raise "
+                             "IndexError or wrap the index, bbox.py:22-30,43-49)")
 
     def close(self):
         self.batch = None

@@ -81,12 +81,13 @@ def make_actions(steps, n, seed, H=30, W=30, n_ops=35):
 
 
 def make_actions_c2(steps, n, seed):
-    """ops U{0..23}; 50 % rectangle, 40 % point (x1=x2, y1=y2), 10 % empty (a negative corner selects nothing)."""
+    """ops U{0..23}; 50 % rectangle, 40 % point (x1=x2, y1=y2), 10 % empty (corners beyond the plane: the wrapper's
+    slices clip to nothing, bbox.py:29)."""
     bbox, op = make_actions(steps, n, seed, 10, 10, 24)
     u = np.random.default_rng(seed + 7).random((steps, n))
     point, empty = (u >= 0.5) & (u < 0.9), u >= 0.9
     bbox[point, 2:] = bbox[point, :2]
-    bbox[empty] = -1
+    bbox[empty] = 10
     return bbox, op
 
 

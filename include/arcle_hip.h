@@ -147,6 +147,9 @@ enum arcle_op_kind {
 #define ARCLE_ST_BAD_OP 1u       /* operation index out of range / empty slot: step skipped
                                     (reference: IndexError / TypeError)                   */
 #define ARCLE_ST_BAD_TASK 4u      /* arcle_reset_from_table: task index outside the table: env left untouched */
+#define ARCLE_ST_BAD_SELECTION 8u /* a point outside the H x W plane or a negative bbox / point coordinate: the reference
+                                    raises IndexError (or NumPy wraps the negative index); here the selection is
+                                    empty, the step runs, and this bit reports it                          */
 #define ARCLE_ST_ROTATE_DOMAIN 2u /* Rotate produced a position outside int8 or a tile that
                                     does not fit HxW (reference: ValueError/garbage,
                                     SURVEY.md A.6-2, A.6-6): step skipped                  */
@@ -283,8 +286,10 @@ int arcle_set_flat_output(arcle_env* env, int8_t* out, int32_t out_stride, int f
 int arcle_packed_obs_size(const arcle_env* env);
 int arcle_pack_obs(arcle_env* env, const int32_t* reward, const uint8_t* term, uint8_t* out, void* stream);
 
-/* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*). Synchronises
- * the stream. */
+/* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*): one atomic exchange on the device, so a
+ * bit raised by a kernel on another stream is never lost between the read and the clear.  Synchronises the stream.
+ * (arcle_set_op_table / arcle_set_task_table / arcle_set_sampler change what later launches see: call them with no
+ * launch of this handle in flight — arcle_set_op_table synchronises the device itself.) */
 int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);
 
 /* Algorithmic HBM bytes (SURVEY.md §8d accounting) moved by all step launches since the

@@ -606,6 +606,7 @@ int oracle_step_bbox(oracle_env* e, const int32_t* bbox, const int32_t* op, int3
     int x1 = bbox[4 * n], y1 = bbox[4 * n + 1], x2 = bbox[4 * n + 2], y2 = bbox[4 * n + 3];
     if (x1 > x2) { int t = x1; x1 = x2; x2 = t; }
     if (y1 > y2) { int t = y1; y1 = y2; y2 = t; }
+    if (x1 < 0 || y1 < 0) __atomic_fetch_or(&e->status, ARCLE_ST_BAD_SELECTION, __ATOMIC_RELAXED);
     memset(sel, 0, (size_t)e->H * e->W);
     for (int i = x1 < 0 ? e->H : x1; i <= x2 && i < e->H; i++)
       for (int j = y1 < 0 ? e->W : y1; j <= y2 && j < e->W; j++) sel[i * e->W + j] = 1;
@@ -623,6 +624,7 @@ int oracle_step_point(oracle_env* e, const int32_t* xy, const int32_t* op, int32
     int x = xy[2 * n], y = xy[2 * n + 1];
     memset(sel, 0, (size_t)e->H * e->W);
     if (x >= 0 && x < e->H && y >= 0 && y < e->W) sel[x * e->W + y] = 1;
+    else __atomic_fetch_or(&e->status, ARCLE_ST_BAD_SELECTION, __ATOMIC_RELAXED);
     step_one(e, n, sel, op[n], &reward[n], &term[n], flags);
   }
   return 0;

@@ -69,9 +69,25 @@ def random_task(rng, H, W):
     return a, ans
 
 
+_WRAPPERS = {}
+
+
+def reference_wrapper_mask(H, W, kind, payload):
+    """The selection mask the REFERENCE's BBoxWrapper / PointWrapper builds for a tuple (arcle/wrappers/bbox.py:22-30,
+    43-49) — called on the reference classes themselves, wrapped around a reference env of that grid size."""
+    if (H, W) not in _WRAPPERS:
+        import_reference()
+        from arcle.wrappers import BBoxWrapper, PointWrapper
+        env = make_reference_env("o2arc", H, W, -1, (np.ones((1, 1), np.int8), np.ones((1, 1), np.int8)))
+        _WRAPPERS[(H, W)] = (BBoxWrapper(env), PointWrapper(env))
+    bw, pw = _WRAPPERS[(H, W)]
+    act = (bw if kind == "bbox" else pw).action(tuple(int(v) for v in payload) + (0,))
+    return np.asarray(act["selection"], np.int8).copy()
+
+
 def random_selection(rng, H, W, weird=False):
-    """Returns (kind, payload, mask): kind in {'bbox','point','mask'}; mask is the HxW int8 mask the
-    reference's wrapper would build (bbox.py:22-30,43-49) or the raw mask."""
+    """Returns (kind, payload, mask): kind in {'bbox','point','mask'}; for a tuple the mask is what the reference's
+    wrapper class builds from it (reference_wrapper_mask), otherwise the raw mask."""
     t = rng.below(100)
     m = np.zeros((H, W), np.int8)
     if t < 40:
@@ -79,12 +95,10 @@ def random_selection(rng, H, W, weird=False):
         if rng.chance(1, 2):  # small rectangles: keep objects on the grid more often
             x2 = min(H - 1, x1 + rng.below(4))
             y2 = min(W - 1, y1 + rng.below(4))
-        m[min(x1, x2):max(x1, x2) + 1, min(y1, y2):max(y1, y2) + 1] = 1
-        return "bbox", (x1, y1, x2, y2), m
+        return "bbox", (x1, y1, x2, y2), reference_wrapper_mask(H, W, "bbox", (x1, y1, x2, y2))
     if t < 60:
         x, y = rng.below(H), rng.below(W)
-        m[x, y] = 1
-        return "point", (x, y), m
+        return "point", (x, y), reference_wrapper_mask(H, W, "point", (x, y))
     if t < 80:
         return "mask", None, m  # empty selection
     if t < 97 or not weird:

@@ -248,3 +248,28 @@ def packed(cls):
         if rows.shape[1] != ((P + 7 + 15) & ~15) or not np.array_equal(rows[:, :P + 7], want) or rows[:, P + 7:].any():
             errs.append(f"{H}x{W}: packed observation rows differ")
     return errs
+
+
+def bad_selection(cls):
+    """A point outside the plane / negative coordinates: empty selection + ARCLE_ST_BAD_SELECTION, on the backend and the
+    oracle alike (the reference's wrappers raise IndexError or wrap the index)."""
+    errs = []
+    N, H, W = 4, 10, 10
+    ops = O.o2arc_ops()
+    be, orc = cls(N, H, W, -1, "o2arc", ops), B.OracleBackend(N, H, W, -1, "o2arc", ops)
+    inp = np.ones((N, H, W), np.int8)
+    dims = np.tile(np.array([[H, W]], np.int8), (N, 1))
+    for b in (be, orc):
+        b.set_tasks(inp, dims, inp, dims)
+        b.reset()
+    for ing, pay in (("point", np.array([[H, 0], [0, W], [-1, 2], [3, 3]], np.int32)),
+                     ("bbox", np.array([[-1, 0, 2, 2], [0, -3, 1, 1], [1, 1, 2, 2], [H, W, H, W]], np.int32))):
+        op = np.full(N, 4, np.int32)
+        be.step(ing, pay, op)
+        orc.step(ing, pay, op)
+        s1, s2 = be.status(), orc.status()
+        if s1 != 8 or s2 != 8:
+            errs.append(f"{ing}: status {s1} (oracle {s2}), expected ARCLE_ST_BAD_SELECTION")
+        if not np.array_equal(be.get("grid"), orc.get("grid")):
+            errs.append(f"{ing}: grid differs from the oracle")
+    return errs

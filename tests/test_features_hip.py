@@ -25,7 +25,7 @@ def _gpu():
 
 
 @pytest.mark.parametrize("check", [F.wrappers, F.augment, F.dense, F.reset_on_submit, F.flat, F.continue_rule, F.sampler,
-                                   F.truncation, F.packed], ids=lambda f: f.__name__)
+                                   F.truncation, F.packed, F.bad_selection], ids=lambda f: f.__name__)
 def test_hip_feature(check):
     errs = check(B.HipBackend)
     assert not errs, "\n".join(errs[:10])
