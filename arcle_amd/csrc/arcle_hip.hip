@@ -44,9 +44,24 @@ ARCLE_DEV int lds_idx(int i, int /*n*/) { return i; }
 // Wave-uniform loads of per-env scalars (record, op index, counters, bbox / point payload): the address is uniform and
 // the location is not written by anyone else during the launch, so they go through the scalar cache straight into
 // SGPRs (s_load_dword[x2|x4]) — no VGPRs, no v_readfirstlane, handled by the scalar ALU afterwards.
+#ifdef ARCLE_VECTOR_INPUTS  // A/B: the same values through the vector memory path (global_load + v_readfirstlane)
+ARCLE_DEV uint32_t uload1(const void* p) { return uniform(*reinterpret_cast<const ARCLE_AS_GLOBAL uint32_t*>((uintptr_t)p)); }
+ARCLE_DEV U2 uload2(const void* p) {
+  U2 v = *reinterpret_cast<const ARCLE_AS_GLOBAL U2*>((uintptr_t)p);
+  v[0] = uniform(v[0]);
+  v[1] = uniform(v[1]);
+  return v;
+}
+ARCLE_DEV U4 uload4(const void* p) {
+  U4 v = *reinterpret_cast<const ARCLE_AS_GLOBAL U4*>((uintptr_t)p);
+  for (int i = 0; i < 4; i++) v[i] = uniform(v[i]);
+  return v;
+}
+#else
 ARCLE_DEV uint32_t uload1(const void* p) { return *reinterpret_cast<const ARCLE_AS_CONST uint32_t*>((uintptr_t)p); }
 ARCLE_DEV U2 uload2(const void* p) { return *reinterpret_cast<const ARCLE_AS_CONST U2*>((uintptr_t)p); }
 ARCLE_DEV U4 uload4(const void* p) { return *reinterpret_cast<const ARCLE_AS_CONST U4*>((uintptr_t)p); }
+#endif
 // 16 B plane load: SGPR base + 32-bit VGPR byte offset (global_load_dwordx4 v, v_off, s[base])
 ARCLE_DEV U4 load16(const int8_t* base, uint32_t off) {
   return *reinterpret_cast<const ARCLE_AS_GLOBAL U4*>((uintptr_t)base + off);
@@ -103,13 +118,13 @@ typedef arcle::BlockLDS<WAVES_PER_WG> BlockLDS;
 __device__ __forceinline__ int wave_of_launch() {
   const uint32_t nb = gridDim.x, b = blockIdx.x;  // nb is a multiple of 8
   const uint32_t vb = (b & 7u) * (nb >> 3) + (b >> 3);
-  return __builtin_amdgcn_readfirstlane((int)(vb * WAVES_PER_WG + (threadIdx.x >> 6)));
+  return __builtin_amdgcn_readfirstlane((int)(vb * (blockDim.x >> 6) + (threadIdx.x >> 6)));
 }
 
 // ING: selection ingress form; FW: arcle::FW_* grid-width class; TBL: arcle::TBL_O2ARC when the installed op table is
 // the canonical O2ARCv2Env one (descriptor computed in registers), arcle::TBL_LOOKUP for any other table;
-// ACCT: 1 = add the step's algorithmic bytes to p.acct[env]
-template <int ING, int FW, int TBL, int ACCT>
+// ACCT: 1 = add the step's algorithmic bytes to p.acct[env]; FEAT: 1 = carries the ARCLE_STEP_FEATURE_FLAGS code
+template <int ING, int FW, int TBL, int ACCT, int FEAT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
 #ifdef ARCLE_TRACE_WAVES
@@ -120,20 +135,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   const int env = valid ? wv : 0;
   arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false);
   arcle::StepInputs in = arcle::load_inputs<ING>(w, env);  // in flight while the expansion table is built
-  arcle::lut_init(lds.lut, (int)threadIdx.x, 64 * WAVES_PER_WG);
+  arcle::lut_init(lds.lut, (int)threadIdx.x, (int)blockDim.x);
   xl::wg_barrier();
   if (!valid) return;
 #ifdef ARCLE_TRACE_WAVES
-  arcle::wave_step<ING, FW, TBL, ACCT>(w, env, in, t_entry, xl::clock());
+  arcle::wave_step<ING, FW, TBL, ACCT, FEAT>(w, env, in, t_entry, xl::clock());
 #else
-  arcle::wave_step<ING, FW, TBL, ACCT>(w, env, in);
+  arcle::wave_step<ING, FW, TBL, ACCT, FEAT>(w, env, in);
 #endif
 }
 
 template <int ING, int FW, int TBL>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
-  arcle::lut_init(lds.lut, (int)threadIdx.x, 64 * WAVES_PER_WG);
+  arcle::lut_init(lds.lut, (int)threadIdx.x, (int)blockDim.x);
   xl::wg_barrier();
   const int env = wave_of_launch();
   if (env >= p.n_envs) return;
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const St
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_table_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
-  arcle::lut_init(lds.lut, (int)threadIdx.x, 64 * WAVES_PER_WG);
+  arcle::lut_init(lds.lut, (int)threadIdx.x, (int)blockDim.x);
   xl::wg_barrier();
   const int env = wave_of_launch();
   if (env >= p.n_envs) return;
@@ -395,7 +410,7 @@ extern "C" int arcle_can_elide_selected(const arcle_env* e) {
   return e->bufs.plane[ARCLE_PL_SELECTED] != nullptr;
 }
 
-static dim3 grid_for(int n_envs);
+static dim3 grid_for(int n_envs, int waves_per_wg = WAVES_PER_WG);
 
 extern "C" int arcle_reset_from_table(arcle_env* e, const int32_t* task_idx, const uint8_t* mask, void* stream) {
   if (!e || !task_idx) return ARCLE_ERR_ARG;
@@ -409,8 +424,8 @@ extern "C" int arcle_reset_from_table(arcle_env* e, const int32_t* task_idx, con
   return ARCLE_OK;
 }
 
-static dim3 grid_for(int n_envs) {
-  unsigned nb = (unsigned)((n_envs + WAVES_PER_WG - 1) / WAVES_PER_WG);
+static dim3 grid_for(int n_envs, int waves_per_wg) {
+  unsigned nb = (unsigned)((n_envs + waves_per_wg - 1) / waves_per_wg);
   nb = (nb + 7u) & ~7u;
   return dim3(nb);
 }
@@ -434,28 +449,30 @@ static int width_class(const StepParams& p) {
 }
 #ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiation exists (seconds instead of a minute)
 template <int ING>
-static int launch_step_ing(int, int, bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL) return ARCLE_ERR_CONFIG;
-  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 1>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 0>), g, b, 0, st, p);
+static int launch_step_ing(int, int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || feat) return ARCLE_ERR_CONFIG;
+  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 1, 0>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 0, 0>), g, b, 0, st, p);
   return ARCLE_OK;
 }
 #else
 template <int ING, int FW, int TBL>
 static void launch_step_acct(bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 1>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 0>), g, b, 0, st, p);
+  if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 1, 0>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 0, 0>), g, b, 0, st, p);
 }
 template <int ING, int FW>
-static void launch_step_tbl(int tbl, bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (tbl == arcle::TBL_O2ARC) launch_step_acct<ING, FW, arcle::TBL_O2ARC>(acct, g, b, st, p);
+static void launch_step_tbl(int tbl, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  // the feature instantiation decodes through the table copy (also correct for the canonical table) and has no accounting
+  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, arcle::TBL_LOOKUP, 0, 1>), g, b, 0, st, p);
+  else if (tbl == arcle::TBL_O2ARC) launch_step_acct<ING, FW, arcle::TBL_O2ARC>(acct, g, b, st, p);
   else launch_step_acct<ING, FW, arcle::TBL_LOOKUP>(acct, g, b, st, p);
 }
 template <int ING>
-static int launch_step_ing(int fw, int tbl, bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (fw == arcle::FW_FULL) launch_step_tbl<ING, arcle::FW_FULL>(tbl, acct, g, b, st, p);
-  else if (fw == arcle::FW_FAST) launch_step_tbl<ING, arcle::FW_FAST>(tbl, acct, g, b, st, p);
-  else launch_step_tbl<ING, arcle::FW_GENERIC>(tbl, acct, g, b, st, p);
+static int launch_step_ing(int fw, int tbl, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (fw == arcle::FW_FULL) launch_step_tbl<ING, arcle::FW_FULL>(tbl, acct, feat, g, b, st, p);
+  else if (fw == arcle::FW_FAST) launch_step_tbl<ING, arcle::FW_FAST>(tbl, acct, feat, g, b, st, p);
+  else launch_step_tbl<ING, arcle::FW_GENERIC>(tbl, acct, feat, g, b, st, p);
   return ARCLE_OK;
 }
 #endif
@@ -479,14 +496,19 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.flags = flags;
   p.acct = e->d_acct;
   p.rmask = nullptr;
-  const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
+  // workgroups of 8 waves while the batch is one occupancy round or two (7.3 vs 7.7 us per launch at 8192 envs), 4 waves in
+  // the streaming regime (76-79 vs 85-88 us at 131072 envs): in-box A/B, profiles/round2_experiments.txt
+  const int wpw = p.n_envs >= 65536 ? 4 : WAVES_PER_WG;
+  const dim3 g = grid_for(p.n_envs, wpw), b(64 * wpw);
   hipStream_t st = (hipStream_t)stream;
   const int fw = width_class(p), tbl = e->canonical;
   const bool acct = e->d_acct != nullptr;
+  const bool feat = (flags & ARCLE_STEP_FEATURE_FLAGS) != 0;
+  if (feat && acct) return fail(e, ARCLE_ERR_CONFIG, "byte accounting is not available together with ARCLE_STEP_FEATURE_FLAGS");
   int rc;
-  if (ingress == arcle::INGRESS_BBOX) rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, tbl, acct, g, b, st, p);
-  else if (ingress == arcle::INGRESS_POINT) rc = launch_step_ing<arcle::INGRESS_POINT>(fw, tbl, acct, g, b, st, p);
-  else rc = launch_step_ing<arcle::INGRESS_MASK>(fw, tbl, acct, g, b, st, p);
+  if (ingress == arcle::INGRESS_BBOX) rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, tbl, acct, feat, g, b, st, p);
+  else if (ingress == arcle::INGRESS_POINT) rc = launch_step_ing<arcle::INGRESS_POINT>(fw, tbl, acct, feat, g, b, st, p);
+  else rc = launch_step_ing<arcle::INGRESS_MASK>(fw, tbl, acct, feat, g, b, st, p);
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
@@ -535,7 +557,8 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
   if (flags & ~(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT))
     return fail(e, ARCLE_ERR_ARG, "flag not supported by the rollout kernels");
-  if ((flags & ARCLE_STEP_CONTINUE_RULE) && ingress != arcle::INGRESS_MASK) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_CONTINUE_RULE needs mask ingress");
+  if ((flags & ARCLE_STEP_FEATURE_FLAGS) && ingress != arcle::INGRESS_MASK)
+    return fail(e, ARCLE_ERR_CONFIG, "the rollout kernels take ARCLE_STEP_CONTINUE_RULE / _RESET_ON_SUBMIT with mask ingress only");
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.ingress = ingress;

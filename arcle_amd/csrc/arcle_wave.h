@@ -1060,22 +1060,26 @@ struct StepOut {
 // Everything of step() between "record/op/payload are in registers" and "record/counters/outputs go back to
 // memory": autoreset, op decode, the operation itself, reward.  Planes are read/written through w.load/w.store, so
 // the same code serves the single-step kernel (HBM) and the rollout kernel (register-resident planes).
-template <int ING, int FW, int TBL, int ACCT>
+// FEAT: 1 = the instantiation also carries the rarely used step flags (ARCLE_STEP_FEATURE_FLAGS: device-side task
+// re-sampling + augmentation, dense reward, continuation rule, reset_on_submit); the plain instantiations (FEAT = 0) keep
+// them out of the hot kernel's code, registers and SGPR spills
+template <int ING, int FW, int TBL, int ACCT, int FEAT>
 ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, const int op) {
   const StepParams& p = w.p;
   const int P = p.P, W = p.W, lane = w.lane;
   StepOut out;
   out.reward = 0;
   out.bytes = 0;
-  if (p.flags & (ARCLE_STEP_AUTORESET | ARCLE_STEP_RESAMPLE)) {
+  if (p.flags & (ARCLE_STEP_AUTORESET | (FEAT ? ARCLE_STEP_RESAMPLE : 0u))) {
     // next-step autoreset: an env whose episode ended (terminated, or — with ARCLE_STEP_TRUNCATE — out of steps) is
     // re-initialised instead of executing the action; ARCLE_STEP_RESAMPLE first draws a new task on the device
     const bool ended = r.term() != 0 || ((p.flags & ARCLE_STEP_TRUNCATE) && cnt0.x >= p.step_limit);
     if (ended) {
       bool ok = true;
       U4 in = u4_zero();
-      if (p.flags & ARCLE_STEP_RESAMPLE) ok = load_sampled_task(w, r, w.env, in);
-      if (ok) init_state(w, r, cnt0, (p.flags & ARCLE_STEP_RESAMPLE) ? &in : nullptr);
+      const bool resample = FEAT && (p.flags & ARCLE_STEP_RESAMPLE);
+      if (resample) ok = load_sampled_task(w, r, w.env, in);
+      if (ok) init_state(w, r, cnt0, resample ? &in : nullptr);
       else if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
       out.term = 0;
       out.bytes = (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
@@ -1104,7 +1108,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   Sel sel;
   ingest_selection(w, sel, payload);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
-  if (ING == INGRESS_MASK && (p.flags & ARCLE_STEP_CONTINUE_RULE) &&
+  if (FEAT && ING == INGRESS_MASK && (p.flags & ARCLE_STEP_CONTINUE_RULE) &&
       (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
     // the O2ARC trace harness (tests/o2arc_check.py:169-170): an object op whose logged selection equals the env's
     // current `selected` plane continues the active object, i.e. is sent with an empty selection
@@ -1355,7 +1359,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
         trials = i8w(trials - 1);  // :174 int8 wrap
         r.put(ARCLE_REC_TRIALS, trials);
         submit_inc = 1;
-        if (p.flags & ARCLE_STEP_RESET_ON_SUBMIT) {
+        if (FEAT && (p.flags & ARCLE_STEP_RESET_ON_SUBMIT)) {
           // base.py:179-180: init_state() rebinds current_state inside submit — the decrement, the `terminated` of a
           // correct answer and the trials-exhausted check below all land on the discarded dict;
           // what the caller sees is the re-initialised state, and reward() is evaluated on it
@@ -1391,7 +1395,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     if (eq < 0) eq = grid_equals_answer<ACCT>(w, s, r) ? 1 : 0;
     reward = eq;
   }
-  if (p.flags & ARCLE_STEP_DENSE) {
+  if (FEAT && (p.flags & ARCLE_STEP_DENSE)) {
     // the research env's dense reward (agents/env.py:44-58) as an exact integer pair (correct cells, total cells);
     // the host forms  sparse*100 - 1 + correct/total
     need_grid<ACCT>(w, s);
@@ -1441,7 +1445,7 @@ ARCLE_DEV StepInputs load_inputs(const Wave& w, int env) {
 // One wave = one env of the launch.  (A grid-stride variant — a wave walking several envs with the next env's scalars
 // prefetched — measured no faster on this access pattern, tools/membench.hip "E=2/4/8 seq", and its loop-invariant
 // code motion costs SGPRs on the single-env path.)
-template <int ING, int FW, int TBL, int ACCT>
+template <int ING, int FW, int TBL, int ACCT, int FEAT>
 ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0, uint64_t t_lut = 0) {
   const StepParams& p = w.p;
   const int lane = w.lane;
@@ -1460,7 +1464,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   cnt0.y = (int32_t)in.cnt[1];
   w.set_env(env);
   const Rec r_in = r;
-  const StepOut out = step_core<ING, FW, TBL, ACCT>(w, r, cnt0, in.payload, (int)in.op);
+  const StepOut out = step_core<ING, FW, TBL, ACCT, FEAT>(w, r, cnt0, in.payload, (int)in.op);
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_core = xl::clock();
 #endif
@@ -1520,7 +1524,8 @@ ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, const U2* lut, in
       next_payload = load_payload_v(w, env, (size_t)t + 1);
       next_op = (uint32_t)p.op[((size_t)t + 1) * N + env];
     }
-    const StepOut out = step_core<ING, FW, TBL, 0>(w, r, cnt, payload, op);
+    // (the feature flags a rollout accepts — continuation rule, reset_on_submit — belong to mask-ingress trace replay)
+    const StepOut out = step_core<ING, FW, TBL, 0, ING == INGRESS_MASK ? 1 : 0>(w, r, cnt, payload, op);
     if (lane == 0) {
       p.reward[(size_t)t * N + env] = out.reward;
       p.term[(size_t)t * N + env] = (uint8_t)out.term;
@@ -1678,20 +1683,16 @@ ARCLE_DEV void wave_pack_obs(const StepParams& p, WaveLDS* lds, const U2* lut, i
   if (16 * lane + 16 > P) {          // this lane's window holds the metadata bytes
     const Rec r = load_rec(p, env);
     const uint32_t rew = (uint32_t)p.reward[env];
-    uint8_t meta[7];
-    meta[0] = (uint8_t)r.gh();
-    meta[1] = (uint8_t)r.gw();
-    meta[2] = (uint8_t)rew;
-    meta[3] = (uint8_t)(rew >> 8);
-    meta[4] = (uint8_t)(rew >> 16);
-    meta[5] = (uint8_t)(rew >> 24);
-    meta[6] = p.term[env];
+    // the 7 metadata bytes as one little-endian word: grid_dim (2), reward int32 (4), terminated (1)
+    const uint64_t meta = (uint64_t)(uint32_t)r.gh() | ((uint64_t)(uint32_t)r.gw() << 8) | ((uint64_t)rew << 16) |
+                          ((uint64_t)p.term[env] << 48);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int b = 16 * lane + k - P;
-      uint32_t byte = (v[k >> 2] >> (8 * (k & 3))) & 0xffu;
-      if (b >= 0) byte = b < 7 ? meta[b] : 0u;
-      v[k >> 2] = (v[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (byte << (8 * (k & 3)));
+      if (b >= 0) {
+        const uint32_t byte = b < 7 ? (uint32_t)(meta >> (8 * b)) & 0xffu : 0u;
+        v[k >> 2] = (v[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (byte << (8 * (k & 3)));
+      }
     }
   }
   *reinterpret_cast<U4*>(p.flat_out + (size_t)env * p.flat_stride + 16 * lane) = v;

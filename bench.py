@@ -283,6 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-headline legs (kernel A/B runs)")
     ap.add_argument("--no-graph", action="store_true", help="launch the K steps of a region eagerly instead of as one hipGraph")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp launches (counter-collection runs)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -374,15 +375,7 @@ def main():
             pass
         torch.cuda.synchronize(dev)
 
-    # ---- untimed: clock ramp (the chip idles at low clocks before the first launch) + W warm-up steps -------------
-    t_ramp = time.perf_counter()
-    i = 0
-    while time.perf_counter() - t_ramp < 0.08:
-        for _ in range(64):
-            step(i)
-            i += 1
-        torch.cuda.synchronize(dev)
-    batch.reset()
+    # ---- untimed: W warm-up steps ---------------------------------------------------------------------------------
     for i in range(Wm):
         step(i)
     torch.cuda.synchronize(dev)
@@ -392,40 +385,50 @@ def main():
 
     # The K steps of a region are captured once into a hipGraph (K launches of arcle_step_kernel, each with its own
     # action batch) and replayed per region: a launch-bound inner loop belongs in a graph, and the host then issues one
-    # call per region instead of K.  (c4 keeps eager launches: its collective is not captured.)
+    # call per region instead of K.  (With more than one rank c4 keeps eager launches: its collective is not captured.)
     graph = None
-    if not a.no_graph and gather is None:
+    if not a.no_graph and (gather is None or dist is None):
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev)):
                 csh = torch.cuda.current_stream(dev).cuda_stream
                 for i in range(Wm, Wm + K):
                     batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, csh)
-            graph.replay()  # (first replay uploads the graph)
-            torch.cuda.synchronize(dev)
-            for k, v in snap.items():
-                batch.planes[k].copy_(v)
-            batch.rec.copy_(snap_rec)
-            batch.cnt.copy_(snap_cnt)
-            torch.cuda.synchronize(dev)
+                    if gather is not None:
+                        batch.packed_obs_ptr(packed_ptr, csh)
         except Exception as exc:  # capture unsupported: eager launches
             print(f"bench: hipGraph capture failed ({exc}); eager launches", file=sys.stderr)
             graph = None
+
+    def region(r):
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(Wm + r * K, Wm + (r + 1) * K):
+                step(i)
+
+    # untimed clock ramp (the chip idles at low clocks before the first launch): the region's own launches, ~80 ms of them
+    t_ramp, r = time.perf_counter(), 0
+    n_ramp = max(2, min(50, 4000 // max(K, 1)))  # (a fixed count when ranks must stay in step with each other)
+    while not a.no_ramp and ((time.perf_counter() - t_ramp < 0.08) if dist is None else (r < n_ramp)):
+        region(r)
+        r += 1
+        torch.cuda.synchronize(dev)
+    for k, v in snap.items():  # back to the state the regions are defined to start from
+        batch.planes[k].copy_(v)
+    batch.rec.copy_(snap_rec)
+    batch.cnt.copy_(snap_cnt)
+    torch.cuda.synchronize(dev)
 
     # ---- R timed regions of exactly K steps, each bracketed by barrier + synchronize ---------------------------
     wall, kern = [], []
     for r in range(R):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        base = Wm + r * K
         barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         ev0.record(stream)  # HIP events on the stream the kernel is launched on
-        if graph is not None:
-            graph.replay()
-        else:
-            for i in range(base, base + K):
-                step(i)
+        region(r)
         ev1.record(stream)
         wait_gpu(ev1)
         barrier()
@@ -490,7 +493,8 @@ def main():
             "config": {"workload": cfg["name"], "id": a.config, "envs_per_gpu": n, "global_envs": n * world,
                        "grid": [H, W], "ingress": "bbox",
                        "parallelism": f"env-shard x{world} (no data-path collective)" if gather is None
-                       else f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL'})"},
+                       else (f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL'})"
+                             if dist is not None else "one rank: step + packing launch per step, nothing to gather")},
             "timing": {"regions": R, "stat": "median region, max over ranks per region",
                        "launch": "hipGraph of the K step launches, one replay per region" if graph is not None else "eager",
                        "region_ms": [round(float(x) * 1e3, 4) for x in wall_t.tolist()][:12]},

@@ -136,6 +136,8 @@ enum arcle_op_kind {
 /* reset(options={'reset_on_submit': True}) (base.py:87-93,179-180): a Submit with trials left
  * re-initialises the env from its input inside the op; the caller sees the fresh state, terminated stays 0 */
 #define ARCLE_STEP_RESET_ON_SUBMIT 64u
+/* the step flags served by the feature instantiations of the step kernel (the plain ones stay lean) */
+#define ARCLE_STEP_FEATURE_FLAGS (ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT)
 /* the step call also emits the flattened observation rows (arcle_set_flat_output) of the state it produced */
 #define ARCLE_STEP_FLAT_OBS 128u
 

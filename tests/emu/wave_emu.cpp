@@ -112,8 +112,9 @@ int g_tbl;  // arcle::TBL_* of the installed table (emu_run compares it with the
   do {                                                                                      \
     arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, I, F, false);                      \
     arcle::StepInputs in = arcle::load_inputs<I>(w, g_env);                                 \
-    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_step<I, F, arcle::TBL_O2ARC, 1>(w, g_env, in); \
-    else arcle::wave_step<I, F, arcle::TBL_LOOKUP, 1>(w, g_env, in);                        \
+    if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, arcle::TBL_LOOKUP, 0, 1>(w, g_env, in); \
+    else if (g_tbl == arcle::TBL_O2ARC) arcle::wave_step<I, F, arcle::TBL_O2ARC, 1, 0>(w, g_env, in); \
+    else arcle::wave_step<I, F, arcle::TBL_LOOKUP, 1, 0>(w, g_env, in);                     \
   } while (0)
 #define RUN_ROLL(I, F)                                                                                          \
   do {                                                                                                          \

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   name=$1; shift
   rm -rf $R/gpurun_out/pmc_$name
-  rocprofv3 --pmc "$@" --kernel-trace -d $R/gpurun_out/pmc_$name -o p --output-format csv -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace -d $R/gpurun_out/pmc_$name -o p --output-format csv -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras --no-graph --no-ramp --regions 2 > $R/gpurun_out/pmc_$name.log 2>&1
   python - "$R/gpurun_out/pmc_$name" <<'PY'
 import sys, csv, glob, collections
 d=sys.argv[1]

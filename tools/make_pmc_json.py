@@ -6,7 +6,7 @@ the bytes of a wide coalesced (16 B/lane) read stream, so it is doubled; WRITE_S
 import csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-tag = sys.argv[2] if len(sys.argv) > 2 else "round1"
+tag = sys.argv[2] if len(sys.argv) > 2 else "round2"
 
 
 def mean_counter(d, name):
@@ -23,7 +23,8 @@ write, n2 = mean_counter("pmc_mem2", "WRITE_SIZE")
 out = {"kernel": "arcle_step_kernel", "launches_sampled": [n1, n2], "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
        "read_bytes_per_launch": fetch * 1024 * 2, "write_bytes_per_launch": write * 1024,
        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
-       "source": f"profiles/{tag}_pmc_*.csv: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
-                 "`python bench.py --steps 40 --warmup 5`; FETCH_SIZE x2 (gfx950 half-count of 16 B/lane streams), KiB->B"}
+       "source": f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+                 "`python bench.py --steps 40 --warmup 5 --no-graph --no-ramp --regions 2`; FETCH_SIZE x2 (gfx950 half-count "
+                 "of 16 B/lane streams), KiB->B"}
 json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
