@@ -97,6 +97,11 @@ ARCLE_DEV uint32_t opaque(uint32_t v) {  // hides a value's origin from the opti
 // the compiler from sinking some of the loads below a branch on another (a second dependent latency)
 ARCLE_DEV void arrived(U4& a, U2& b, uint32_t& c, U4& d) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)); }
 ARCLE_DEV void arrived3(U4& a, U2& b, uint32_t& c) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c)); }
+#ifndef ARCLE_STOP_AT
+#define ARCLE_STOP_AT 0
+#endif
+__device__ __forceinline__ void sink_s(uint32_t v) { asm volatile("" ::"s"(v)); }
+__device__ __forceinline__ void sink_v(uint32_t v) { asm volatile("" ::"v"(v)); }
 }  // namespace xl
 
 #include "arcle_wave.h"
@@ -115,44 +120,48 @@ typedef arcle::BlockLDS<WAVES_PER_WG> BlockLDS;
 
 // wave index of the launch with XCD-contiguous ranges: workgroup b runs on XCD b%8 (observed), so
 // vb = (b&7)*(nb/8) + (b>>3) gives each XCD one contiguous range of waves (affinity only)
-__device__ __forceinline__ int wave_of_launch() {
+// (waves_per_wg comes from the caller, not from blockDim: the workgroup size sits in the hidden kernel arguments as a 16-bit
+// field, which costs a VECTOR load and its latency before the wave can even compute which env it owns)
+__device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG) {
   const uint32_t nb = gridDim.x, b = blockIdx.x;  // nb is a multiple of 8
   const uint32_t vb = (b & 7u) * (nb >> 3) + (b >> 3);
-  return __builtin_amdgcn_readfirstlane((int)(vb * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  return __builtin_amdgcn_readfirstlane((int)(vb * (uint32_t)waves_per_wg + (threadIdx.x >> 6)));
 }
 
-// ING: selection ingress form; FW: arcle::FW_* grid-width class; TBL: arcle::TBL_O2ARC when the installed op table is
-// the canonical O2ARCv2Env one (descriptor computed in registers), arcle::TBL_LOOKUP for any other table;
+// ING: selection ingress form; FW: arcle::FW_* grid-width class;
 // ACCT: 1 = add the step's algorithmic bytes to p.acct[env]; FEAT: 1 = carries the ARCLE_STEP_FEATURE_FLAGS code
-template <int ING, int FW, int TBL, int ACCT, int FEAT>
+template <int ING, int FW, int ACCT, int FEAT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_entry = xl::clock();
 #endif
-  const int wv = wave_of_launch();
+  const int wv = wave_of_launch(p.wpw);
   const bool valid = wv < p.n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = valid ? wv : 0;
   arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false);
   arcle::StepInputs in = arcle::load_inputs<ING>(w, env);  // in flight while the expansion table is built
-  arcle::lut_init(lds.lut, (int)threadIdx.x, (int)blockDim.x);
+  arcle::lut_init(lds.lut, (int)threadIdx.x);
   xl::wg_barrier();
   if (!valid) return;
+#if ARCLE_STOP_AT == 1
+  return;
+#endif
 #ifdef ARCLE_TRACE_WAVES
-  arcle::wave_step<ING, FW, TBL, ACCT, FEAT>(w, env, in, t_entry, xl::clock());
+  arcle::wave_step<ING, FW, ACCT, FEAT>(w, env, in, t_entry, xl::clock());
 #else
-  arcle::wave_step<ING, FW, TBL, ACCT, FEAT>(w, env, in);
+  arcle::wave_step<ING, FW, ACCT, FEAT>(w, env, in);
 #endif
 }
 
-template <int ING, int FW, int TBL>
+template <int ING, int FW>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
-  arcle::lut_init(lds.lut, (int)threadIdx.x, (int)blockDim.x);
+  arcle::lut_init(lds.lut, (int)threadIdx.x);
   xl::wg_barrier();
   const int env = wave_of_launch();
   if (env >= p.n_envs) return;
-  arcle::wave_rollout<ING, FW, TBL>(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
+  arcle::wave_rollout<ING, FW>(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
 // one LDS row buffer per wave: 7 planes of <= 1024 B + 14 scalars, rounded up
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const St
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_table_kernel(const StepParams p) {
   __shared__ BlockLDS lds;
-  arcle::lut_init(lds.lut, (int)threadIdx.x, (int)blockDim.x);
+  arcle::lut_init(lds.lut, (int)threadIdx.x);
   xl::wg_barrier();
   const int env = wave_of_launch();
   if (env >= p.n_envs) return;
@@ -212,7 +221,6 @@ struct arcle_env {
   uint32_t* d_status;
   uint32_t* d_ops;
   uint32_t ops_host[ARCLE_MAX_OPS];
-  int canonical;  // arcle::TBL_*: the installed table equals a canonical one
   int8_t* flat_out;  // ARCLE_STEP_FLAT_OBS destination (arcle_set_flat_output)
   int32_t flat_stride;
   int flat_filtered;
@@ -352,14 +360,6 @@ extern "C" int arcle_get_buffers(const arcle_env* e, arcle_buffers* out) {
   return ARCLE_OK;
 }
 
-// is the table the canonical O2ARCv2Env one (o2arcenv.py:88-113)?  Must match arcle::decode_op<TBL_O2ARC> exactly.
-static int canonical_table(const uint32_t* d, int n) {
-  if (n != 35) return arcle::TBL_LOOKUP;
-  for (int i = 0; i < n; i++)
-    if (d[i] != arcle::o2arc_desc(i)) return arcle::TBL_LOOKUP;
-  return arcle::TBL_O2ARC;
-}
-
 extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n_ops) {
   if (!e || !descs) return ARCLE_ERR_ARG;
   DeviceGuard guard(e->device);
@@ -385,7 +385,6 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
   memcpy(e->ops_host, descs, sizeof(uint32_t) * (size_t)n_ops);
   HIP_TRY(e, hipMemcpy(e->d_ops, e->ops_host, sizeof(e->ops_host), hipMemcpyHostToDevice));  // synchronous
   e->base.n_ops = n_ops;
-  e->canonical = canonical_table(e->ops_host, n_ops);
   return ARCLE_OK;
 }
 
@@ -449,30 +448,24 @@ static int width_class(const StepParams& p) {
 }
 #ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiation exists (seconds instead of a minute)
 template <int ING>
-static int launch_step_ing(int, int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || feat) return ARCLE_ERR_CONFIG;
-  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 1, 0>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, arcle::TBL_O2ARC, 0, 0>), g, b, 0, st, p);
+  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 0>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0>), g, b, 0, st, p);
   return ARCLE_OK;
 }
 #else
-template <int ING, int FW, int TBL>
-static void launch_step_acct(bool acct, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 1, 0>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, TBL, 0, 0>), g, b, 0, st, p);
-}
 template <int ING, int FW>
-static void launch_step_tbl(int tbl, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  // the feature instantiation decodes through the table copy (also correct for the canonical table) and has no accounting
-  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, arcle::TBL_LOOKUP, 0, 1>), g, b, 0, st, p);
-  else if (tbl == arcle::TBL_O2ARC) launch_step_acct<ING, FW, arcle::TBL_O2ARC>(acct, g, b, st, p);
-  else launch_step_acct<ING, FW, arcle::TBL_LOOKUP>(acct, g, b, st, p);
+static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, p);  // (the feature instantiation has no accounting)
+  else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, p);
 }
 template <int ING>
-static int launch_step_ing(int fw, int tbl, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (fw == arcle::FW_FULL) launch_step_tbl<ING, arcle::FW_FULL>(tbl, acct, feat, g, b, st, p);
-  else if (fw == arcle::FW_FAST) launch_step_tbl<ING, arcle::FW_FAST>(tbl, acct, feat, g, b, st, p);
-  else launch_step_tbl<ING, arcle::FW_GENERIC>(tbl, acct, feat, g, b, st, p);
+static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if (fw == arcle::FW_FULL) launch_step_tbl<ING, arcle::FW_FULL>(acct, feat, g, b, st, p);
+  else if (fw == arcle::FW_FAST) launch_step_tbl<ING, arcle::FW_FAST>(acct, feat, g, b, st, p);
+  else launch_step_tbl<ING, arcle::FW_GENERIC>(acct, feat, g, b, st, p);
   return ARCLE_OK;
 }
 #endif
@@ -499,16 +492,17 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   // workgroups of 8 waves while the batch is one occupancy round or two (7.3 vs 7.7 us per launch at 8192 envs), 4 waves in
   // the streaming regime (76-79 vs 85-88 us at 131072 envs): in-box A/B, profiles/round2_experiments.txt
   const int wpw = p.n_envs >= 65536 ? 4 : WAVES_PER_WG;
+  p.wpw = wpw;
   const dim3 g = grid_for(p.n_envs, wpw), b(64 * wpw);
   hipStream_t st = (hipStream_t)stream;
-  const int fw = width_class(p), tbl = e->canonical;
+  const int fw = width_class(p);
   const bool acct = e->d_acct != nullptr;
   const bool feat = (flags & ARCLE_STEP_FEATURE_FLAGS) != 0;
   if (feat && acct) return fail(e, ARCLE_ERR_CONFIG, "byte accounting is not available together with ARCLE_STEP_FEATURE_FLAGS");
   int rc;
-  if (ingress == arcle::INGRESS_BBOX) rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, tbl, acct, feat, g, b, st, p);
-  else if (ingress == arcle::INGRESS_POINT) rc = launch_step_ing<arcle::INGRESS_POINT>(fw, tbl, acct, feat, g, b, st, p);
-  else rc = launch_step_ing<arcle::INGRESS_MASK>(fw, tbl, acct, feat, g, b, st, p);
+  if (ingress == arcle::INGRESS_BBOX) rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, acct, feat, g, b, st, p);
+  else if (ingress == arcle::INGRESS_POINT) rc = launch_step_ing<arcle::INGRESS_POINT>(fw, acct, feat, g, b, st, p);
+  else rc = launch_step_ing<arcle::INGRESS_MASK>(fw, acct, feat, g, b, st, p);
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
@@ -534,18 +528,17 @@ extern "C" int arcle_step_point(arcle_env* e, const int32_t* xy, const int32_t* 
 
 #ifdef ARCLE_FAST_BUILD
 template <int ING>
-static int launch_rollout_ing(int, int, dim3, dim3, hipStream_t, const StepParams&) { return ARCLE_ERR_CONFIG; }
+static int launch_rollout_ing(int, dim3, dim3, hipStream_t, const StepParams&) { return ARCLE_ERR_CONFIG; }
 #else
 template <int ING, int FW>
-static void launch_rollout_tbl(int tbl, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (tbl == arcle::TBL_O2ARC) hipLaunchKernelGGL((arcle_rollout_kernel<ING, FW, arcle::TBL_O2ARC>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((arcle_rollout_kernel<ING, FW, arcle::TBL_LOOKUP>), g, b, 0, st, p);
+static void launch_rollout_tbl(dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  hipLaunchKernelGGL((arcle_rollout_kernel<ING, FW>), g, b, 0, st, p);
 }
 template <int ING>
-static int launch_rollout_ing(int fw, int tbl, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+static int launch_rollout_ing(int fw, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   // (the rollout keeps planes in registers: lane predication does not matter, FW_FULL shares FW_FAST's code)
-  if (fw != arcle::FW_GENERIC) launch_rollout_tbl<ING, arcle::FW_FAST>(tbl, g, b, st, p);
-  else launch_rollout_tbl<ING, arcle::FW_GENERIC>(tbl, g, b, st, p);
+  if (fw != arcle::FW_GENERIC) launch_rollout_tbl<ING, arcle::FW_FAST>(g, b, st, p);
+  else launch_rollout_tbl<ING, arcle::FW_GENERIC>(g, b, st, p);
   return ARCLE_OK;
 }
 #endif
@@ -572,11 +565,11 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   p.n_steps = n_steps;
   const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
   hipStream_t st = (hipStream_t)stream;
-  const int fw = width_class(p), tbl = e->canonical;
+  const int fw = width_class(p);
   int rc;
-  if (ingress == arcle::INGRESS_BBOX) rc = launch_rollout_ing<arcle::INGRESS_BBOX>(fw, tbl, g, b, st, p);
-  else if (ingress == arcle::INGRESS_POINT) rc = launch_rollout_ing<arcle::INGRESS_POINT>(fw, tbl, g, b, st, p);
-  else rc = launch_rollout_ing<arcle::INGRESS_MASK>(fw, tbl, g, b, st, p);
+  if (ingress == arcle::INGRESS_BBOX) rc = launch_rollout_ing<arcle::INGRESS_BBOX>(fw, g, b, st, p);
+  else if (ingress == arcle::INGRESS_POINT) rc = launch_rollout_ing<arcle::INGRESS_POINT>(fw, g, b, st, p);
+  else rc = launch_rollout_ing<arcle::INGRESS_MASK>(fw, g, b, st, p);
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no rollout kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   return ARCLE_OK;

@@ -39,7 +39,6 @@ enum { INGRESS_MASK = 0, INGRESS_BBOX = 1, INGRESS_POINT = 2 };
 enum { FW_GENERIC = 0,  // any W
        FW_FAST = 1,     // 16 <= W <= 32: a lane's 16-cell window spans at most two rows (cheap rectangle masks, DPP flood fill)
        FW_FULL = 2 };   // FW_FAST and PS == 1024: all 64 lanes hold cells of the plane row, no lane predication on plane I/O
-enum { TBL_LOOKUP = 0, TBL_O2ARC = 1 };
 
 struct StepParams {
   // ---- step / rollout kernels ----
@@ -82,7 +81,7 @@ struct StepParams {
   const uint8_t* aug_k;     // explicit augmentation (ARCLE_AUG_EXPLICIT): rot90 count per env, uint8 [N]
   const uint8_t* aug_perm;  // explicit colour permutation per env, uint8 [N][16] (perm[c], c < 10)
   int32_t n_problems;
-  int32_t pad_;
+  int32_t wpw;  // step kernel: waves per workgroup of this launch (set by the launcher)
 };
 
 // 16 bytes of a plane = 4 VGPRs; a first-class vector value so that it always lives in registers
@@ -226,9 +225,6 @@ struct Rec {
   ARCLE_DEV int ah() const { return ub(14); }
   ARCLE_DEV int aw() const { return ub(15); }
 };
-ARCLE_DEV bool rec_differs(const Rec& a, const Rec& b) {
-  return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) != 0u;
-}
 
 // ------------------------------------------------------------------------------------------------
 // wave context
@@ -384,7 +380,8 @@ struct Wave {
 };
 
 // fills the workgroup's mask-expansion table; every thread of the workgroup calls it, followed by xl::wg_barrier()
-ARCLE_DEV void lut_init(U2* lut, int tid, int nthreads) {
+// (workgroups that use the table have >= 256 threads; the emulator's single wave passes `nthreads` = 64)
+ARCLE_DEV void lut_init(U2* lut, int tid, int nthreads = 256) {
   for (int b = tid; b < 256; b += nthreads) {
     const uint32_t lo = (uint32_t)b & 0xfu, hi = ((uint32_t)b >> 4) & 0xfu;
     const uint32_t x = (lo * 0x00204081u) & 0x01010101u, y = (hi * 0x00204081u) & 0x01010101u;
@@ -407,21 +404,15 @@ struct Sel {
   bool is_rect;        // built from a bbox / point tuple: every cell of the bbox is 1
 };
 
-ARCLE_DEV void sel_from_rect(const Wave& w, Sel& s, int x1, int x2, int y1, int y2) {
-  s.is_rect = true;
-  s.any_nz = s.any_pos = (x1 <= x2 && y1 <= y2);
-  s.x0 = x1;
-  s.x1 = x2;
-  s.y0 = y1;
-  s.y1 = y2;
-  s.nz = s.pos = w.rect16(x1, x2, y1, y2);
-  s.vals = u4_zero();
-}
+// Cell masks of the selection.  For a bbox / point tuple they are a rectangle mask built where an op needs it (most ops of
+// the O2ARC table read only the tuple: FloodFill, Copy, Paste, CropGrid, ResizeGrid), for a mask payload ingest_cells made them.
+ARCLE_DEV uint32_t sel_nz(const Wave& w, const Sel& s) { return s.is_rect ? w.rect16(s.x0, s.x1, s.y0, s.y1) : s.nz; }
+ARCLE_DEV uint32_t sel_pos(const Wave& w, const Sel& s) { return s.is_rect ? w.rect16(s.x0, s.x1, s.y0, s.y1) : s.pos; }
 
 // the raw int8 selection values (`selected = sel`, keep_sel object.py:38; mask ingress keeps what it loaded)
 ARCLE_DEV U4 sel_values(const Wave& w, const Sel& s) {
   if (!s.is_rect) return s.vals;
-  return u4_and1(w.expand16(s.nz), 0x01010101u);
+  return u4_and1(w.expand16(sel_nz(w, s)), 0x01010101u);
 }
 
 // The selection payload of this env.  bbox = 4 ints, point = 2 ints: wave-uniform scalar loads; mask = this lane's
@@ -468,8 +459,12 @@ ARCLE_DEV U4 load_payload_v(const Wave& w, int env, size_t step) {
   return v;
 }
 
-ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
+// Ingest: `ingest_scalar` is the wave-uniform part of a bbox / point tuple (returns false for a tuple outside the wrappers'
+// action space; the caller raises ARCLE_ST_BAD_SELECTION), `ingest_cells` produces the per-lane cell masks (and everything
+// for a mask payload).
+ARCLE_DEV bool ingest_scalar(const Wave& w, Sel& s, const U4& payload) {
   const StepParams& p = w.p;
+  bool ok = true;
   if (w.ingress == INGRESS_BBOX) {
     // BBoxWrapper.action (bbox.py:22-30): sort the corners, sel[x1:x2+1, y1:y2+1] = 1 (slices clip at H, W;
     // negative coordinates are outside the wrapper's Discrete action space and select nothing here)
@@ -478,17 +473,26 @@ ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
     int ya = imin(by1, by2), yb = imin(imax(by1, by2), p.W - 1);
     if ((xa | ya) < 0) {
       xa = xb + 1;
-      if (w.lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
+      ok = false;
     }
-    sel_from_rect(w, s, xa, xb, ya, yb);
-    return;
-  }
-  if (w.ingress == INGRESS_POINT) {
+    s.x0 = xa; s.x1 = xb; s.y0 = ya; s.y1 = yb;
+  } else if (w.ingress == INGRESS_POINT) {
     // PointWrapper.action (bbox.py:43-49)
     const int x = (int)payload[0], y = (int)payload[1];
-    const bool ok = x >= 0 && x < p.H && y >= 0 && y < p.W;
-    if (!ok && w.lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
-    sel_from_rect(w, s, x, ok ? x : x - 1, y, y);
+    ok = x >= 0 && x < p.H && y >= 0 && y < p.W;
+    s.x0 = x; s.x1 = ok ? x : x - 1; s.y0 = s.y1 = y;
+  } else {
+    return true;
+  }
+  s.is_rect = true;
+  s.any_nz = s.any_pos = (s.x0 <= s.x1 && s.y0 <= s.y1);
+  return ok;
+}
+ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload) {
+  const StepParams& p = w.p;
+  if (w.ingress != INGRESS_MASK) {  // (masks on demand: sel_nz / sel_pos)
+    s.nz = s.pos = 0;
+    s.vals = u4_zero();
     return;
   }
   const U4 v = payload;
@@ -533,7 +537,8 @@ ARCLE_DEV void ingest_selection(const Wave& w, Sel& s, const U4& payload) {
 // ------------------------------------------------------------------------------------------------
 struct Scratch {
   U4 grid;
-  bool have_grid;    // `grid` holds the current grid plane
+  bool have_grid;    // `grid` holds the current grid plane (loaded, requested early, or just produced by the op)
+  bool grid_counted; // ACCT: the byte count already includes the grid read (or the op replaced the plane)
   bool sel_written;  // the op itself wrote `selected` (place): the reset_sel / keep_sel value is superseded
   uint32_t bytes;  // algorithmic HBM bytes of this step (SURVEY.md §8d accounting; ACCT instantiations only)
 };
@@ -547,7 +552,10 @@ ARCLE_DEV void need_grid(const Wave& w, Scratch& s) {
   if (!s.have_grid) {
     s.grid = w.load(ARCLE_PL_GRID);
     s.have_grid = true;
-    ARCLE_ACCT(w.p.P);  // the op semantically reads the grid
+  }
+  if (ACCT && !s.grid_counted) {
+    s.bytes += w.p.P;  // the op semantically reads the grid
+    s.grid_counted = true;
   }
 }
 
@@ -593,7 +601,7 @@ ARCLE_DEV void place(const Wave& w, Scratch& s, const Rec& r, const U4& backgrou
   }
   w.store(ARCLE_PL_GRID, s.grid);
   w.store(ARCLE_PL_SELECTED, selected);
-  s.have_grid = true;
+  s.have_grid = s.grid_counted = true;
   s.sel_written = true;
   ARCLE_ACCT(2 * w.p.P);
 }
@@ -646,7 +654,8 @@ ARCLE_DEV void init_objsel(const Wave& w, Scratch& s, Rec& r, const Sel& sel, Li
   if (sel.any_nz) {  // object.py:67-99
     need_grid<ACCT>(w, s);
     const int h = sel.x1 - sel.x0 + 1, wd = sel.y1 - sel.y0 + 1;
-    const U4 pm = w.expand16(sel.pos);
+    const uint32_t pos = sel_pos(w, sel);
+    const U4 pm = w.expand16(pos);
     // every read of the tile below is masked by a rectangle inside the selection's bbox image, so for a
     // rectangle selection (all cells of the bbox selected) the grid itself can be staged
     w.stage(w.lds->a, sel.is_rect ? s.grid : u4_and(s.grid, pm));
@@ -654,7 +663,7 @@ ARCLE_DEV void init_objsel(const Wave& w, Scratch& s, Rec& r, const Sel& sel, Li
     const uint32_t orect = w.rect16(0, h - 1, 0, wd - 1);
     const U4 ob = w.expand16(orect);
     L.object = u4_and(w.shifted(w.lds->a, S0), ob);
-    L.object_sel = u4_and1(sel.is_rect ? ob : w.expand16(w.shifted_bits(sel.pos, S0) & orect), 0x01010101u);
+    L.object_sel = u4_and1(sel.is_rect ? ob : w.expand16(w.shifted_bits(pos, S0) & orect), 0x01010101u);
     L.background = u4_andn(s.grid, pm);
     r.put2(ARCLE_REC_OBJECT_DIM, h, wd);
     r.put2(ARCLE_REC_OBJECT_POS, sel.x0, sel.y0);
@@ -667,7 +676,7 @@ ARCLE_DEV void init_objsel(const Wave& w, Scratch& s, Rec& r, const Sel& sel, Li
     ARCLE_ACCT(3 * P);
     L.ok = true;
     L.fresh = true;
-    L.osel = sel.pos;  // in the grid frame, consistent with the tile
+    L.osel = pos;  // in the grid frame, consistent with the tile
     L.S0 = S0;
     L.osel_full = sel.is_rect;
     return;
@@ -1007,49 +1016,11 @@ ARCLE_DEV I2 load_cnt(const StepParams& p, int env) {
 // ------------------------------------------------------------------------------------------------
 // one step() of one env:  O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step / RawARCEnv.step
 // ------------------------------------------------------------------------------------------------
-// Descriptor of slot `op`.  For the canonical O2ARCv2Env table (o2arcenv.py:88-113) it is computed in scalar
-// registers instead of fetched (the host selects that instantiation only when the installed table equals it); any
-// other table is a scalar load through the constant cache.
-constexpr uint32_t o2arc_desc_ref(int op) {  // the table O2ARCv2Env.create_operations builds (o2arcenv.py:88-113)
-  const uint32_t R = ARCLE_OPF_RESET_SEL;
-  if (op < 10) return ARCLE_OP_DESC(ARCLE_OP_COLOR, op, R);
-  if (op < 20) return ARCLE_OP_DESC(ARCLE_OP_FLOODFILL, op - 10, R);
-  if (op < 24) return ARCLE_OP_DESC(ARCLE_OP_MOVE, op - 20, 0);
-  if (op < 26) return ARCLE_OP_DESC(ARCLE_OP_ROTATE, 2 * (op - 24) + 1, 0);
-  if (op < 28) return ARCLE_OP_DESC(ARCLE_OP_FLIP, op - 26, 0);
-  if (op < 30) return ARCLE_OP_DESC(ARCLE_OP_COPY, op - 28, R);
-  if (op == 30) return ARCLE_OP_DESC(ARCLE_OP_PASTE, 1, R);
-  if (op == 31) return ARCLE_OP_DESC(ARCLE_OP_COPY_FROM_INPUT, 0, R);
-  if (op == 32) return ARCLE_OP_DESC(ARCLE_OP_RESET_GRID, 0, R);
-  if (op == 33) return ARCLE_OP_DESC(ARCLE_OP_RESIZE_GRID, 0, R);
-  return ARCLE_OP_DESC(ARCLE_OP_SUBMIT, 0, 0);
-}
-// 16 slots per 64-bit word, one nibble each: field 0 = kind, 1 = arg, 2 = flags
-constexpr uint64_t o2arc_nibbles(int first, int field) {
-  uint64_t v = 0;
-  for (int i = 0; i < 16; i++) {
-    const uint32_t d = first + i < 35 ? o2arc_desc_ref(first + i) : 0u;
-    const uint64_t f = field == 0 ? ARCLE_OP_KIND(d) : field == 1 ? ARCLE_OP_ARG(d) : ARCLE_OP_FLAGS(d);
-    v |= (f & 0xfull) << (4 * i);
-  }
-  return v;
-}
-// branch-free register decode of the canonical table (scalar ALU, ~15 instructions, no memory access)
-ARCLE_HD uint32_t o2arc_desc(int op) {
-  constexpr uint64_t K0 = o2arc_nibbles(0, 0), K1 = o2arc_nibbles(16, 0), K2 = o2arc_nibbles(32, 0);
-  constexpr uint64_t A0 = o2arc_nibbles(0, 1), A1 = o2arc_nibbles(16, 1), A2 = o2arc_nibbles(32, 1);
-  constexpr uint64_t F0 = o2arc_nibbles(0, 2), F1 = o2arc_nibbles(16, 2), F2 = o2arc_nibbles(32, 2);
-  const int hi = op >> 4, sh = (op & 15) * 4;
-  const uint64_t k = hi == 0 ? K0 : hi == 1 ? K1 : K2;
-  const uint64_t a = hi == 0 ? A0 : hi == 1 ? A1 : A2;
-  const uint64_t f = hi == 0 ? F0 : hi == 1 ? F1 : F2;
-  return ARCLE_OP_DESC((uint32_t)(k >> sh) & 0xfu, (uint32_t)(a >> sh) & 0xfu, (uint32_t)(f >> sh) & 0xfu);
-}
-template <int TBL>
-ARCLE_DEV uint32_t decode_op(const StepParams& p, int op) {
-  if (TBL == TBL_O2ARC) return o2arc_desc(op);
-  return xl::uload1(p.d_ops + op);
-}
+// Descriptor of slot `op`: one scalar load from the device copy of the op table (35 dwords for O2ARCv2Env, resident in
+// the scalar cache).  (Round 2 measured a branch-free register decode of the canonical table — ~35 scalar instructions, no
+// memory access — at 7.09 us per launch against 6.80 us for the load: instruction issue, not latency, is what a wave of
+// this kernel competes for.)
+ARCLE_DEV uint32_t decode_op(const StepParams& p, int op) { return xl::uload1(p.d_ops + op); }
 
 struct StepOut {
   int reward;      // 0/1
@@ -1063,7 +1034,7 @@ struct StepOut {
 // FEAT: 1 = the instantiation also carries the rarely used step flags (ARCLE_STEP_FEATURE_FLAGS: device-side task
 // re-sampling + augmentation, dense reward, continuation rule, reset_on_submit); the plain instantiations (FEAT = 0) keep
 // them out of the hot kernel's code, registers and SGPR spills
-template <int ING, int FW, int TBL, int ACCT, int FEAT>
+template <int ING, int FW, int ACCT, int FEAT>
 ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, const int op) {
   const StepParams& p = w.p;
   const int P = p.P, W = p.W, lane = w.lane;
@@ -1087,8 +1058,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     }
   }
   bool bad_op = (uint32_t)op >= (uint32_t)p.n_ops;
-  const uint32_t desc = bad_op ? 0u : decode_op<TBL>(p, op);
-  if (TBL != TBL_O2ARC && !bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
+  const uint32_t desc = bad_op ? 0u : decode_op(p, op);
+  if (!bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
     if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
@@ -1097,16 +1068,22 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   }
   const int kind = (int)ARCLE_OP_KIND(desc), arg = (int)ARCLE_OP_ARG(desc);
   const uint32_t oflags = ARCLE_OP_FLAGS(desc);
+#if ARCLE_STOP_AT == 3  // (diagnostic builds, tools/gpu_stagepmc.sh: instruction counts of the step's stages)
+  xl::sink_s(desc);
+  return out;
+#endif
 
   Scratch s;
   s.have_grid = false;
+  s.grid_counted = false;
   s.bytes = 2 * ARCLE_REC_BYTES + 24;  // record R/W + action in + reward/term out
   int submit_inc = 0;
   bool domain_error = false;
   int eq = -1;  // grid == answer, evaluated at most once (Submit and reward see the same state)
 
   Sel sel;
-  ingest_selection(w, sel, payload);
+  if (!ingest_scalar(w, sel, payload) && lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
+  ingest_cells(w, sel, payload);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
   if (FEAT && ING == INGRESS_MASK && (p.flags & ARCLE_STEP_CONTINUE_RULE) &&
       (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
@@ -1124,6 +1101,11 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     }
   }
 
+#if ARCLE_STOP_AT == 4
+  xl::sink_s(sel.x0 + sel.x1 + sel.y0 + sel.y1 + (int)sel.any_nz);
+  xl::sink_v(sel_nz(w, sel));
+  return out;
+#endif
   const Rec r_before = r;
   // reset_sel / keep_sel (object.py:10-41) set `selected` BEFORE the wrapped op runs; an object op that places its
   // object overwrites it afterwards.  The plane is written once, after the op, with whichever value is final — and not at
@@ -1143,7 +1125,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     case ARCLE_OP_COLOR: {  // color.py:70-74 — whole HxW plane, grid_dim ignored
       if (sel.any_nz) {
         need_grid<ACCT>(w, s);
-        s.grid = u4_sel1(w.expand16(sel.nz), ((uint32_t)arg & 0xffu) * 0x01010101u, s.grid);
+        s.grid = u4_sel1(w.expand16(sel_nz(w, sel)), ((uint32_t)arg & 0xffu) * 0x01010101u, s.grid);
         w.store(ARCLE_PL_GRID, s.grid);
         ARCLE_ACCT(P);
       }
@@ -1218,7 +1200,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
         U4 src_sel = u4_zero(), background;
         if (fresh) {  // _init_objsel, object.py:67-99, fused with the transform
           need_grid<ACCT>(w, s);
-          const U4 pm = w.expand16(sel.pos);
+          const U4 pm = w.expand16(sel_pos(w, sel));
           background = u4_andn(s.grid, pm);
           w.store(ARCLE_PL_BACKGROUND, background);
           w.stage(w.lds->a, rect_sel ? s.grid : u4_and(s.grid, pm));
@@ -1285,7 +1267,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       }
       const int h = sel.x1 - sel.x0 + 1, wd = sel.y1 - sel.y0 + 1;
       // where=logical_and(src, sel): for a rectangle selection the destination rectangle already excludes the rest
-      w.stage(w.lds->a, sel.is_rect ? src : u4_and(src, w.expand16(sel.nz)));
+      w.stage(w.lds->a, sel.is_rect ? src : u4_and(src, w.expand16(sel_nz(w, sel))));
       const U4 clip = u4_and(w.shifted(w.lds->a, sel.x0 * W + sel.y0), w.expand16(w.rect16(0, h - 1, 0, wd - 1)));
       w.store(ARCLE_PL_CLIP, clip);
       r.put2(ARCLE_REC_CLIP_DIM, h, wd);
@@ -1311,7 +1293,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     }
     case ARCLE_OP_COPY_FROM_INPUT: {  // critical.py:28-29
       s.grid = w.load(ARCLE_PL_INPUT);
-      s.have_grid = true;
+      s.have_grid = s.grid_counted = true;
       w.store(ARCLE_PL_GRID, s.grid);
       r.w[0] = (r.w[0] & 0xffffu) | (r.w[0] << 16);  // grid_dim = input_dim
       ARCLE_ACCT(2 * P);
@@ -1319,7 +1301,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     }
     case ARCLE_OP_RESET_GRID: {  // critical.py:17
       s.grid = u4_zero();
-      s.have_grid = true;
+      s.have_grid = s.grid_counted = true;
       w.store(ARCLE_PL_GRID, s.grid);
       ARCLE_ACCT(P);
       break;
@@ -1327,7 +1309,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     case ARCLE_OP_RESIZE_GRID: {  // critical.py:39-46
       if (!sel.any_nz) break;
       s.grid = u4_zero();
-      s.have_grid = true;
+      s.have_grid = s.grid_counted = true;
       w.store(ARCLE_PL_GRID, s.grid);
       r.put2(ARCLE_REC_GRID_DIM, sel.x1 - sel.x0 + 1, sel.y1 - sel.y0 + 1);
       ARCLE_ACCT(P);
@@ -1337,7 +1319,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       if (!sel.any_nz) break;
       need_grid<ACCT>(w, s);
       const int h = sel.x1 - sel.x0 + 1, wd = sel.y1 - sel.y0 + 1;
-      w.stage(w.lds->a, sel.is_rect ? s.grid : u4_and(s.grid, w.expand16(sel.nz)));
+      w.stage(w.lds->a, sel.is_rect ? s.grid : u4_and(s.grid, w.expand16(sel_nz(w, sel))));
       s.grid = u4_and(w.shifted(w.lds->a, sel.x0 * W + sel.y0), w.expand16(w.rect16(0, h - 1, 0, wd - 1)));
       w.store(ARCLE_PL_GRID, s.grid);
       r.put2(ARCLE_REC_GRID_DIM, h, wd);
@@ -1365,7 +1347,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
           // what the caller sees is the re-initialised state, and reward() is evaluated on it
           I2 keep = cnt0;
           init_state(w, r, keep);
-          s.have_grid = false;
+          s.have_grid = s.grid_counted = false;
           break;
         }
         eq = grid_equals_answer<ACCT>(w, s, r) ? 1 : 0;
@@ -1378,6 +1360,9 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       break;
   }
 
+#if ARCLE_STOP_AT == 5
+  return out;
+#endif
   if (domain_error) {  // the reference raised inside the op: the step did not happen (nothing was written yet)
     if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
     r = r_before;
@@ -1445,7 +1430,7 @@ ARCLE_DEV StepInputs load_inputs(const Wave& w, int env) {
 // One wave = one env of the launch.  (A grid-stride variant — a wave walking several envs with the next env's scalars
 // prefetched — measured no faster on this access pattern, tools/membench.hip "E=2/4/8 seq", and its loop-invariant
 // code motion costs SGPRs on the single-env path.)
-template <int ING, int FW, int TBL, int ACCT, int FEAT>
+template <int ING, int FW, int ACCT, int FEAT>
 ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0, uint64_t t_lut = 0) {
   const StepParams& p = w.p;
   const int lane = w.lane;
@@ -1463,14 +1448,19 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   cnt0.x = (int32_t)in.cnt[0];
   cnt0.y = (int32_t)in.cnt[1];
   w.set_env(env);
-  const Rec r_in = r;
-  const StepOut out = step_core<ING, FW, TBL, ACCT, FEAT>(w, r, cnt0, in.payload, (int)in.op);
+#if ARCLE_STOP_AT == 2
+  xl::sink_s(r.w[0] + r.w[1] + r.w[2] + r.w[3] + (uint32_t)cnt0.x + (uint32_t)cnt0.y + in.op + in.payload[0] + in.payload[3]);
+  return;
+#endif
+  const StepOut out = step_core<ING, FW, ACCT, FEAT>(w, r, cnt0, in.payload, (int)in.op);
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_core = xl::clock();
 #endif
   // ---- epilogue: record (only when it changed), counters and the step outputs ------------------------
   xl::lanes_converged();  // (emulator: every lane has read the record / counters before lane 0 rewrites them)
-  if (rec_differs(r, r_in)) store_rec(p, env, lane, r);
+  // (the 16 B record is written back unconditionally: comparing it with what was loaded costs 13 scalar instructions per wave,
+  // 6.72 vs 6.85 us per launch)
+  store_rec(p, env, lane, r);
   if (lane == 0) {
     *reinterpret_cast<I2*>(p.cnt + 2 * (size_t)env) = cnt0;
     p.reward[env] = out.reward;
@@ -1499,7 +1489,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
 //   sel: int32 [n_steps][n_envs][4|2] | int8 [n_steps][n_envs][P]   op: int32 [n_steps][n_envs]
 //   reward: int32 [n_steps][n_envs]     term: uint8 [n_steps][n_envs]
 // ------------------------------------------------------------------------------------------------
-template <int ING, int FW, int TBL>
+template <int ING, int FW>
 ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
   Wave w(p, lds, lut, lane, ING, FW, false);
   w.set_env(env);
@@ -1525,7 +1515,7 @@ ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, const U2* lut, in
       next_op = (uint32_t)p.op[((size_t)t + 1) * N + env];
     }
     // (the feature flags a rollout accepts — continuation rule, reset_on_submit — belong to mask-ingress trace replay)
-    const StepOut out = step_core<ING, FW, TBL, 0, ING == INGRESS_MASK ? 1 : 0>(w, r, cnt, payload, op);
+    const StepOut out = step_core<ING, FW, 0, ING == INGRESS_MASK ? 1 : 0>(w, r, cnt, payload, op);
     if (lane == 0) {
       p.reward[(size_t)t * N + env] = out.reward;
       p.term[(size_t)t * N + env] = (uint8_t)out.term;

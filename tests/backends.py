@@ -101,7 +101,7 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("env_base", ctypes.c_int64), ("episode", ctypes.c_void_p), ("cur_task", ctypes.c_void_p),
                 ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p), ("aug_k", ctypes.c_void_p),
                 ("aug_perm", ctypes.c_void_p), ("n_problems", ctypes.c_int32),
-                ("pad_", ctypes.c_int32)]
+                ("wpw", ctypes.c_int32)]
 
 
 _emu = None

@@ -92,6 +92,9 @@ ARCLE_DEV void wg_barrier() { yield(8); }
 ARCLE_DEV void lanes_converged() { yield(9); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 ARCLE_DEV uint32_t opaque(uint32_t v) { return v; }
+#define ARCLE_STOP_AT 0
+ARCLE_DEV void sink_s(uint32_t) {}
+ARCLE_DEV void sink_v(uint32_t) {}
 ARCLE_DEV void arrived(U4&, U2&, uint32_t&, U4&) {}
 ARCLE_DEV void arrived3(U4&, U2&, uint32_t&) {}
 }  // namespace xl
@@ -106,21 +109,15 @@ char* g_stacks;
 const size_t STACK = 256 * 1024;
 
 alignas(16) uint8_t g_row[7 * ARCLE_MAX_CELLS + 32];  // the flatten kernel's LDS row buffer
-int g_tbl;  // arcle::TBL_* of the installed table (emu_run compares it with the canonical decoders)
 
 #define RUN_STEP(I, F)                                                                      \
   do {                                                                                      \
     arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, I, F, false);                      \
     arcle::StepInputs in = arcle::load_inputs<I>(w, g_env);                                 \
-    if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, arcle::TBL_LOOKUP, 0, 1>(w, g_env, in); \
-    else if (g_tbl == arcle::TBL_O2ARC) arcle::wave_step<I, F, arcle::TBL_O2ARC, 1, 0>(w, g_env, in); \
-    else arcle::wave_step<I, F, arcle::TBL_LOOKUP, 1, 0>(w, g_env, in);                     \
+    if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, 0, 1>(w, g_env, in);  \
+    else arcle::wave_step<I, F, 1, 0>(w, g_env, in);                                        \
   } while (0)
-#define RUN_ROLL(I, F)                                                                                          \
-  do {                                                                                                          \
-    if (g_tbl == arcle::TBL_O2ARC) arcle::wave_rollout<I, F, arcle::TBL_O2ARC>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane); \
-    else arcle::wave_rollout<I, F, arcle::TBL_LOOKUP>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);                          \
-  } while (0)
+#define RUN_ROLL(I, F) arcle::wave_rollout<I, F>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane)
 
 // the same width classes the HIP library launches: FW_FULL when 16 <= W <= 32 and the plane stride is 1024
 int width_class() {
@@ -223,13 +220,6 @@ extern "C" int emu_run(int kind, arcle::StepParams* p) {
   if (!g_stacks) g_stacks = (char*)malloc(64 * STACK);
   g_p = p;
   g_kind = kind;
-  // canonical-table detection, the same rule libarcle_hip uses: the table must equal what o2arc_desc computes
-  g_tbl = arcle::TBL_LOOKUP;
-  if (p->d_ops && p->n_ops == 35) {
-    bool same = true;
-    for (int i = 0; same && i < 35; i++) same = arcle::o2arc_desc(i) == p->d_ops[i];
-    if (same) g_tbl = arcle::TBL_O2ARC;
-  }
   xl::error_flag = 0;
   for (int env = 0; env < p->n_envs; env++) {
     g_env = env;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment: the 8192-env batch as G independent groups stepped on G HIP streams (launch overhead and the
-latency chain of one group overlap the other groups' work).  Prints env-steps/s for G = 1, 2, 4."""
+"""Experiment: the env batch as G independent groups stepped on G HIP streams inside ONE hipGraph (fork / join per region), so that
+one group's launch ramp and tail overlap the other groups' work.  Prints env-steps/s for G = 1, 2, 4 at a fixed total batch."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,10 +8,10 @@ import bench
 from arcle_amd import actions
 from arcle_amd.engine import EnvBatch
 from arcle_amd.envs import O2ARCv2Env
-dev = torch.device("cuda:0"); N = 8192; K = 400
-for G in (1, 2, 4, 1, 2, 4):
+dev = torch.device("cuda:0"); N = int(os.environ.get("N", 8192)); K = 400
+for G in (1, 2, 4, 8, 1, 2, 4, 8):
     n = N // G
-    streams = [torch.cuda.Stream(dev) for _ in range(G)]
+    side = [torch.cuda.Stream(dev) for _ in range(G)]
     batches, bb, oo = [], [], []
     for g in range(G):
         b = EnvBatch(n, 30, 30, -1, "o2arc", dev)
@@ -20,12 +20,22 @@ for G in (1, 2, 4, 1, 2, 4):
         bn, on = bench.make_actions(K, n, 7 + g)
         batches.append(b); bb.append(torch.from_numpy(bn).to(dev)); oo.append(torch.from_numpy(on).to(dev))
     torch.cuda.synchronize()
-    ptrs = [[(bb[g][i].data_ptr(), oo[g][i].data_ptr()) for i in range(K)] for g in range(G)]
-    sh = [s.cuda_stream for s in streams]
-    for rep in range(2):
+    graph = torch.cuda.CUDAGraph()
+    main = torch.cuda.Stream(dev)
+    with torch.cuda.graph(graph, stream=main):
+        fork = torch.cuda.Event(); fork.record(main)
+        for g in range(G):
+            side[g].wait_event(fork)
+            sh = side[g].cuda_stream
+            for i in range(K):
+                batches[g].step_bbox_ptr(bb[g][i].data_ptr(), oo[g][i].data_ptr(), 0, sh)
+            e = torch.cuda.Event(); e.record(side[g]); main.wait_event(e)
+    for _ in range(30): graph.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for rep in range(7):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for i in range(K):
-            for g in range(G):
-                batches[g].step_bbox_ptr(ptrs[g][i][0], ptrs[g][i][1], 0, sh[g])
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        graph.replay()
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
     print(f"groups={G} envs/group={n}: {N*K/dt/1e6:8.1f} M env-steps/s  ({dt/K*1e6:.2f} us per step of {N} envs)", flush=True)
