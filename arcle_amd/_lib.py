@@ -42,7 +42,10 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise ArcleHipError("hipcc not found: cannot build libarcle_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH, SOURCES[0]]
+    # -amdgpu-kernarg-preload-count: the step kernel's leading scalar arguments (the four per-env array bases, batch size, launch
+    # shape) are in SGPRs when a wave starts instead of behind a scalar load of the argument block
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-kernarg-preload-count=11",
+           "-o", LIB_PATH, SOURCES[0]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

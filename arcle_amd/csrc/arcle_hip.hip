@@ -122,25 +122,28 @@ typedef arcle::BlockLDS<WAVES_PER_WG> BlockLDS;
 // vb = (b&7)*(nb/8) + (b>>3) gives each XCD one contiguous range of waves (affinity only)
 // (waves_per_wg comes from the caller, not from blockDim: the workgroup size sits in the hidden kernel arguments as a 16-bit
 // field, which costs a VECTOR load and its latency before the wave can even compute which env it owns)
-__device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG) {
-  const uint32_t nb = gridDim.x, b = blockIdx.x;  // nb is a multiple of 8
-  const uint32_t vb = (b & 7u) * (nb >> 3) + (b >> 3);
+__device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, uint32_t nb8 = gridDim.x >> 3) {
+  const uint32_t b = blockIdx.x;  // the grid is a multiple of 8 workgroups; nb8 = gridDim.x / 8
+  const uint32_t vb = (b & 7u) * nb8 + (b >> 3);
   return __builtin_amdgcn_readfirstlane((int)(vb * (uint32_t)waves_per_wg + (threadIdx.x >> 6)));
 }
 
 // ING: selection ingress form; FW: arcle::FW_* grid-width class;
 // ACCT: 1 = add the step's algorithmic bytes to p.acct[env]; FEAT: 1 = carries the ARCLE_STEP_FEATURE_FLAGS code
 template <int ING, int FW, int ACCT, int FEAT>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(const StepParams p) {
+__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(
+    const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel, int n_envs, int wpw, uint32_t nb8, const StepParams p) {
+  // (leading scalar arguments = what a wave needs to find and request its env's inputs; built with -amdgpu-kernarg-preload-count they
+  // are in SGPRs at wave start.  They repeat p.rec / p.cnt / p.op / p.sel / p.n_envs / p.wpw.)
   __shared__ BlockLDS lds;
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_entry = xl::clock();
 #endif
-  const int wv = wave_of_launch(p.wpw);
-  const bool valid = wv < p.n_envs;  // (every wave of the workgroup reaches the barrier below)
+  const int wv = wave_of_launch(wpw, nb8);
+  const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = valid ? wv : 0;
   arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false);
-  arcle::StepInputs in = arcle::load_inputs<ING>(w, env);  // in flight while the expansion table is built
+  arcle::StepInputs in = arcle::load_inputs<ING>(w, env, rec, cnt, op, sel);  // in flight while the expansion table is built
   arcle::lut_init(lds.lut, (int)threadIdx.x);
   xl::wg_barrier();
   if (!valid) return;
@@ -450,16 +453,16 @@ static int width_class(const StepParams& p) {
 template <int ING>
 static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || feat) return ARCLE_ERR_CONFIG;
-  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 0>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0>), g, b, 0, st, p);
+  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
   return ARCLE_OK;
 }
 #else
 template <int ING, int FW>
 static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, p);  // (the feature instantiation has no accounting)
-  else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, p);
+  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);  // (the feature instantiation has no accounting)
+  else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
+  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
 }
 template <int ING>
 static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {

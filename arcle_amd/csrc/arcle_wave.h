@@ -417,19 +417,20 @@ ARCLE_DEV U4 sel_values(const Wave& w, const Sel& s) {
 
 // The selection payload of this env.  bbox = 4 ints, point = 2 ints: wave-uniform scalar loads; mask = this lane's
 // 16 cells of the contiguous int8 [N][P] array the caller holds (no 16 B alignment guarantee).
-ARCLE_DEV U4 load_payload(const Wave& w, int env, size_t step = 0) {  // step: rollout kernels index [step][env]
+ARCLE_DEV U4 load_payload(const Wave& w, int env, size_t step = 0, const void* sel_arg = nullptr) {  // step: rollout kernels index [step][env]
   const StepParams& p = w.p;
+  const void* sel = sel_arg ? sel_arg : p.sel;
   U4 v = u4_zero();
   const size_t e = step * (size_t)p.n_envs + (size_t)env;
   if (w.ingress == INGRESS_BBOX) {
-    v = xl::uload4(reinterpret_cast<const int32_t*>(p.sel) + 4 * e);
+    v = xl::uload4(reinterpret_cast<const int32_t*>(sel) + 4 * e);
   } else if (w.ingress == INGRESS_POINT) {
-    const U2 b = xl::uload2(reinterpret_cast<const int32_t*>(p.sel) + 2 * e);
+    const U2 b = xl::uload2(reinterpret_cast<const int32_t*>(sel) + 2 * e);
     v[0] = b[0];
     v[1] = b[1];
   } else {
-    const int8_t* src = reinterpret_cast<const int8_t*>(p.sel) + e * (size_t)p.P + 16 * w.lane;
-    if ((p.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.sel) & 3) == 0)) {
+    const int8_t* src = reinterpret_cast<const int8_t*>(sel) + e * (size_t)p.P + 16 * w.lane;
+    if ((p.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(sel) & 3) == 0)) {
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (16 * w.lane + 4 * i < p.P) v[i] = *reinterpret_cast<const uint32_t*>(src + 4 * i);
@@ -1051,7 +1052,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       const bool resample = FEAT && (p.flags & ARCLE_STEP_RESAMPLE);
       if (resample) ok = load_sampled_task(w, r, w.env, in);
       if (ok) init_state(w, r, cnt0, resample ? &in : nullptr);
-      else if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+      else xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
       out.term = 0;
       out.bytes = (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
       return out;
@@ -1062,7 +1063,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   if (!bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
-    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
+    xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
     out.term = r.term() != 0;
     return out;
   }
@@ -1082,7 +1083,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   int eq = -1;  // grid == answer, evaluated at most once (Submit and reward see the same state)
 
   Sel sel;
-  if (!ingest_scalar(w, sel, payload) && lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
+  if (!ingest_scalar(w, sel, payload)) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
   ingest_cells(w, sel, payload);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
   if (FEAT && ING == INGRESS_MASK && (p.flags & ARCLE_STEP_CONTINUE_RULE) &&
@@ -1106,7 +1107,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   xl::sink_v(sel_nz(w, sel));
   return out;
 #endif
-  const Rec r_before = r;
+  const uint32_t w3_before = r.w[3];  // (only reset_sel below touches the record before an op can turn out to be out of its domain)
   // reset_sel / keep_sel (object.py:10-41) set `selected` BEFORE the wrapped op runs; an object op that places its
   // object overwrites it afterwards.  The plane is written once, after the op, with whichever value is final — and not at
   // all when the op turns out to be out of its domain (the step is skipped).
@@ -1364,8 +1365,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   return out;
 #endif
   if (domain_error) {  // the reference raised inside the op: the step did not happen (nothing was written yet)
-    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
-    r = r_before;
+    xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+    r.w[3] = w3_before;
     out.term = r.term() != 0;
     return out;
   }
@@ -1416,15 +1417,20 @@ struct StepInputs {
   uint32_t op;
   U4 payload;
 };
+// (the four array bases arrive as separate kernel arguments: the first dwords of the argument segment are preloaded into SGPRs
+// when the wave is created, so these loads do not wait for a fetch of the argument block)
+template <int ING>
+ARCLE_DEV StepInputs load_inputs(const Wave& w, int env, const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel) {
+  StepInputs in;
+  in.rec = xl::uload4(rec + (size_t)env * ARCLE_REC_BYTES);
+  in.op = xl::uload1(op + env);
+  in.cnt = xl::uload2(cnt + 2 * (size_t)env);
+  in.payload = load_payload(w, env, 0, sel);
+  return in;
+}
 template <int ING>
 ARCLE_DEV StepInputs load_inputs(const Wave& w, int env) {
-  const StepParams& p = w.p;
-  StepInputs in;
-  in.rec = xl::uload4(p.rec + (size_t)env * ARCLE_REC_BYTES);
-  in.op = xl::uload1(p.op + env);
-  in.cnt = xl::uload2(p.cnt + 2 * (size_t)env);
-  in.payload = load_payload(w, env);
-  return in;
+  return load_inputs<ING>(w, env, w.p.rec, w.p.cnt, w.p.op, w.p.sel);
 }
 
 // One wave = one env of the launch.  (A grid-stride variant — a wave walking several envs with the next env's scalars
@@ -1458,10 +1464,15 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
 #endif
   // ---- epilogue: record (only when it changed), counters and the step outputs ------------------------
   xl::lanes_converged();  // (emulator: every lane has read the record / counters before lane 0 rewrites them)
-  // (the 16 B record is written back unconditionally: comparing it with what was loaded costs 13 scalar instructions per wave,
-  // 6.72 vs 6.85 us per launch)
-  store_rec(p, env, lane, r);
   if (lane == 0) {
+    // (the 16 B record is written back unconditionally: comparing it with what was loaded costs 13 scalar instructions per wave,
+    // 6.72 vs 6.85 us per launch)
+    U4 rv;
+    rv[0] = r.w[0];
+    rv[1] = r.w[1];
+    rv[2] = r.w[2];
+    rv[3] = r.w[3];
+    *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rv;
     *reinterpret_cast<I2*>(p.cnt + 2 * (size_t)env) = cnt0;
     p.reward[env] = out.reward;
     p.term[env] = (uint8_t)out.term;
@@ -1557,7 +1568,7 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
   if (p.task_idx) {
     const int t = (int)xl::uniform((uint32_t)p.task_idx[env]);
     if (t < 0 || t >= p.n_tasks) {
-      if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_BAD_TASK);
+      xl::atomic_or(p.status, ARCLE_ST_BAD_TASK);
       return;
     }
     int k = 0;
@@ -1573,7 +1584,7 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
     ok = load_sampled_task(w, r, env, in);
   }
   if (!ok) {
-    if (lane == 0) xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+    xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
     return;
   }
   I2 cnt;
