@@ -146,6 +146,17 @@ ARCLE_DEV U4 posbytes(const U4& v) {
   }
   return r;
 }
+// base + unsigned 32-bit byte offset: scalar loads take the offset in an SGPR, vector accesses as the 32-bit VGPR offset of the
+// saddr form — no 64-bit address arithmetic per access
+template <typename T>
+ARCLE_DEV const T* at(const T* base, uint32_t byte_off) {
+  return reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+template <typename T>
+ARCLE_DEV T* at(T* base, uint32_t byte_off) {
+  return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(base) + byte_off);
+}
+
 ARCLE_DEV U4 u4_zero() {
   U4 r;
   r[0] = r[1] = r[2] = r[3] = 0;
@@ -417,9 +428,8 @@ ARCLE_DEV U4 sel_values(const Wave& w, const Sel& s) {
 
 // The selection payload of this env.  bbox = 4 ints, point = 2 ints: wave-uniform scalar loads; mask = this lane's
 // 16 cells of the contiguous int8 [N][P] array the caller holds (no 16 B alignment guarantee).
-ARCLE_DEV U4 load_payload(const Wave& w, int env, size_t step = 0, const void* sel_arg = nullptr) {  // step: rollout kernels index [step][env]
+ARCLE_DEV U4 load_payload(const Wave& w, int env, size_t step, const void* sel) {  // step: rollout kernels index [step][env]
   const StepParams& p = w.p;
-  const void* sel = sel_arg ? sel_arg : p.sel;
   U4 v = u4_zero();
   const size_t e = step * (size_t)p.n_envs + (size_t)env;
   if (w.ingress == INGRESS_BBOX) {
@@ -455,7 +465,7 @@ ARCLE_DEV U4 load_payload_v(const Wave& w, int env, size_t step) {
     v[0] = b[0];
     v[1] = b[1];
   } else {
-    v = load_payload(w, env, step);
+    v = load_payload(w, env, step, p.sel);
   }
   return v;
 }
@@ -1021,7 +1031,7 @@ ARCLE_DEV I2 load_cnt(const StepParams& p, int env) {
 // the scalar cache).  (Round 2 measured a branch-free register decode of the canonical table — ~35 scalar instructions, no
 // memory access — at 7.09 us per launch against 6.80 us for the load: instruction issue, not latency, is what a wave of
 // this kernel competes for.)
-ARCLE_DEV uint32_t decode_op(const StepParams& p, int op) { return xl::uload1(p.d_ops + op); }
+ARCLE_DEV uint32_t decode_op(const StepParams& p, int op) { return xl::uload1(at(p.d_ops, (uint32_t)op * 4u)); }
 
 struct StepOut {
   int reward;      // 0/1
@@ -1422,10 +1432,21 @@ struct StepInputs {
 template <int ING>
 ARCLE_DEV StepInputs load_inputs(const Wave& w, int env, const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel) {
   StepInputs in;
-  in.rec = xl::uload4(rec + (size_t)env * ARCLE_REC_BYTES);
-  in.op = xl::uload1(op + env);
-  in.cnt = xl::uload2(cnt + 2 * (size_t)env);
-  in.payload = load_payload(w, env, 0, sel);
+  // 32-bit unsigned byte offsets: the scalar loads take them as an SGPR offset (no 64-bit address arithmetic per array)
+  const uint32_t e = (uint32_t)env;
+  in.rec = xl::uload4(at(rec, e * (uint32_t)ARCLE_REC_BYTES));
+  in.op = xl::uload1(at(op, e * 4u));
+  in.cnt = xl::uload2(at(cnt, e * 8u));
+  if (ING == INGRESS_BBOX) {
+    in.payload = xl::uload4(at(sel, e * 16u));
+  } else if (ING == INGRESS_POINT) {
+    const U2 b = xl::uload2(at(sel, e * 8u));
+    in.payload = u4_zero();
+    in.payload[0] = b[0];
+    in.payload[1] = b[1];
+  } else {
+    in.payload = load_payload(w, env, 0, sel);
+  }
   return in;
 }
 template <int ING>
@@ -1472,11 +1493,12 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
     rv[1] = r.w[1];
     rv[2] = r.w[2];
     rv[3] = r.w[3];
-    *reinterpret_cast<U4*>(p.rec + (size_t)env * ARCLE_REC_BYTES) = rv;
-    *reinterpret_cast<I2*>(p.cnt + 2 * (size_t)env) = cnt0;
-    p.reward[env] = out.reward;
-    p.term[env] = (uint8_t)out.term;
-    if (p.flags & ARCLE_STEP_TRUNCATE) p.trunc[env] = (uint8_t)(cnt0.x >= p.step_limit);
+    const uint32_t e = (uint32_t)env;
+    *reinterpret_cast<U4*>(at(p.rec, e * (uint32_t)ARCLE_REC_BYTES)) = rv;
+    *reinterpret_cast<I2*>(at(p.cnt, e * 8u)) = cnt0;
+    *at(p.reward, e * 4u) = out.reward;
+    *at(p.term, e) = (uint8_t)out.term;
+    if (p.flags & ARCLE_STEP_TRUNCATE) *at(p.trunc, e) = (uint8_t)(cnt0.x >= p.step_limit);
 #ifdef ARCLE_TRACE_WAVES
     if (ACCT) {
       uint64_t* tr = reinterpret_cast<uint64_t*>(p.acct) + 8 * (size_t)env;
