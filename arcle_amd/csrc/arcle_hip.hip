@@ -130,7 +130,7 @@ __device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, u
 
 // ING: selection ingress form; FW: arcle::FW_* grid-width class;
 // ACCT: 1 = add the step's algorithmic bytes to p.acct[env]; FEAT: 1 = carries the ARCLE_STEP_FEATURE_FLAGS code
-template <int ING, int FW, int ACCT, int FEAT>
+template <int ING, int FW, int ACCT, int FEAT, int FL = -1>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(
     const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel, int n_envs, int wpw, uint32_t nb8, const StepParams p) {
   // (leading scalar arguments = what a wave needs to find and request its env's inputs; built with -amdgpu-kernarg-preload-count they
@@ -151,9 +151,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   return;
 #endif
 #ifdef ARCLE_TRACE_WAVES
-  arcle::wave_step<ING, FW, ACCT, FEAT>(w, env, in, t_entry, xl::clock());
+  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in, t_entry, xl::clock());
 #else
-  arcle::wave_step<ING, FW, ACCT, FEAT>(w, env, in);
+  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in);
 #endif
 }
 
@@ -326,8 +326,8 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
     }
   }
   if (hipMalloc((void**)&e->d_status, 8) != hipSuccess || hipMemset(e->d_status, 0, 8) != hipSuccess ||
-      hipMalloc((void**)&e->d_ops, sizeof(uint32_t) * ARCLE_MAX_OPS) != hipSuccess ||
-      hipMemset(e->d_ops, 0, sizeof(uint32_t) * ARCLE_MAX_OPS) != hipSuccess) {
+      hipMalloc((void**)&e->d_ops, sizeof(uint32_t) * (ARCLE_MAX_OPS + 1)) != hipSuccess ||  // (+1: slot n_ops is always an empty one)
+      hipMemset(e->d_ops, 0, sizeof(uint32_t) * (ARCLE_MAX_OPS + 1)) != hipSuccess) {
     arcle_destroy(e);
     return ARCLE_ERR_HIP;
   }
@@ -449,20 +449,28 @@ static int width_class(const StepParams& p) {
   if (p.W < 16 || p.W > 32) return arcle::FW_GENERIC;
   return p.PS == ARCLE_MAX_CELLS ? arcle::FW_FULL : arcle::FW_FAST;
 }
+#define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p
+// the flag combination ARCVecEnv steps with (next-step autoreset, elided zero-fill of `selected`) has its own instantiation
+// with the flags as a compile-time constant
+static constexpr int HOT_FLAGS = ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED;
 #ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiation exists (seconds instead of a minute)
 template <int ING>
 static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || feat) return ARCLE_ERR_CONFIG;
-  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
+  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 0>), g, b, 0, st, STEP_ARGS);
+#ifndef ARCLE_NO_HOT_FLAGS
+  else if (p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
+#endif
+  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0>), g, b, 0, st, STEP_ARGS);
   return ARCLE_OK;
 }
 #else
 template <int ING, int FW>
 static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);  // (the feature instantiation has no accounting)
-  else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
-  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
+  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, STEP_ARGS);  // (the feature instantiation has no accounting)
+  else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, STEP_ARGS);
+  else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
+  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, STEP_ARGS);
 }
 template <int ING>
 static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {

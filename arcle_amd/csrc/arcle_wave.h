@@ -60,7 +60,7 @@ struct StepParams {
   int32_t step_limit;  // ARCLE_STEP_TRUNCATE: truncated = action_steps >= step_limit (TimeLimit, agents/train.py:67)
   uint32_t* status;
   uint32_t* acct;         // optional per-env algorithmic-byte accumulator (ACCT instantiations)
-  const uint32_t* d_ops;  // device copy of the op table, ARCLE_MAX_OPS entries (unused slots 0)
+  const uint32_t* d_ops;  // device copy of the op table, ARCLE_MAX_OPS + 1 entries (unused slots 0; slot n_ops is always one)
   uint8_t* trunc;         // optional truncated output (ARCLE_STEP_TRUNCATE)
   int32_t* dense;         // optional int32 [N][2] = (correct cells, total cells) of the dense reward (ARCLE_STEP_DENSE)
   int8_t* flat_out;       // optional flattened observation rows (ARCLE_STEP_FLAT_OBS / flatten kernel)
@@ -1045,21 +1045,24 @@ struct StepOut {
 // FEAT: 1 = the instantiation also carries the rarely used step flags (ARCLE_STEP_FEATURE_FLAGS: device-side task
 // re-sampling + augmentation, dense reward, continuation rule, reset_on_submit); the plain instantiations (FEAT = 0) keep
 // them out of the hot kernel's code, registers and SGPR spills
-template <int ING, int FW, int ACCT, int FEAT>
+template <int ING, int FW, int ACCT, int FEAT, int FL = -1>
 ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, const int op) {
   const StepParams& p = w.p;
   const int P = p.P, W = p.W, lane = w.lane;
   StepOut out;
   out.reward = 0;
   out.bytes = 0;
-  if (p.flags & (ARCLE_STEP_AUTORESET | (FEAT ? ARCLE_STEP_RESAMPLE : 0u))) {
+  // FL >= 0: the launch's step flags are this compile-time constant (the launcher picks the instantiation for the common
+  // combination), so the flag tests below fold away
+  const uint32_t flags = FL >= 0 ? (uint32_t)FL : p.flags;
+  if (flags & (ARCLE_STEP_AUTORESET | (FEAT ? ARCLE_STEP_RESAMPLE : 0u))) {
     // next-step autoreset: an env whose episode ended (terminated, or — with ARCLE_STEP_TRUNCATE — out of steps) is
     // re-initialised instead of executing the action; ARCLE_STEP_RESAMPLE first draws a new task on the device
-    const bool ended = r.term() != 0 || ((p.flags & ARCLE_STEP_TRUNCATE) && cnt0.x >= p.step_limit);
+    const bool ended = r.term() != 0 || ((flags & ARCLE_STEP_TRUNCATE) && cnt0.x >= p.step_limit);
     if (ended) {
       bool ok = true;
       U4 in = u4_zero();
-      const bool resample = FEAT && (p.flags & ARCLE_STEP_RESAMPLE);
+      const bool resample = FEAT && (flags & ARCLE_STEP_RESAMPLE);
       if (resample) ok = load_sampled_task(w, r, w.env, in);
       if (ok) init_state(w, r, cnt0, resample ? &in : nullptr);
       else xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
@@ -1068,9 +1071,10 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       return out;
     }
   }
-  bool bad_op = (uint32_t)op >= (uint32_t)p.n_ops;
-  const uint32_t desc = bad_op ? 0u : decode_op(p, op);
-  if (!bad_op) bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
+  // an index past the table reads slot n_ops, which is always empty (the table copy has one more slot than ARCLE_MAX_OPS)
+  const uint32_t slot = (uint32_t)op < (uint32_t)p.n_ops ? (uint32_t)op : (uint32_t)p.n_ops;
+  const uint32_t desc = decode_op(p, (int)slot);
+  const bool bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
     xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
@@ -1096,7 +1100,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   if (!ingest_scalar(w, sel, payload)) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
   ingest_cells(w, sel, payload);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
-  if (FEAT && ING == INGRESS_MASK && (p.flags & ARCLE_STEP_CONTINUE_RULE) &&
+  if (FEAT && ING == INGRESS_MASK && (flags & ARCLE_STEP_CONTINUE_RULE) &&
       (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
     // the O2ARC trace harness (tests/o2arc_check.py:169-170): an object op whose logged selection equals the env's
     // current `selected` plane continues the active object, i.e. is sent with an empty selection
@@ -1125,7 +1129,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   if (oflags & ARCLE_OPF_RESET_SEL) {  // object.py:20-25
     // with ARCLE_STEP_ELIDE_SELECTED an env that enters the step inactive is known to hold an all-zero `selected`
     // plane already (see include/arcle_hip.h): the zero-fill would rewrite zeros with zeros
-    zero_selected = !((p.flags & ARCLE_STEP_ELIDE_SELECTED) && r.active() == 0);
+    zero_selected = !((flags & ARCLE_STEP_ELIDE_SELECTED) && r.active() == 0);
     ARCLE_ACCT(P);  // semantic accounting is unchanged
     r.put(ARCLE_REC_ACTIVE, 0);
   }
@@ -1352,7 +1356,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
         trials = i8w(trials - 1);  // :174 int8 wrap
         r.put(ARCLE_REC_TRIALS, trials);
         submit_inc = 1;
-        if (FEAT && (p.flags & ARCLE_STEP_RESET_ON_SUBMIT)) {
+        if (FEAT && (flags & ARCLE_STEP_RESET_ON_SUBMIT)) {
           // base.py:179-180: init_state() rebinds current_state inside submit — the decrement, the `terminated` of a
           // correct answer and the trials-exhausted check below all land on the discarded dict;
           // what the caller sees is the re-initialised state, and reward() is evaluated on it
@@ -1391,7 +1395,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     if (eq < 0) eq = grid_equals_answer<ACCT>(w, s, r) ? 1 : 0;
     reward = eq;
   }
-  if (FEAT && (p.flags & ARCLE_STEP_DENSE)) {
+  if (FEAT && (flags & ARCLE_STEP_DENSE)) {
     // the research env's dense reward (agents/env.py:44-58) as an exact integer pair (correct cells, total cells);
     // the host forms  sparse*100 - 1 + correct/total
     need_grid<ACCT>(w, s);
@@ -1457,7 +1461,7 @@ ARCLE_DEV StepInputs load_inputs(const Wave& w, int env) {
 // One wave = one env of the launch.  (A grid-stride variant — a wave walking several envs with the next env's scalars
 // prefetched — measured no faster on this access pattern, tools/membench.hip "E=2/4/8 seq", and its loop-invariant
 // code motion costs SGPRs on the single-env path.)
-template <int ING, int FW, int ACCT, int FEAT>
+template <int ING, int FW, int ACCT, int FEAT, int FL = -1>
 ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0, uint64_t t_lut = 0) {
   const StepParams& p = w.p;
   const int lane = w.lane;
@@ -1479,7 +1483,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   xl::sink_s(r.w[0] + r.w[1] + r.w[2] + r.w[3] + (uint32_t)cnt0.x + (uint32_t)cnt0.y + in.op + in.payload[0] + in.payload[3]);
   return;
 #endif
-  const StepOut out = step_core<ING, FW, ACCT, FEAT>(w, r, cnt0, in.payload, (int)in.op);
+  const StepOut out = step_core<ING, FW, ACCT, FEAT, FL>(w, r, cnt0, in.payload, (int)in.op);
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_core = xl::clock();
 #endif
@@ -1498,7 +1502,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
     *reinterpret_cast<I2*>(at(p.cnt, e * 8u)) = cnt0;
     *at(p.reward, e * 4u) = out.reward;
     *at(p.term, e) = (uint8_t)out.term;
-    if (p.flags & ARCLE_STEP_TRUNCATE) *at(p.trunc, e) = (uint8_t)(cnt0.x >= p.step_limit);
+    if ((FL >= 0 ? (uint32_t)FL : p.flags) & ARCLE_STEP_TRUNCATE) *at(p.trunc, e) = (uint8_t)(cnt0.x >= p.step_limit);
 #ifdef ARCLE_TRACE_WAVES
     if (ACCT) {
       uint64_t* tr = reinterpret_cast<uint64_t*>(p.acct) + 8 * (size_t)env;

@@ -150,7 +150,7 @@ class EmuBackend:
         p.status, p.acct = self.stat.ctypes.data, self.acct.ctypes.data
         p.n_envs, p.H, p.W, p.max_trial, p.n_ops = self.N, self.H, self.W, self.max_trial, len(self.ops)
         p.PS = self.PS
-        self._ops_arr = np.zeros(64, np.uint32)  # the "device" op table
+        self._ops_arr = np.zeros(65, np.uint32)  # the "device" op table (ARCLE_MAX_OPS + 1 slots)
         self._ops_arr[:len(self.ops)] = self.ops
         p.d_ops = self._ops_arr.ctypes.data
         return p
