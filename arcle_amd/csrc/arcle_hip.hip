@@ -223,6 +223,7 @@ struct arcle_env {
   StepParams base;
   uint32_t* d_status;
   uint32_t* d_ops;
+  uint64_t acct_extra = 0;  // algorithmic bytes of launches without a per-env counter (flattened observation rows)
   uint32_t ops_host[ARCLE_MAX_OPS];
   int8_t* flat_out;  // ARCLE_STEP_FLAT_OBS destination (arcle_set_flat_output)
   int32_t flat_stride;
@@ -674,6 +675,8 @@ static int launch_flatten(arcle_env* e, int8_t* out, int32_t out_stride, int fil
   p.flat_filter = filtered ? 1 : 0;
   hipLaunchKernelGGL(arcle_flatten_kernel, dim3((unsigned)((p.n_envs + FLAT_WAVES - 1) / FLAT_WAVES)), dim3(64 * FLAT_WAVES), 0, st, p);
   HIP_TRY(e, hipGetLastError());
+  // a row reads its planes + the record once and is written once (SURVEY.md 8d accounting of the observation writer)
+  if (e->d_acct) e->acct_extra += (uint64_t)p.n_envs * (uint64_t)(2 * len + ARCLE_REC_BYTES);
   return ARCLE_OK;
 }
 
@@ -772,8 +775,8 @@ extern "C" int arcle_get_accounting(arcle_env* e, uint64_t* bytes, uint64_t* ste
   uint64_t tot = 0;
   for (size_t i = 0; i < n; i++) tot += h[i];
   free(h);
-  *bytes = tot;
+  *bytes = tot + e->acct_extra;
   *steps = e->acct_steps;
-  if (clear) e->acct_steps = 0;
+  if (clear) e->acct_steps = 0, e->acct_extra = 0;
   return ARCLE_OK;
 }

@@ -19,7 +19,9 @@ prints ONE JSON line.  Workloads (`config.workload` names the on
 
 Timing: after an untimed clock ramp and W warm-up steps, the region "barrier + synchronize, exactly K steps, synchronize
 + barrier" is run R times (R reported as `timing.regions`); `value`/`ms_per_step` are the MEDIAN region (max over
-ranks per region).  Besides the contract fields the line carries
+ranks per region).  A region that is one hipGraph replay is clocked by HIP events recorded on the launch stream between the two
+synchronisations (device time of exactly the K steps; the host-clock figure of the same regions is `timing.host_region_ms`);
+eagerly launched regions (multi-rank c4) are clocked by the host.  Besides the contract fields the line carries
   roofline      achieved ALGORITHMIC HBM bytes/s of the step kernel: bytes from the kernel's own per-env accounting
                 (planes semantically read+written by the executed op/mode + 56 B) divided by the kernel's
                 average launch duration, measured with a HIP-event pair recorded on the launch stream around the K
@@ -421,7 +423,12 @@ def main():
     torch.cuda.synchronize(dev)
 
     # ---- R timed regions of exactly K steps, each bracketed by barrier + synchronize ---------------------------
-    wall, kern = [], []
+    # Clock of a region: the HIP events recorded on the launch stream right inside the two synchronisations when the region
+    # is ONE hipGraph replay (device time of exactly the K steps), the host clock otherwise.  The host figure additionally
+    # holds one graph-launch submission and one wake-up (~20 us per region, i.e. 17 % of a 20-step region and 1 % of a
+    # 400-step one) — it is reported beside it (timing.host_region_ms), never instead of work.
+    device_clock = graph is not None
+    wall, kern, devt = [], [], []
     for r in range(R):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
@@ -433,8 +440,10 @@ def main():
         wait_gpu(ev1)
         barrier()
         wall.append(time.perf_counter() - t0)
-        kern.append(ev0.elapsed_time(ev1) * 1e-3 / K)
-    wall_t = torch.tensor(wall, dtype=torch.float64)
+        devt.append(ev0.elapsed_time(ev1) * 1e-3)
+        kern.append(devt[-1] / K)
+    host_ms = [round(x * 1e3, 4) for x in wall][:12]
+    wall_t = torch.tensor(devt if device_clock else wall, dtype=torch.float64)
     if dist is not None:  # max over ranks, per region
         wt = wall_t if shared_gpu else wall_t.to(dev)
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
@@ -496,6 +505,8 @@ def main():
                        else (f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL'})"
                              if dist is not None else "one rank: step + packing launch per step, nothing to gather")},
             "timing": {"regions": R, "stat": "median region, max over ranks per region",
+                       "clock": "HIP events on the launch stream, recorded between the region's two synchronisations" if device_clock else "host perf_counter between the region's two synchronisations",
+                       "host_region_ms": host_ms,
                        "launch": "hipGraph of the K step launches, one replay per region" if graph is not None else "eager",
                        "region_ms": [round(float(x) * 1e3, 4) for x in wall_t.tolist()][:12]},
             "roofline": roofline,

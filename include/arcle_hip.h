@@ -294,7 +294,8 @@ int arcle_pack_obs(arcle_env* env, const int32_t* reward, const uint8_t* term, u
  * launch of this handle in flight — arcle_set_op_table synchronises the device itself.) */
 int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);
 
-/* Algorithmic HBM bytes (SURVEY.md §8d accounting) moved by all step launches since the
+/* Algorithmic HBM bytes (SURVEY.md §8d accounting) moved by all step launches (and the observation rows written by
+ * arcle_flatten_obs / ARCLE_STEP_FLAT_OBS: planes + record read once, row written once) since the
  * last call with clear != 0; accumulated on device by the step kernel only when the handle
  * was created with accounting enabled via arcle_enable_accounting(env, 1). */
 int arcle_enable_accounting(arcle_env* env, int on);

@@ -267,3 +267,19 @@ def test_device_cuda_means_the_current_device():
         assert b.status() == 0 and torch.cuda.current_device() == 1
     finally:
         torch.cuda.set_device(prev)
+
+
+def test_flat_rows_are_in_the_byte_accounting():
+    """The observation writer's bytes (planes + record read once, row written once) are added to arcle_get_accounting."""
+    from arcle_amd.engine import EnvBatch
+    N, H, W = 48, 30, 30
+    b = EnvBatch(N, H, W, 3, "o2arc", "cuda")
+    b.set_op_table(O.o2arc_ops())
+    b.enable_accounting(True)
+    b.reset()
+    b.accounting(clear=True)
+    for filtered, length in ((False, 7 * H * W + 14), (True, 3 * H * W + 10)):
+        assert b.flat_obs_size(filtered) == length
+        b.flat_obs(filtered=filtered)
+        got, steps = b.accounting(clear=True)
+        assert got == N * (2 * length + 16) and steps == 0
