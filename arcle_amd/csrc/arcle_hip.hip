@@ -130,9 +130,19 @@ __device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, u
 
 // ING: selection ingress form; FW: arcle::FW_* grid-width class;
 // ACCT: 1 = add the step's algorithmic bytes to p.acct[env]; FEAT: 1 = carries the ARCLE_STEP_FEATURE_FLAGS code
-template <int ING, int FW, int ACCT, int FEAT, int FL = -1>
+// WC: 30 = the launch's grid is the standard 30 x 30 (H, W, P, plane stride and the division constant are compile-time
+// constants: every clamp, row/column split and rectangle mask folds), 0 = read from the arguments
+template <int ING, int FW, int ACCT, int FEAT, int FL = -1, int WC = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(
-    const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel, int n_envs, int wpw, uint32_t nb8, const StepParams p) {
+    const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel, int n_envs, int wpw, uint32_t nb8, const StepParams pa) {
+  StepParams p = pa;  // (a register-promoted copy: only the fields a path reads are ever fetched)
+  if (WC == 30) {
+    p.H = p.W = 30;
+    p.P = 900;
+    p.PS = ARCLE_MAX_CELLS;
+    p.div_magic = 65536u / 30u + 1u;
+    p.nseg = 2;
+  }
   // (leading scalar arguments = what a wave needs to find and request its env's inputs; built with -amdgpu-kernarg-preload-count they
   // are in SGPRs at wave start.  They repeat p.rec / p.cnt / p.op / p.sel / p.n_envs / p.wpw.)
   __shared__ BlockLDS lds;
@@ -460,6 +470,7 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
   if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || feat) return ARCLE_ERR_CONFIG;
   if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 0>), g, b, 0, st, STEP_ARGS);
 #ifndef ARCLE_NO_HOT_FLAGS
+  else if (p.flags == (uint32_t)HOT_FLAGS && p.H == 30 && p.W == 30) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS, 30>), g, b, 0, st, STEP_ARGS);
   else if (p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
 #endif
   else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0>), g, b, 0, st, STEP_ARGS);
@@ -470,7 +481,10 @@ template <int ING, int FW>
 static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, STEP_ARGS);  // (the feature instantiation has no accounting)
   else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, STEP_ARGS);
-  else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
+  else if (FW == arcle::FW_FULL && p.H == 30 && p.W == 30) {  // the standard 30 x 30 grid: dimensions are compile-time constants
+    if (p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS, (FW == arcle::FW_FULL ? 30 : 0)>), g, b, 0, st, STEP_ARGS);
+    else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, -1, (FW == arcle::FW_FULL ? 30 : 0)>), g, b, 0, st, STEP_ARGS);
+  } else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
   else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, STEP_ARGS);
 }
 template <int ING>
