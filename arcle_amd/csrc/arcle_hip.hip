@@ -100,6 +100,11 @@ ARCLE_DEV void arrived3(U4& a, U2& b, uint32_t& c) { asm volatile("" : "+s"(a), 
 #ifndef ARCLE_STOP_AT
 #define ARCLE_STOP_AT 0
 #endif
+// Reading back what this wave stored earlier needs no cache maintenance and no wait: a wave's vector memory operations reach its
+// write-through L1 in issue order, so a load issued after a store to the same address returns the stored data (the guarantee
+// every `a[i] = x; y = a[i];` relies on).  An agent-scope invalidate (`buffer_inv sc1`) here cost 50 us per launch: it empties the
+// CU's L1 under the 31 other resident waves.  The asm is a compiler-level fence only (the plane stores are inline asm).
+ARCLE_DEV void own_stores_visible() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void sink_s(uint32_t v) { asm volatile("" ::"s"(v)); }
 __device__ __forceinline__ void sink_v(uint32_t v) { asm volatile("" ::"v"(v)); }
 }  // namespace xl
@@ -177,15 +182,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const 
   arcle::wave_rollout<ING, FW>(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
-// one LDS row buffer per wave: 7 planes of <= 1024 B + 14 scalars, rounded up
-static constexpr int FLAT_ROW_LDS = 7 * ARCLE_MAX_CELLS + 32;
-static constexpr int FLAT_WAVES = 4;
-__global__ __launch_bounds__(64 * FLAT_WAVES) void arcle_flatten_kernel(const StepParams p) {
-  __shared__ arcle::WaveLDS tiles[FLAT_WAVES];
-  __shared__ __attribute__((aligned(16))) uint8_t rows[FLAT_WAVES][FLAT_ROW_LDS];
-  const int env = (int)(blockIdx.x * FLAT_WAVES + (threadIdx.x >> 6));
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_flatten_kernel(const StepParams p) {
+  __shared__ BlockLDS lds;
+  const int env = wave_of_launch();
   if (env >= p.n_envs) return;
-  arcle::wave_flatten(p, &tiles[threadIdx.x >> 6], nullptr, rows[threadIdx.x >> 6], env, (int)(threadIdx.x & 63));
+  arcle::wave_flatten(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_pack_kernel(const StepParams p) {
@@ -519,6 +520,12 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   // the streaming regime (76-79 vs 85-88 us at 131072 envs): in-box A/B, profiles/round2_experiments.txt
   const int wpw = p.n_envs >= 65536 ? 4 : WAVES_PER_WG;
   p.wpw = wpw;
+  if (flags & ARCLE_STEP_FLAT_OBS) {
+    if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
+    p.flat_out = e->flat_out;
+    p.flat_stride = e->flat_stride;
+    p.flat_filter = e->flat_filtered ? 1 : 0;
+  }
   const dim3 g = grid_for(p.n_envs, wpw), b(64 * wpw);
   hipStream_t st = (hipStream_t)stream;
   const int fw = width_class(p);
@@ -532,10 +539,6 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
-  if (flags & ARCLE_STEP_FLAT_OBS) {  // the observation rows of the state this step produced, same stream, no host round trip
-    if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
-    return launch_flatten(e, e->flat_out, e->flat_stride, e->flat_filtered, st);
-  }
   return ARCLE_OK;
 }
 
@@ -687,7 +690,7 @@ static int launch_flatten(arcle_env* e, int8_t* out, int32_t out_stride, int fil
   p.flat_out = out;
   p.flat_stride = out_stride;
   p.flat_filter = filtered ? 1 : 0;
-  hipLaunchKernelGGL(arcle_flatten_kernel, dim3((unsigned)((p.n_envs + FLAT_WAVES - 1) / FLAT_WAVES)), dim3(64 * FLAT_WAVES), 0, st, p);
+  hipLaunchKernelGGL(arcle_flatten_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, st, p);
   HIP_TRY(e, hipGetLastError());
   // a row reads its planes + the record once and is written once (SURVEY.md 8d accounting of the observation writer)
   if (e->d_acct) e->acct_extra += (uint64_t)p.n_envs * (uint64_t)(2 * len + ARCLE_REC_BYTES);

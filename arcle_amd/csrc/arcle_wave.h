@@ -1423,6 +1423,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   return out;
 }
 
+ARCLE_DEV void flat_row(const Wave& w, const Rec& r);  // (the observation writer, below)
+
 // The per-env inputs of one step: record, op index, counters and the selection payload — four independent loads
 // (scalar loads for everything but a full mask), issued together so that they share ONE latency window.
 struct StepInputs {
@@ -1515,6 +1517,13 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
 #else
     if (ACCT) p.acct[env] += out.bytes;
 #endif
+  }
+  if (FEAT && (p.flags & ARCLE_STEP_FLAT_OBS)) {
+    // fused observation writer: the flattened row of the state this step just produced (FlattenObservation, optionally after
+    // FilterO2ARC), written by the same wave — no second launch, no re-read of
+    // the record.  The planes are read back through the wave's own L1 path (program order, see xl::own_stores_visible).
+    xl::own_stores_visible();
+    flat_row(w, r);
   }
 }
 
@@ -1626,24 +1635,32 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
 //   full     clip clip_dim grid grid_dim input input_dim | active background object object_dim object_pos object_sel
 //            rotation_parity | selected terminated trials_remain                       = 7*H*W + 14 bytes (6314 at 30x30)
 //   filtered active clip clip_dim grid grid_dim object object_dim object_pos trials_remain = 3*H*W + 10 bytes (2710)
-// The segments start at arbitrary byte offsets, so the row is assembled byte-accurately in the wave's LDS row buffer and
-// then streamed out with aligned, fully coalesced 16 B stores (row stride = a multiple of 16 >= the logical length).
+// The segments start at arbitrary byte offsets of the row (row base 16-byte aligned, stride a multiple of 16 >= the logical
+// length).  A plane segment is written as whole aligned 16-byte chunks — the plane is staged in the wave's 1 KiB LDS tile and each
+// lane reads its chunk at the segment's misalignment S with the same uniform flat shift the object ops use — plus at most 15 head
+// and 15 tail bytes stored singly; scalars are byte stores.  No per-row LDS buffer: the writer runs at the step kernel's occupancy.
 // ------------------------------------------------------------------------------------------------
 struct FlatRow {
-  uint8_t* buf;  // LDS, >= flat stride bytes
-  int off;
+  int8_t* row;  // global memory, this env's row
+  int off;      // bytes written so far
 };
 ARCLE_DEV void flat_plane(const Wave& w, FlatRow& fr, int pl) {
   if (!w.p.plane[pl]) return;
-  const U4 v = w.load_hbm(pl);
-  uint8_t* d = fr.buf + fr.off + 16 * w.lane;
-#pragma unroll
-  for (int k = 0; k < 16; k++)
-    if ((w.valid16 >> k) & 1u) d[k] = (uint8_t)u4_byte(v, k);
-  fr.off += w.p.P;
+  const int P = w.p.P, off = fr.off, lane = w.lane;
+  w.stage(w.lds->a, w.load_hbm(pl));
+  const int c0 = (off + 15) >> 4, S = 16 * c0 - off;  // first whole chunk of the row inside the segment; its plane byte offset
+  const int n_full = ((off + P) >> 4) - c0;           // whole chunks (<= 64); negative: the segment ends inside its first chunk
+  const U4 o = w.shifted(w.lds->a, S);
+  if (lane < n_full) *reinterpret_cast<U4*>(fr.row + 16 * (size_t)(c0 + lane)) = o;
+  const uint8_t* t8 = reinterpret_cast<const uint8_t*>(w.lds->a);
+  const int head = imin(S, P);                        // row bytes [off, 16 c0) = plane bytes [0, S)
+  if (lane < head) fr.row[off + lane] = (int8_t)t8[xl::lds_idx(lane, 1024)];
+  const int tail = n_full >= 0 ? ((off + P) & 15) : 0;  // row bytes [16 (c0 + n_full), off + P) = plane bytes [16 n_full + S, P)
+  if (lane < tail) fr.row[16 * (c0 + n_full) + lane] = (int8_t)t8[xl::lds_idx(16 * n_full + S + lane, 1024)];
+  fr.off += P;
 }
 ARCLE_DEV void flat_scalar(const Wave& w, FlatRow& fr, const Rec& r, int field, int n) {
-  if (w.lane < n) fr.buf[fr.off + w.lane] = (uint8_t)r.ub(field + (w.lane < n ? w.lane : 0));
+  if (w.lane < n) fr.row[fr.off + w.lane] = (int8_t)r.ub(field + (w.lane < n ? w.lane : 0));
   fr.off += n;
 }
 ARCLE_HD int flat_obs_len(const StepParams& p, int filtered) {
@@ -1651,13 +1668,13 @@ ARCLE_HD int flat_obs_len(const StepParams& p, int filtered) {
   if (filtered) return 3 * p.P + 10;
   return 2 * p.P + 6 + (clip ? p.P + 2 : 0) + (o2 ? 4 * p.P + 6 : 0);
 }
-ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, uint8_t* rowbuf, int env, int lane) {
-  Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
-  w.set_env(env);
-  const Rec r = load_rec(p, env);
+// the row of w's env from the planes in memory and the record `r` (the step kernel calls it with the record it just produced)
+ARCLE_DEV void flat_row(const Wave& w, const Rec& r) {
+  const StepParams& p = w.p;
+  const int lane = w.lane, env = w.env;
   const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
   FlatRow fr;
-  fr.buf = rowbuf;
+  fr.row = p.flat_out + (size_t)env * p.flat_stride;
   fr.off = 0;
   if (p.flat_filter) {
     flat_scalar(w, fr, r, ARCLE_REC_ACTIVE, 1);
@@ -1689,11 +1706,14 @@ ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, ui
     flat_scalar(w, fr, r, ARCLE_REC_TERMINATED, 1);
     flat_scalar(w, fr, r, ARCLE_REC_TRIALS, 1);
   }
-  if (lane < 16 && fr.off + lane < p.flat_stride) rowbuf[fr.off + lane] = 0;  // row padding up to the stride
-  xl::lds_fence();
-  int8_t* row = p.flat_out + (size_t)env * p.flat_stride;
-  for (int c = 16 * lane; c < p.flat_stride; c += 1024)
-    *reinterpret_cast<U4*>(row + c) = *reinterpret_cast<const U4*>(rowbuf + c);
+  if (lane < 16 && fr.off + lane < p.flat_stride) fr.row[fr.off + lane] = 0;  // row padding up to the stride
+}
+
+ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
+  Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
+  w.set_env(env);
+  const Rec r = load_rec(p, env);
+  flat_row(w, r);
 }
 
 // ------------------------------------------------------------------------------------------------

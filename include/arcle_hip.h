@@ -137,9 +137,11 @@ enum arcle_op_kind {
  * re-initialises the env from its input inside the op; the caller sees the fresh state, terminated stays 0 */
 #define ARCLE_STEP_RESET_ON_SUBMIT 64u
 /* the step flags served by the feature instantiations of the step kernel (the plain ones stay lean) */
-#define ARCLE_STEP_FEATURE_FLAGS (ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT)
-/* the step call also emits the flattened observation rows (arcle_set_flat_output) of the state it produced */
+/* the step kernel also writes the flattened observation row (arcle_set_flat_output: FlattenObservation, optionally after
+ * FilterO2ARC) of the state it produced — fused into the same launch */
 #define ARCLE_STEP_FLAT_OBS 128u
+#define ARCLE_STEP_FEATURE_FLAGS \
+  (ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT | ARCLE_STEP_FLAT_OBS)
 
 /* ---- augmentation of a task at reset (arcle_set_sampler / ARCLE_STEP_RESAMPLE / arcle_reset_sampled) ---- */
 #define ARCLE_AUG_PERMUTE 1u /* random permutation of the colours 0..9 (applied to input and answer) */

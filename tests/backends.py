@@ -225,6 +225,22 @@ class EmuBackend:
         if getattr(self, "tbl", None) is not None:
             p.tbl_in, p.tbl_in_dim, p.tbl_ans, p.tbl_ans_dim = [t.ctypes.data for t in self.tbl]
             p.n_tasks = len(self.tbl[0])
+        if getattr(self, "_flat", None) is not None:  # destination of STEP_FLAT_OBS
+            out, L, filtered = self._flat
+            p.flat_out, p.flat_stride, p.flat_filter = out.ctypes.data, out.shape[1], int(filtered)
+
+    def _flat_len(self, filtered):
+        o2, clip = "selected" in self.buf, "clip" in self.buf
+        return 3 * self.P + 10 if filtered else 2 * self.P + 6 + (self.P + 2 if clip else 0) + (4 * self.P + 6 if o2 else 0)
+
+    def set_flat_output(self, filtered=False):
+        L = self._flat_len(filtered)
+        self._flat = (np.full((self.N, (L + 15) & ~15), 0x55, np.int8), L, filtered)
+
+    def fused_flat(self):
+        out, L, _ = self._flat
+        assert not out[:, L:].any()
+        return out[:, :L].copy()
 
     def set_truncation(self, limit):
         self.trunc, self.step_limit = np.zeros(self.N, np.uint8), int(limit)
@@ -366,6 +382,15 @@ class HipBackend:
 
     def flat_obs(self, filtered=False):
         return self.b.flat_obs(filtered=filtered).cpu().numpy().copy()
+
+    def set_flat_output(self, filtered=False):
+        self.b.set_flat_output(filtered)
+        self.b._flat_buf.fill_(0x55)
+
+    def fused_flat(self):
+        self.torch.cuda.synchronize()
+        assert not self.b._flat_buf[:, self.b.flat.shape[1]:].any()
+        return self.b.flat.cpu().numpy().copy()
 
     def packed_obs(self):
         return self.b.packed_obs().cpu().numpy().copy()

@@ -94,6 +94,7 @@ ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b &
 ARCLE_DEV uint32_t opaque(uint32_t v) { return v; }
 #define ARCLE_STOP_AT 0
 ARCLE_DEV void sink_s(uint32_t) {}
+ARCLE_DEV void own_stores_visible() {}
 ARCLE_DEV void sink_v(uint32_t) {}
 ARCLE_DEV void arrived(U4&, U2&, uint32_t&, U4&) {}
 ARCLE_DEV void arrived3(U4&, U2&, uint32_t&) {}
@@ -108,13 +109,12 @@ int g_env, g_kind;
 char* g_stacks;
 const size_t STACK = 256 * 1024;
 
-alignas(16) uint8_t g_row[7 * ARCLE_MAX_CELLS + 32];  // the flatten kernel's LDS row buffer
 
 #define RUN_STEP(I, F)                                                                      \
   do {                                                                                      \
     arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, I, F, false);                      \
     arcle::StepInputs in = arcle::load_inputs<I>(w, g_env);                                 \
-    if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, 0, 1>(w, g_env, in);  \
+    if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, 0, 1>(w, g_env, in);           \
     else arcle::wave_step<I, F, 1, 0>(w, g_env, in);                                        \
   } while (0)
 #define RUN_ROLL(I, F) arcle::wave_rollout<I, F>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane)
@@ -157,7 +157,7 @@ void lane_main(int lane) {
     }
   }
   else if (g_kind == 4)
-    arcle::wave_flatten(*g_p, &g_lds.wave[0], g_lds.lut, g_row, g_env, lane);
+    arcle::wave_flatten(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
   else if (g_kind == 5)
     arcle::wave_pack_obs(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
   else

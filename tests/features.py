@@ -10,7 +10,7 @@ import backends as B
 from oracle import oracle as O
 
 G = None
-STEP_AUTORESET, STEP_ELIDE, STEP_TRUNCATE, STEP_RESAMPLE, STEP_DENSE, STEP_CONTINUE, STEP_ROS = 1, 2, 4, 8, 16, 32, 64
+STEP_AUTORESET, STEP_ELIDE, STEP_TRUNCATE, STEP_RESAMPLE, STEP_DENSE, STEP_CONTINUE, STEP_ROS, STEP_FLAT_OBS = 1, 2, 4, 8, 16, 32, 64, 128
 AUG_PERMUTE, AUG_ROT90 = 1, 2
 
 
@@ -137,6 +137,20 @@ def flat(cls):
         if got.shape != want.shape or not np.array_equal(got, want):
             bad = np.nonzero((got != want).any(1))[0] if got.shape == want.shape else "shape"
             errs.append(f"flat obs (filtered={filtered}): rows differ for envs {bad if isinstance(bad, str) else bad.tolist()}")
+    # the same rows written by the step kernel itself (STEP_FLAT_OBS, fused epilogue): replay the trace with the flag set; the
+    # rows after the last step are the golden ones, and after every step they equal the stand-alone writer's
+    for filtered, want in ((False, g["flat_rows"]), (True, g["flat_rows_filtered"])):
+        be = cls(N, H, W, 5, "o2arc", O.o2arc_ops())
+        be.set_tasks(g["flat_in"], g["flat_in_dim"], g["flat_ans"], g["flat_ans_dim"])
+        be.reset()
+        be.set_flat_output(filtered)
+        for s in range(S):
+            be.step("mask", g["flat_mask"][s], g["flat_op"][s], STEP_FLAT_OBS)
+            if s % 5 == 0 and not np.array_equal(be.fused_flat(), be.flat_obs(filtered)):
+                errs.append(f"fused flat obs (filtered={filtered}) differs from the stand-alone writer after step {s}")
+        got = be.fused_flat()
+        if got.shape != want.shape or not np.array_equal(got, want):
+            errs.append(f"fused flat obs (filtered={filtered}): rows differ from the golden rows")
     return errs
 
 

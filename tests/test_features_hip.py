@@ -283,3 +283,29 @@ def test_flat_rows_are_in_the_byte_accounting():
         b.flat_obs(filtered=filtered)
         got, steps = b.accounting(clear=True)
         assert got == N * (2 * length + 16) and steps == 0
+
+
+def test_fused_flat_rows_at_full_size():
+    """STEP_FLAT_OBS at benchmark size: the rows the step kernel writes itself (it reads back planes it stored a moment ago) equal
+    the stand-alone writer's rows of the same state, under full load, for both row formats."""
+    import torch
+    import bench
+    from arcle_amd import actions
+    from arcle_amd.engine import EnvBatch, STEP_FLAT_OBS
+    from arcle_amd.envs import O2ARCv2Env
+    n, K = 8192, 24
+    bbox_np, op_np = bench.make_actions(K, n, 11)
+    bbox, ops = torch.from_numpy(bbox_np).cuda(), torch.from_numpy(op_np).cuda()
+    for filtered in (False, True):
+        b = EnvBatch(n, 30, 30, -1, "o2arc", "cuda")
+        b.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
+        b.set_tasks_padded(*bench.make_tasks(n, 2))
+        b.reset()
+        b.set_flat_output(filtered)
+        FL = b.elide_flag | bench.STEP_AUTORESET | STEP_FLAT_OBS
+        for i in range(K):
+            b.step_bbox(bbox[i], ops[i], FL)
+            if i % 4 == 3:
+                fused = b.flat.clone()
+                assert torch.equal(fused, b.flat_obs(filtered=filtered)), (filtered, i)
+        assert b.status() == 0
