@@ -87,6 +87,7 @@ ARCLE_DEV uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 
 // neighbouring lane's value through DPP wave shifts (no LDS): lane j-1 / lane j+1, 0 at the wave boundary
 ARCLE_DEV uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 ARCLE_DEV uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+ARCLE_DEV uint32_t bfrev(uint32_t v) { return __builtin_bitreverse32(v); }  // v_bfrev_b32
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }  // full-rate 24-bit multiply
 ARCLE_DEV uint32_t opaque(uint32_t v) {  // hides a value's origin from the optimiser (no instruction)

@@ -768,6 +768,24 @@ ARCLE_DEV uint32_t board_shr(const Wave& w, uint32_t v, int n) {
   return b ? ((w0 >> b) | (w1 << (32 - b))) : w0;
 }
 
+// row board <-> per-lane 16-cell windows (16 <= W <= 32): row i = flat cells [W i, W i + W) = bits of up to three windows
+ARCLE_DEV uint32_t rows_from16(const Wave& w, uint32_t m16, uint32_t Wb) {
+  const uint32_t start = xl::mul24((uint32_t)w.lane, Wb), a = start >> 4, sh = start & 15u;
+  uint32_t c0 = xl::shfl(m16, (int)(a & 63u)), c1 = xl::shfl(m16, (int)((a + 1u) & 63u)), c2 = xl::shfl(m16, (int)((a + 2u) & 63u));
+  if (a > 63u) c0 = 0;
+  if (a + 1u > 63u) c1 = 0;
+  if (a + 2u > 63u) c2 = 0;
+  const uint32_t lo = c0 | (c1 << 16);
+  const uint32_t v = sh ? ((lo >> sh) | (c2 << (32u - sh))) : lo;
+  return Wb == 32u ? v : (v & ((1u << Wb) - 1u));
+}
+ARCLE_DEV uint32_t rows_to16(const Wave& w, uint32_t rows, uint32_t Wb) {  // window = row r0 from column c0 (k1 cells), then row r0 + 1
+  const uint32_t R0 = xl::shfl(rows, w.r0 & 63), R1 = xl::shfl(rows, (w.r0 + 1) & 63);
+  const uint32_t lo = w.r0 > 63 ? 0u : (R0 >> (uint32_t)w.c0);
+  const uint32_t hi = (w.r0 + 1 > 63 || w.k1 >= 16) ? 0u : (R1 << (uint32_t)w.k1);
+  return (lo | hi) & 0xffffu;
+}
+
 template <int ACCT>
 ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& sel, int color) {
   const StepParams& p = w.p;
@@ -798,39 +816,47 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
   // colour at the seed: lane seed>>4, byte seed&15
   uint32_t mine = u4_byte(s.grid, seed & 15);
   uint32_t col = xl::uniform(xl::shfl(mine, seed >> 4));
-  uint32_t inside = w.rect16(0, gh - 1, 0, gw - 1);
-  uint32_t M = to32(w, eq16(s.grid, col) & inside);
-  uint32_t notfirst = to32(w, w.rect16(0, p.H - 1, 1, p.W - 1));
-  uint32_t notlast = to32(w, w.rect16(0, p.H - 1, 0, p.W - 2));
-  uint32_t F = (w.lane == (seed >> 5)) ? (1u << (seed & 31)) : 0u;
+  const uint32_t inside = w.rect16(0, gh - 1, 0, gw - 1);
+  const uint32_t M16 = eq16(s.grid, col) & inside;  // fillable cells of this lane's window: same colour as the seed, inside grid_dim
+  uint32_t vis;
   if (w.fw != FW_GENERIC) {
-    // 16 <= W <= 32: every neighbour shift (1 or W bits) only needs the adjacent lanes' words, fetched with two DPP
-    // wave shifts per propagation step (no LDS round trip); 4 steps per convergence ballot (the closure is monotone,
-    // extra steps are harmless)
+    // 16 <= W <= 32 (so H <= 64): ROW BOARD — lane i holds row i as a W-bit word.  A vertical step is two DPP wave shifts; a
+    // horizontal fill closes every run of a row in ONE pass with the carry trick: adding the filled bits to the fillable mask
+    // ripples a carry up through each run of ones that contains one, (M ^ (M + F)) & M are the cells it passed, and the same on the
+    // bit-reversed words fills downwards.  The two alternate until neither adds a cell: the number of passes follows the number of
+    // corridor legs / row transitions of the region, not its cell-path length (a 1-wide spiral: ~60 legs against 434 cell steps).
     const uint32_t Wb = (uint32_t)p.W;
-    for (int it = 0; it < ARCLE_MAX_CELLS / 4 + 1; it++) {
-      const uint32_t F0 = F;
+    const uint32_t M = rows_from16(w, M16, Wb), rM = xl::bfrev(M);
+    uint32_t F = (w.lane == sx) ? (1u << sy) : 0u;
+    for (int it = 0; it < ARCLE_MAX_CELLS; it++) {
+      for (int v = 0; v < ARCLE_MAX_CELLS / 4 + 1; v++) {  // vertical closure, 4 steps per convergence ballot
+        const uint32_t F0 = F;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t prev = xl::lane_prev(F), next = xl::lane_next(F);  // lane j-1 / j+1, 0 outside the wave
-        const uint32_t l1 = (F << 1) | (prev >> 31), r1 = (F >> 1) | (next << 31);
-        const uint32_t lW = (Wb == 32) ? prev : ((F << Wb) | (prev >> (32 - Wb)));
-        const uint32_t rW = (Wb == 32) ? next : ((F >> Wb) | (next << (32 - Wb)));
-        F |= ((l1 & notfirst) | (r1 & notlast) | lW | rW) & M;
+        for (int u = 0; u < 4; u++) F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;  // rows i-1 / i+1 (0 beyond the wave)
+        if (!w.any(F != F0)) break;
       }
-      if (!w.any(F != F0)) break;
+      const uint32_t rF = xl::bfrev(F);
+      const uint32_t Fh = F | ((M ^ (M + F)) & M) | xl::bfrev((rM ^ (rM + rF)) & rM);
+      const bool grew = w.any(Fh != F);
+      F = Fh;
+      if (!grew) break;
     }
+    vis = rows_to16(w, F, Wb);
   } else {
+    uint32_t Mb = to32(w, M16);
+    uint32_t notfirst = to32(w, w.rect16(0, p.H - 1, 1, p.W - 1));
+    uint32_t notlast = to32(w, w.rect16(0, p.H - 1, 0, p.W - 2));
+    uint32_t F = (w.lane == (seed >> 5)) ? (1u << (seed & 31)) : 0u;
     for (int it = 0; it < ARCLE_MAX_CELLS; it++) {
       uint32_t grow = (board_shl(w, F, 1) & notfirst) | (board_shr(w, F, 1) & notlast) | board_shl(w, F, p.W) |
                       board_shr(w, F, p.W);
-      uint32_t Fn = F | (grow & M);
+      uint32_t Fn = F | (grow & Mb);
       bool changed = w.any(Fn != F);
       F = Fn;
       if (!changed) break;
     }
+    vis = to16(w, F);
   }
-  const uint32_t vis = to16(w, F);
   s.grid = u4_sel1(w.expand16(vis), ((uint32_t)color & 0xffu) * 0x01010101u, s.grid);
   w.store(ARCLE_PL_GRID, s.grid);
   ARCLE_ACCT(p.P);

@@ -92,6 +92,11 @@ ARCLE_DEV void wg_barrier() { yield(8); }
 ARCLE_DEV void lanes_converged() { yield(9); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 ARCLE_DEV uint32_t opaque(uint32_t v) { return v; }
+ARCLE_DEV uint32_t bfrev(uint32_t v) {
+  uint32_t r = 0;
+  for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
 #define ARCLE_STOP_AT 0
 ARCLE_DEV void sink_s(uint32_t) {}
 ARCLE_DEV void own_stores_visible() {}
