@@ -1,12 +1,15 @@
 // arcle_hip.hip — gfx950 kernels + the C ABI of include/arcle_hip.h  (libarcle_hip.so)
 //
-// Kernels
-//   arcle_step_kernel   one wavefront per env, 4 envs per 256-thread workgroup; body in arcle_wave.h
-//   arcle_reset_kernel  init_state for (masked) envs
-// Launch geometry: grid = ceil(N/4) workgroups rounded up to a multiple of 8.  Workgroup b is observed
+// Kernels (bodies in arcle_wave.h; one wavefront per env everywhere)
+//   arcle_step_kernel          one step() of every env; 8 waves per workgroup (4 from 65536 envs on)
+//   arcle_rollout_kernel       n_steps step()s per launch with the env state resident in registers
+//   arcle_reset[_table]_kernel init_state for (masked) envs, optionally from the device task table / device-drawn tasks
+//   arcle_flatten_kernel       flattened observation rows (also an epilogue of the step kernel: ARCLE_STEP_FLAT_OBS)
+//   arcle_pack_kernel          packed per-step observation rows for the multi-GPU gather
+// Launch geometry: grid = ceil(N / waves per workgroup) rounded up to a multiple of 8.  Workgroup b is observed
 // to run on XCD b%8 (MI355X_MICROARCH.md §Workgroup dispatch); the block->env map below gives each XCD
-// one contiguous range of envs, so the 128 B lines shared by neighbouring envs' planes stay in one
-// XCD's L2.  That is an affinity choice only — correctness never depends on placement (envs share no
+// one contiguous range of envs, so an env's state stays in one XCD's L2 / Infinity-Cache slice from step to step.
+// That is an affinity choice only — correctness never depends on placement (envs share no
 // data and no workgroup communicates with another).
 #include <hip/hip_runtime.h>
 
@@ -120,7 +123,7 @@ using arcle::WaveLDS;
 #endif
 static constexpr int WAVES_PER_WG = ARCLE_WAVES_PER_WG;
 #ifndef ARCLE_SGPR_CAP
-#define ARCLE_SGPR_CAP 80  // 256-thread workgroups: 8 per CU need <= 80 SGPRs per wave (MI355X_MICROARCH.md, residency)
+#define ARCLE_SGPR_CAP 80  // 8 waves per SIMD need <= 80 SGPRs per wave (MI355X_MICROARCH.md, residency)
 #endif
 typedef arcle::BlockLDS<WAVES_PER_WG> BlockLDS;
 
