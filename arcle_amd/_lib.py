@@ -17,7 +17,7 @@ ABI_VERSION = 2
 N_PLANES = 8
 MAX_OPS = 64
 EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buffers", "arcle_set_op_table",
-           "arcle_can_elide_selected", "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table", "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation", "arcle_packed_obs_size", "arcle_pack_obs", "arcle_set_sampler", "arcle_reset_sampled", "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_flat_obs_size", "arcle_flatten_obs", "arcle_set_flat_output", "arcle_get_status",
+           "arcle_can_elide_selected", "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table", "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation", "arcle_packed_obs_size", "arcle_pack_obs", "arcle_set_packed_output", "arcle_set_sampler", "arcle_reset_sampled", "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_flat_obs_size", "arcle_flatten_obs", "arcle_set_flat_output", "arcle_get_status",
            "arcle_enable_accounting", "arcle_get_accounting", "arcle_last_error"]
 
 
@@ -84,6 +84,7 @@ def lib():
     L.arcle_set_dense_output.argtypes = [vp, vp]
     L.arcle_packed_obs_size.argtypes = [vp]
     L.arcle_pack_obs.argtypes = [vp, vp, vp, vp, vp]
+    L.arcle_set_packed_output.argtypes = [vp, vp]
     for name in ("arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask"):
         getattr(L, name).argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
     L.arcle_flat_obs_size.argtypes = [vp, ctypes.c_int]

@@ -241,6 +241,7 @@ struct arcle_env {
   uint64_t acct_extra = 0;  // algorithmic bytes of launches without a per-env counter (flattened observation rows)
   uint32_t ops_host[ARCLE_MAX_OPS];
   int8_t* flat_out;  // ARCLE_STEP_FLAT_OBS destination (arcle_set_flat_output)
+  int8_t* pack_out;  // ARCLE_STEP_PACK_OBS destination (arcle_set_packed_output)
   int32_t flat_stride;
   int flat_filtered;
   uint32_t* d_acct;
@@ -469,6 +470,8 @@ static int width_class(const StepParams& p) {
 // the flag combination ARCVecEnv steps with (next-step autoreset, elided zero-fill of `selected`) has its own instantiation
 // with the flags as a compile-time constant
 static constexpr int HOT_FLAGS = ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED;
+// ... and the same plus the fused packed row (what a ShardedVecEnv steps with): lean 30 x 30 instantiation
+static constexpr int HOT_PACK_FLAGS = HOT_FLAGS | ARCLE_STEP_PACK_OBS;
 #ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiation exists (seconds instead of a minute)
 template <int ING>
 static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
@@ -484,12 +487,16 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
 #else
 template <int ING, int FW>
 static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  if constexpr (FW == arcle::FW_FULL) {  // the standard 30 x 30 grid: lean instantiations with the dimensions as compile-time constants
+    if (p.H == 30 && p.W == 30 && !acct) {
+      if (p.flags == (uint32_t)HOT_PACK_FLAGS) { hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_PACK_FLAGS, 30>), g, b, 0, st, STEP_ARGS); return; }
+      if (p.flags == (uint32_t)HOT_FLAGS) { hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS, 30>), g, b, 0, st, STEP_ARGS); return; }
+      if (!feat) { hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, -1, 30>), g, b, 0, st, STEP_ARGS); return; }
+    }
+  }
   if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, STEP_ARGS);  // (the feature instantiation has no accounting)
   else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, STEP_ARGS);
-  else if (FW == arcle::FW_FULL && p.H == 30 && p.W == 30) {  // the standard 30 x 30 grid: dimensions are compile-time constants
-    if (p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS, (FW == arcle::FW_FULL ? 30 : 0)>), g, b, 0, st, STEP_ARGS);
-    else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, -1, (FW == arcle::FW_FULL ? 30 : 0)>), g, b, 0, st, STEP_ARGS);
-  } else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
+  else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
   else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, STEP_ARGS);
 }
 template <int ING>
@@ -529,6 +536,10 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     p.flat_out = e->flat_out;
     p.flat_stride = e->flat_stride;
     p.flat_filter = e->flat_filtered ? 1 : 0;
+  }
+  if (flags & ARCLE_STEP_PACK_OBS) {
+    if (!e->pack_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output");
+    p.pack_out = e->pack_out;
   }
   const dim3 g = grid_for(p.n_envs, wpw), b(64 * wpw);
   hipStream_t st = (hipStream_t)stream;
@@ -737,6 +748,13 @@ extern "C" int arcle_pack_obs(arcle_env* e, const int32_t* reward, const uint8_t
   p.flat_stride = arcle_packed_obs_size(e);
   hipLaunchKernelGGL(arcle_pack_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
   HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_set_packed_output(arcle_env* e, uint8_t* out) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(out) & 15) return fail(e, ARCLE_ERR_ARG, "packed observation rows must be 16-byte aligned");
+  e->pack_out = reinterpret_cast<int8_t*>(out);
   return ARCLE_OK;
 }
 

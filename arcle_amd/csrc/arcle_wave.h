@@ -66,6 +66,7 @@ struct StepParams {
   int8_t* flat_out;       // optional flattened observation rows (ARCLE_STEP_FLAT_OBS / flatten kernel)
   int32_t flat_stride;    // bytes between rows of flat_out
   int32_t flat_filter;    // 0 = full state (FlattenObservation), 1 = FilterO2ARC subset (agents/env.py:109-126)
+  int8_t* pack_out;       // optional packed per-step rows (ARCLE_STEP_PACK_OBS), stride = packed_stride(P)
   // ---- reset kernels ----
   const uint8_t* rmask;
   const int32_t* task_idx;                 // reset-from-table kernel only
@@ -1449,7 +1450,9 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   return out;
 }
 
-ARCLE_DEV void flat_row(const Wave& w, const Rec& r);  // (the observation writer, below)
+ARCLE_DEV void flat_row(const Wave& w, const Rec& r);  // (the observation writers, below)
+ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride);
+ARCLE_HD int packed_stride(int P);
 
 // The per-env inputs of one step: record, op index, counters and the selection payload — four independent loads
 // (scalar loads for everything but a full mask), issued together so that they share ONE latency window.
@@ -1550,6 +1553,12 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
     // the record.  The planes are read back through the wave's own L1 path (program order, see xl::own_stores_visible).
     xl::own_stores_visible();
     flat_row(w, r);
+  }
+  // fused packed row for the multi-GPU gather (grid | grid_dim | reward | terminated): in the feature instantiations, and in
+  // the lean ones whose compile-time flags ask for it
+  if ((FEAT || FL >= 0) && ((FL >= 0 ? (uint32_t)FL : p.flags) & ARCLE_STEP_PACK_OBS)) {
+    xl::own_stores_visible();
+    pack_row(w, r, (uint32_t)out.reward, (uint32_t)out.term, p.pack_out, packed_stride(p.P));
   }
 }
 
@@ -1747,18 +1756,15 @@ ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, in
 //   row = grid (H*W bytes) | grid_dim (2) | reward int32 LE (4) | terminated (1) | zero padding to a multiple of 16
 // one aligned 16 B store per lane; p.flat_out / p.flat_stride name the destination, p.reward / p.term the step outputs
 // ------------------------------------------------------------------------------------------------
-ARCLE_DEV void wave_pack_obs(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
-  Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
-  w.set_env(env);
-  const int P = p.P;
-  if (16 * lane >= p.flat_stride) return;
+ARCLE_HD int packed_stride(int P) { return (P + 7 + 15) & ~15; }
+// `reward` / `term`: the step outputs of this env (the fused epilogue passes what it just computed)
+ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride) {
+  const int P = w.p.P, lane = w.lane;
+  if (16 * lane >= stride) return;
   U4 v = w.load_hbm(ARCLE_PL_GRID);  // (bytes >= P of the plane row are zero padding)
   if (16 * lane + 16 > P) {          // this lane's window holds the metadata bytes
-    const Rec r = load_rec(p, env);
-    const uint32_t rew = (uint32_t)p.reward[env];
     // the 7 metadata bytes as one little-endian word: grid_dim (2), reward int32 (4), terminated (1)
-    const uint64_t meta = (uint64_t)(uint32_t)r.gh() | ((uint64_t)(uint32_t)r.gw() << 8) | ((uint64_t)rew << 16) |
-                          ((uint64_t)p.term[env] << 48);
+    const uint64_t meta = (uint64_t)(uint32_t)r.gh() | ((uint64_t)(uint32_t)r.gw() << 8) | ((uint64_t)reward << 16) | ((uint64_t)(term & 0xffu) << 48);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int b = 16 * lane + k - P;
@@ -1768,7 +1774,13 @@ ARCLE_DEV void wave_pack_obs(const StepParams& p, WaveLDS* lds, const U2* lut, i
       }
     }
   }
-  *reinterpret_cast<U4*>(p.flat_out + (size_t)env * p.flat_stride + 16 * lane) = v;
+  *reinterpret_cast<U4*>(out + (size_t)w.env * stride + 16 * lane) = v;
+}
+ARCLE_DEV void wave_pack_obs(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
+  Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
+  w.set_env(env);
+  const Rec r = load_rec(p, env);
+  pack_row(w, r, (uint32_t)p.reward[env], (uint32_t)p.term[env], p.flat_out, p.flat_stride);
 }
 
 }  // namespace arcle

@@ -33,6 +33,7 @@ STEP_DENSE = 16
 STEP_CONTINUE_RULE = 32
 STEP_RESET_ON_SUBMIT = 64
 STEP_FLAT_OBS = 128
+STEP_PACK_OBS = 256
 AUG_PERMUTE, AUG_ROT90 = 1, 2
 ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION = 1, 2, 4, 8
 
@@ -311,6 +312,13 @@ class EnvBatch:
         self._check(self.L.arcle_pack_obs(self._h, _ptr(self.reward), _ptr(self.term), _ptr(out), self._stream()),
                     "arcle_pack_obs")
         return out
+
+    def set_packed_output(self):
+        """Installs the destination of STEP_PACK_OBS: every step call with that flag also writes `self.packed` ([N, R] uint8 rows
+        grid | grid_dim | reward | terminated) from inside the step kernel — no packing launch before the multi-GPU gather."""
+        self.packed = torch.empty((self.N, self.packed_obs_size()), dtype=torch.uint8, device=self.device)
+        self._check(self.L.arcle_set_packed_output(self._h, _ptr(self.packed)), "arcle_set_packed_output")
+        return self.packed
 
     def packed_obs_ptr(self, out_ptr, stream=0):
         """Lowest-overhead form for rollout loops: raw device address of the [N, packed_obs_size()] uint8 output."""

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import actions
-from ..engine import (AUG_PERMUTE, AUG_ROT90, EnvBatch, STEP_AUTORESET, STEP_DENSE, STEP_RESAMPLE, STEP_RESET_ON_SUBMIT,
+from ..engine import (AUG_PERMUTE, AUG_ROT90, EnvBatch, STEP_AUTORESET, STEP_DENSE, STEP_PACK_OBS, STEP_RESAMPLE, STEP_RESET_ON_SUBMIT,
                       STEP_TRUNCATE, ST_BAD_OP, ST_BAD_SELECTION, ST_BAD_TASK, ST_ROTATE_DOMAIN)
 
 
@@ -199,6 +199,13 @@ class ARCVecEnv:
         trunc = b.trunc.bool() if self.max_episode_steps is not None else self._no_trunc
         return self._obs, reward, term.bool(), trunc, self._info()
 
+    def enable_packed_rows(self):
+        """From now on every step also writes `batch.packed` ([N, R] uint8: grid | grid_dim | reward | terminated per env) from
+        inside the step kernel (STEP_PACK_OBS) — what ShardedVecEnv.gather sends to a central learner."""
+        packed = self.batch.set_packed_output()
+        self.flags |= STEP_PACK_OBS
+        return packed
+
     def step_bbox(self, bbox, operation):
         def action_of(n):  # BBoxWrapper.action (bbox.py:22-30) for one env, only needed by host-applied ops
             x1, y1, x2, y2 = (int(v) for v in bbox[n].tolist())
@@ -233,7 +240,7 @@ class ARCVecEnv:
     def _rollout_flags(self):
         if self._host_slots or self.flags & (STEP_RESAMPLE | STEP_TRUNCATE | STEP_DENSE):
             raise NotImplementedError("rollouts support plain and same-task autoreset envs with device-only op tables")
-        return self.flags
+        return self.flags & ~STEP_PACK_OBS  # (only the final state of a rollout is observable: no per-step packed rows)
 
     def flat_obs(self, out=None, filtered=False):
         """The observation as one [N, L] int8 tensor in FlattenObservation key order (what the reference's policies

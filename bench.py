@@ -48,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29e12 measured copy)
 STEP_AUTORESET = 1
+STEP_PACK_OBS = 256
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -347,14 +348,13 @@ def main():
 
     gather = None
     if a.config == "c4":  # the learner-side gather: ONE all-gather of the packed 912-byte record per env and step
-        packed = torch.empty((n, batch.packed_obs_size()), dtype=torch.uint8, device=dev)
+        # the step kernel writes the packed rows itself (STEP_PACK_OBS, fused epilogue): no packing launch
+        packed = batch.set_packed_output()
+        FL |= STEP_PACK_OBS
         full = torch.empty((world * n, packed.shape[1]), dtype=torch.uint8, device=dev)
         host_full = torch.empty(full.shape, dtype=torch.uint8) if shared_gpu else None
 
-        packed_ptr = packed.data_ptr()
-
         def gather():
-            batch.packed_obs_ptr(packed_ptr, sh)
             if dist is None:
                 return  # one rank: the packed rows ARE the gathered tensor
             if shared_gpu:
@@ -396,8 +396,6 @@ def main():
                 csh = torch.cuda.current_stream(dev).cuda_stream
                 for i in range(Wm, Wm + K):
                     batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, csh)
-                    if gather is not None:
-                        batch.packed_obs_ptr(packed_ptr, csh)
         except Exception as exc:  # capture unsupported: eager launches
             print(f"bench: hipGraph capture failed ({exc}); eager launches", file=sys.stderr)
             graph = None
@@ -466,10 +464,12 @@ def main():
         batch.accounting(clear=True)
         for i in range(Wm, Wm + K):
             j = i % S
-            batch.step_bbox_ptr(bptr[j], optr[j], FL, sh)
+            batch.step_bbox_ptr(bptr[j], optr[j], FL & ~STEP_PACK_OBS, sh)  # (the accounting instantiation has no epilogues)
         torch.cuda.synchronize(dev)
         nbytes, nsteps = batch.accounting(clear=True)
         batch.enable_accounting(False)
+        if FL & STEP_PACK_OBS:  # the packed row: the grid plane read once more, the row written once
+            nbytes += K * n * (H * W + batch.packed_obs_size())
         per_launch_bytes = nbytes / K
         achieved = per_launch_bytes / kernel_avg_s
         traffic = traffic_src = frac_traffic = None
@@ -483,7 +483,7 @@ def main():
         roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                     "frac_by_traffic": frac_traffic,
-                    "kernel": "arcle_step_kernel" + (" (+ arcle_pack_kernel and the all-gather inside the event pair)"
+                    "kernel": "arcle_step_kernel" + (" (feature instantiation with the fused packed-row epilogue; the all-gather is inside the event pair)"
                                                      if gather is not None else ""),
                     "avg_launch_us": kernel_avg_s * 1e6,
                     "algorithmic_bytes_per_launch": per_launch_bytes,
@@ -503,7 +503,7 @@ def main():
                        "grid": [H, W], "ingress": "bbox",
                        "parallelism": f"env-shard x{world} (no data-path collective)" if gather is None
                        else (f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL'})"
-                             if dist is not None else "one rank: step + packing launch per step, nothing to gather")},
+                             if dist is not None else "one rank: step with the fused packed-row epilogue, nothing to gather")},
             "timing": {"regions": R, "stat": "median region, max over ranks per region",
                        "clock": "HIP events on the launch stream, recorded between the region's two synchronisations" if device_clock else "host perf_counter between the region's two synchronisations",
                        "host_region_ms": host_ms,

@@ -140,8 +140,12 @@ enum arcle_op_kind {
 /* the step kernel also writes the flattened observation row (arcle_set_flat_output: FlattenObservation, optionally after
  * FilterO2ARC) of the state it produced — fused into the same launch */
 #define ARCLE_STEP_FLAT_OBS 128u
-#define ARCLE_STEP_FEATURE_FLAGS \
-  (ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT | ARCLE_STEP_FLAT_OBS)
+/* the step kernel also writes the env's packed per-step row  grid | grid_dim | reward | terminated  (arcle_set_packed_output; the
+ * record a central learner gathers from every GPU) — fused into the same launch */
+#define ARCLE_STEP_PACK_OBS 256u
+#define ARCLE_STEP_FEATURE_FLAGS                                                                                        \
+  (ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT | ARCLE_STEP_FLAT_OBS | \
+   ARCLE_STEP_PACK_OBS)
 
 /* ---- augmentation of a task at reset (arcle_set_sampler / ARCLE_STEP_RESAMPLE / arcle_reset_sampled) ---- */
 #define ARCLE_AUG_PERMUTE 1u /* random permutation of the colours 0..9 (applied to input and answer) */
@@ -289,6 +293,8 @@ int arcle_set_flat_output(arcle_env* env, int8_t* out, int32_t out_stride, int f
  * wrote; out is a device buffer uint8 [n_envs][arcle_packed_obs_size()], 16-byte aligned. */
 int arcle_packed_obs_size(const arcle_env* env);
 int arcle_pack_obs(arcle_env* env, const int32_t* reward, const uint8_t* term, uint8_t* out, void* stream);
+/* destination of ARCLE_STEP_PACK_OBS: uint8 [n_envs][arcle_packed_obs_size()], 16-byte aligned (NULL uninstalls it) */
+int arcle_set_packed_output(arcle_env* env, uint8_t* out);
 
 /* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*): one atomic exchange on the device, so a
  * bit raised by a kernel on another stream is never lost between the read and the clear.  Synchronises the stream.

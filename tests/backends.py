@@ -94,7 +94,7 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("step_limit", ctypes.c_int32),
                 ("status", ctypes.c_void_p), ("acct", ctypes.c_void_p), ("d_ops", ctypes.c_void_p),
                 ("trunc", ctypes.c_void_p), ("dense", ctypes.c_void_p), ("flat_out", ctypes.c_void_p),
-                ("flat_stride", ctypes.c_int32), ("flat_filter", ctypes.c_int32),
+                ("flat_stride", ctypes.c_int32), ("flat_filter", ctypes.c_int32), ("pack_out", ctypes.c_void_p),
                 ("rmask", ctypes.c_void_p), ("task_idx", ctypes.c_void_p), ("tbl_in", ctypes.c_void_p),
                 ("tbl_ans", ctypes.c_void_p), ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p),
                 ("n_tasks", ctypes.c_int32), ("aug_flags", ctypes.c_uint32), ("seed", ctypes.c_uint64),
@@ -225,9 +225,17 @@ class EmuBackend:
         if getattr(self, "tbl", None) is not None:
             p.tbl_in, p.tbl_in_dim, p.tbl_ans, p.tbl_ans_dim = [t.ctypes.data for t in self.tbl]
             p.n_tasks = len(self.tbl[0])
+        if getattr(self, "_pack", None) is not None:  # destination of STEP_PACK_OBS
+            p.pack_out = self._pack.ctypes.data
         if getattr(self, "_flat", None) is not None:  # destination of STEP_FLAT_OBS
             out, L, filtered = self._flat
             p.flat_out, p.flat_stride, p.flat_filter = out.ctypes.data, out.shape[1], int(filtered)
+
+    def set_packed_output(self):
+        self._pack = np.full((self.N, (self.P + 7 + 15) & ~15), 0x55, np.uint8)
+
+    def fused_packed(self):
+        return self._pack.copy()
 
     def _flat_len(self, filtered):
         o2, clip = "selected" in self.buf, "clip" in self.buf
@@ -394,6 +402,13 @@ class HipBackend:
 
     def packed_obs(self):
         return self.b.packed_obs().cpu().numpy().copy()
+
+    def set_packed_output(self):
+        self.b.set_packed_output().fill_(0x55)
+
+    def fused_packed(self):
+        self.torch.cuda.synchronize()
+        return self.b.packed.cpu().numpy().copy()
 
     @property
     def trunc(self):

@@ -10,7 +10,7 @@ import backends as B
 from oracle import oracle as O
 
 G = None
-STEP_AUTORESET, STEP_ELIDE, STEP_TRUNCATE, STEP_RESAMPLE, STEP_DENSE, STEP_CONTINUE, STEP_ROS, STEP_FLAT_OBS = 1, 2, 4, 8, 16, 32, 64, 128
+STEP_AUTORESET, STEP_ELIDE, STEP_TRUNCATE, STEP_RESAMPLE, STEP_DENSE, STEP_CONTINUE, STEP_ROS, STEP_FLAT_OBS, STEP_PACK_OBS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 AUG_PERMUTE, AUG_ROT90 = 1, 2
 
 
@@ -261,6 +261,18 @@ def packed(cls):
                                r.astype("<i4").view(np.uint8).reshape(N, 4), t.reshape(N, 1)], 1)
         if rows.shape[1] != ((P + 7 + 15) & ~15) or not np.array_equal(rows[:, :P + 7], want) or rows[:, P + 7:].any():
             errs.append(f"{H}x{W}: packed observation rows differ")
+        # the same rows written by the step kernel itself (STEP_PACK_OBS, fused epilogue) over a short random trace
+        be.set_packed_output()
+        for s_ in range(6):
+            bb = np.stack([rng.integers(0, H, N), rng.integers(0, W, N), rng.integers(0, H, N), rng.integers(0, W, N)], 1).astype(np.int32)
+            op = rng.integers(0, 35, N).astype(np.int32)
+            r, t = be.step("bbox", bb, op, STEP_AUTORESET | STEP_PACK_OBS)
+            fused = be.fused_packed()
+            want = np.concatenate([be.get("grid").reshape(N, P).view(np.uint8), be.get("grid_dim").view(np.uint8),
+                                   r.astype("<i4").view(np.uint8).reshape(N, 4), t.reshape(N, 1)], 1)
+            if not np.array_equal(fused[:, :P + 7], want) or fused[:, P + 7:].any() or not np.array_equal(fused, be.packed_obs()):
+                errs.append(f"{H}x{W}: fused packed rows differ at step {s_}")
+                break
     return errs
 
 

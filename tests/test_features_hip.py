@@ -169,6 +169,7 @@ def test_sharded_env_over_rccl_world_size_1():
     try:
         env = ShardedVecEnv(256, lambda n, lo, hi: ARCVecEnv(O2ARCv2Env, n, _loader(), max_grid_size=(12, 12), seed=5, env_base=lo))
         env.reset()
+        assert env.fused  # the packed rows come out of the step kernel itself (STEP_PACK_OBS)
         g = torch.Generator().manual_seed(2)
         for _ in range(6):
             bb = torch.randint(0, 12, (256, 4), generator=g, dtype=torch.int32).cuda()
@@ -309,3 +310,24 @@ def test_fused_flat_rows_at_full_size():
                 fused = b.flat.clone()
                 assert torch.equal(fused, b.flat_obs(filtered=filtered)), (filtered, i)
         assert b.status() == 0
+
+
+def test_lean_step_kernel_with_the_fused_packed_rows():
+    """ARCVecEnv.enable_packed_rows at 30 x 30: the lean instantiation (compile-time flags autoreset | elide | pack, constant
+    grid dimensions) writes packed rows equal to the stand-alone arcle_pack_obs of the same state, every step."""
+    import torch
+    import bench
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.engine import EnvBatch
+    n, K = 4096, 16
+    v = ARCVecEnv(O2ARCv2Env, n, _loader(), autoreset=True, seed=5)
+    packed = v.enable_packed_rows()
+    v.reset()
+    bbox_np, op_np = bench.make_actions(K, n, 21)
+    for i in range(K):
+        obs, reward, term, trunc, info = v.step_bbox(torch.from_numpy(bbox_np[i]).cuda(), torch.from_numpy(op_np[i]).cuda())
+        fused = packed.clone()
+        assert torch.equal(fused, v.batch.packed_obs()), i
+        g, gd, r, t = EnvBatch.unpack_obs(fused, 30, 30)
+        assert torch.equal(g, obs["grid"]) and torch.equal(gd, obs["grid_dim"]) and torch.equal(r, v.batch.reward) and torch.equal(t, term)
+    assert v.batch.status() == 0
