@@ -258,6 +258,51 @@ def rollout_leg(batch, bbox, op, dev, T=128, reps=8):
             "note": "state stays on chip between steps; not comparable with the per-step HBM roofline above"}
 
 
+def research_env_leg(dev, n, bbox, op, K=200, reps=3):
+    """NOT the headline metric: the step the reference's training script runs (agents/env.py + agents/train.py:61-68) — op 33 =
+    crop, dense reward, TimeLimit(100) truncation, next-step autoreset onto a NEW device-drawn task with colour-permutation +
+    rot90 augmentation, and the FilterO2ARC + FlattenObservation row of every env written by the step kernel — all in ONE launch
+    per step (feature instantiation), graph-replayed."""
+    from arcle_amd import actions
+    from arcle_amd.engine import STEP_FLAT_OBS
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+
+    class Crop(O2ARCv2Env):  # agents/env.py:23-28
+        def create_operations(self):
+            ops = super().create_operations()
+            ops[33] = actions.reset_sel(actions.crop_grid)
+            return ops
+    v = ARCVecEnv(Crop, n, SyntheticLoader(n_tasks=400, seed=1, max_size=(30, 30)), device=dev, seed=7, autoreset="resample", augment=("permute", "rot90"),
+                  dense_reward=True, max_episode_steps=100)
+    v.reset()
+    rows = v.batch.set_flat_output(filtered=True)
+    FL = v.flags | STEP_FLAT_OBS
+    K = min(K, bbox.shape[0])
+    st = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        csh = torch.cuda.current_stream(dev).cuda_stream
+        for i in range(K):
+            v.batch.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, csh)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1) * 1e-3 / K)
+    sec = float(np.median(ts))
+    assert v.batch.status() == 0
+    return {"mode": "ARCVecEnv(autoreset='resample', augment, dense_reward, max_episode_steps=100) + fused FilterO2ARC rows",
+            "value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6, "row_bytes": int(rows.shape[1]),
+            "note": "one launch per step; 2710-byte observation row per env and step written by the step kernel"}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def _spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per rank)."""
@@ -517,7 +562,7 @@ def main():
             out["floodfill"] = {"share_of_actions": float(((op_np >= 10) & (op_np < 20)).mean()),
                                 "frontier_rounds": frontier_rounds_sample(grids, seeds)}
         if world == 1 and not a.no_extras and a.config == "c3":
-            out["extras"] = {"rollout": rollout_leg(batch, bbox, op, dev)}
+            out["extras"] = {"rollout": rollout_leg(batch, bbox, op, dev), "research_env": research_env_leg(dev, n, bbox, op)}
         if world == 1 and not a.no_cpu_baseline and a.config == "c3":
             out["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(out), flush=True)
