@@ -314,3 +314,25 @@ def test_custom_operation_table_like_reference_subclasses():
     nofill = nofill[:10] + nofill[20:]
     venv = ARCVecEnv(O2ARCv2Env, 32, SyntheticLoader(n_tasks=4, seed=2), operations=nofill)
     assert len(venv.op_names) == 25 and venv.op_names[-1] == "Submit"
+
+
+def test_hip_config5_workload_vs_oracle():
+    """bench.py's c5 workload itself (ARCEnv 27-op table, stripes / blobs / spiral grids, 70 % FloodFill from in-bounds point
+    seeds): every env of a 1024-env batch equals the oracle after every step — the row-board flood fill under load, mixed with
+    the other ops of the table."""
+    import bench
+    N, S = 1024, 24
+    ops = O.arc_ops()
+    inp, dims, ans, adims = bench.make_tasks_c5(N, 11)
+    bbox, op = bench.make_actions_c5(S, N, 13)
+    be, orc = B.HipBackend(N, 30, 30, -1, "arc", ops), B.OracleBackend(N, 30, 30, -1, "arc", ops)
+    for b_ in (be, orc):
+        b_.set_tasks(inp, dims, ans, adims)
+        b_.reset()
+    for s in range(S):
+        r1, t1 = be.step("bbox", bbox[s], op[s])
+        r2, t2 = orc.step("bbox", bbox[s], op[s])
+        assert np.array_equal(r1, r2) and np.array_equal(t1, t2), s
+        for f in ("grid", "grid_dim", "clip", "clip_dim"):
+            assert np.array_equal(be.get(f), orc.get(f)), (s, f)
+    assert be.status() == orc.status() == 0
