@@ -220,8 +220,57 @@ class QuirkScript:
         return 28, m                               # CopyI: any(sel>0) false -> no-op
 
 
+# ---- large same-colour regions for FloodFill (the reference's recursive DFS, color.py:8-30, is the pin) -------------------
+class FloodScript:
+    """Tasks: stripes, coarse 3-colour blobs, a 1-wide spiral corridor (long, winding regions); actions: FloodFill from a random
+    in-bounds point most of the time, now and then a Color rectangle or a CopyFromInput so that regions change and come back."""
+
+    def task(self, n, H, W):
+        rng = RD.SplitMix64(900 + n)
+        kind = n % 3
+        ii, jj = np.arange(H)[:, None], np.arange(W)[None, :]
+        if kind == 0:
+            p = 2 + rng.below(4)
+            g = (((ii // p) + (jj // p if rng.below(3) == 0 else 0)) % 2) * (1 + rng.below(9))
+        elif kind == 1:
+            coarse = np.array([[rng.below(3) for _ in range(W // 5 + 1)] for _ in range(H // 5 + 1)])
+            g = np.kron(coarse, np.ones((5, 5), np.int64))[:H, :W] + 1
+        else:
+            g = np.full((H, W), 2)
+            top, left, bot, right = 0, 0, H - 1, W - 1
+            while top <= bot and left <= right:
+                g[top, left:right + 1] = 1
+                g[top:bot + 1, right] = 1
+                if bot > top + 1:
+                    g[bot, left + 2:right + 1] = 1
+                if right > left + 2 and bot > top + 2:
+                    g[top + 2:bot + 1, left + 2] = 1
+                top, left, bot, right = top + 2, left + 2, bot - 2, right - 2
+                if top <= bot and left <= right:
+                    g[top, left] = 1
+        a = np.asarray(g, np.int8)
+        return a, a.copy()
+
+    def __call__(self, rng, s, n, H, W, n_ops):
+        m = np.zeros((H, W), np.int8)
+        r = rng.below(10)
+        if r < 7:
+            m[rng.below(H), rng.below(W)] = 1
+            return 10 + rng.below(10), m            # FloodFill c from a point
+        if r == 7:
+            x, y = rng.below(H), rng.below(W)
+            m[x:x + 1 + rng.below(6), y:y + 1 + rng.below(6)] = 1
+            return rng.below(10), m                 # Color c on a small rectangle (cuts corridors / merges regions)
+        if r == 8:
+            return 31, m                            # CopyFromInput: the original regions come back
+        m[rng.below(H), rng.below(W)] = 1
+        m[rng.below(H), rng.below(W)] = 1           # two seeds (or one, twice): FloodFill only acts when sum == 1
+        return 10 + rng.below(10), m
+
+
 def main():
     RD.import_reference()
+    sys.setrecursionlimit(5000)  # (the reference's DFS recurses once per cell of the region)
     capture("o2arc_05", "o2arc", 5, 5, -1, 32, 128, 101)
     capture("o2arc_10", "o2arc", 10, 10, 3, 32, 128, 102)
     capture("o2arc_30", "o2arc", 30, 30, -1, 32, 160, 103)
@@ -235,6 +284,8 @@ def main():
     capture("raw_05", "raw", 5, 5, -1, 8, 96, 109)
     capture("raw_30", "raw", 30, 30, 2, 4, 64, 110)
     capture("quirks_30", "o2arc", 30, 30, -1, 8, 300, 111, script=QuirkScript(), full_every=50)
+    capture("flood_30", "o2arc", 30, 30, -1, 12, 48, 114, script=FloodScript(), full_every=12)
+    capture("flood_17x21", "o2arc", 17, 21, -1, 9, 48, 115, script=FloodScript(), full_every=12)
 
 
 if __name__ == "__main__":
