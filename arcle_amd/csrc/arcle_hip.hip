@@ -90,6 +90,11 @@ ARCLE_DEV uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 
 // neighbouring lane's value through DPP wave shifts (no LDS): lane j-1 / lane j+1, 0 at the wave boundary
 ARCLE_DEV uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 ARCLE_DEV uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+// lane j-K / j+K inside the lane's 16-lane DPP row (row_shr:K / row_shl:K), 0 where the source falls outside the row
+template <int K>
+ARCLE_DEV uint32_t row_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xf, 0xf, true); }
+template <int K>
+ARCLE_DEV uint32_t row_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + K, 0xf, 0xf, true); }
 ARCLE_DEV uint32_t bfrev(uint32_t v) { return __builtin_bitreverse32(v); }  // v_bfrev_b32
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }  // full-rate 24-bit multiply

@@ -828,19 +828,22 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
     // corridor legs / row transitions of the region, not its cell-path length (a 1-wide spiral: ~60 legs against 434 cell steps).
     const uint32_t Wb = (uint32_t)p.W;
     const uint32_t M = rows_from16(w, M16, Wb), rM = xl::bfrev(M);
+    // column-wise run masks for vertical steps of 2, 4 and 8 rows: bit j of Pkd says rows i-k+1..i are all fillable in column j
+    // (Pku: rows i..i+k-1).  The k-row shifts are DPP row shifts — they stop at the 16-lane row boundary, which only makes those
+    // steps conservative there; the 1-row wave shifts cross it.
+    const uint32_t P2d = M & xl::lane_prev(M), P2u = M & xl::lane_next(M);
+    const uint32_t P4d = P2d & xl::row_prev<2>(P2d), P4u = P2u & xl::row_next<2>(P2u);
+    const uint32_t P8d = P4d & xl::row_prev<4>(P4d), P8u = P4u & xl::row_next<4>(P4u);
     uint32_t F = (w.lane == sx) ? (1u << sy) : 0u;
-    for (int it = 0; it < ARCLE_MAX_CELLS; it++) {
-      for (int v = 0; v < ARCLE_MAX_CELLS / 4 + 1; v++) {  // vertical closure, 4 steps per convergence ballot
-        const uint32_t F0 = F;
-#pragma unroll
-        for (int u = 0; u < 4; u++) F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;  // rows i-1 / i+1 (0 beyond the wave)
-        if (!w.any(F != F0)) break;
-      }
+    for (int it = 0; it < 2 * ARCLE_MAX_CELLS; it++) {  // one pass = vertical steps of 1, 2, 4, 8 rows (up to 15 rows of a run), then
+      const uint32_t F0 = F;                            // the horizontal fill of every row; one convergence ballot per pass
+      F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;   // rows i-1 / i+1 (0 beyond the wave)
+      F |= (xl::row_prev<2>(F) & P2d) | (xl::row_next<2>(F) & P2u);
+      F |= (xl::row_prev<4>(F) & P4d) | (xl::row_next<4>(F) & P4u);
+      F |= (xl::row_prev<8>(F) & P8d) | (xl::row_next<8>(F) & P8u);
       const uint32_t rF = xl::bfrev(F);
-      const uint32_t Fh = F | ((M ^ (M + F)) & M) | xl::bfrev((rM ^ (rM + rF)) & rM);
-      const bool grew = w.any(Fh != F);
-      F = Fh;
-      if (!grew) break;
+      F |= ((M ^ (M + F)) & M) | xl::bfrev((rM ^ (rM + rF)) & rM);
+      if (!w.any(F != F0)) break;
     }
     vis = rows_to16(w, F, Wb);
   } else {

@@ -79,6 +79,18 @@ ARCLE_DEV uint32_t lane_next(uint32_t v) {
   uint32_t r = shfl(v, (me + 1) & 63);
   return me == 63 ? 0u : r;
 }
+template <int K>
+ARCLE_DEV uint32_t row_prev(uint32_t v) {  // row_shr:K — lane j-K of the same 16-lane row, else 0
+  int me = cur_lane;
+  uint32_t r = shfl(v, (me - K) & 63);
+  return (me & 15) < K ? 0u : r;
+}
+template <int K>
+ARCLE_DEV uint32_t row_next(uint32_t v) {  // row_shl:K
+  int me = cur_lane;
+  uint32_t r = shfl(v, (me + K) & 63);
+  return (me & 15) + K > 15 ? 0u : r;
+}
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return shfl(v, lane); }
 typedef uint32_t U4 __attribute__((vector_size(16)));
 typedef uint32_t U2 __attribute__((vector_size(8)));
