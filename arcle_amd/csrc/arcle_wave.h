@@ -841,6 +841,7 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
       F |= (xl::row_prev<2>(F) & P2d) | (xl::row_next<2>(F) & P2u);
       F |= (xl::row_prev<4>(F) & P4d) | (xl::row_next<4>(F) & P4u);
       F |= (xl::row_prev<8>(F) & P8d) | (xl::row_next<8>(F) & P8u);
+      F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;   // (again: lets a run cross the 16-lane row boundary in the same pass)
       const uint32_t rF = xl::bfrev(F);
       F |= ((M ^ (M + F)) & M) | xl::bfrev((rM ^ (rM + rF)) & rM);
       if (!w.any(F != F0)) break;
