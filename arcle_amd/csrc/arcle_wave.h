@@ -1006,9 +1006,10 @@ ARCLE_DEV bool load_sampled_task(const Wave& w, Rec& r, int env, U4& input_out) 
 // init_state (base.py:155-166 + o2arcenv.py:16-34 / arcenv.py:81-89), counters as in reset (base.py:73-79)
 // ------------------------------------------------------------------------------------------------
 // `input`: the input plane when the caller just wrote it (a fresh task), else it is loaded
-ARCLE_DEV void init_state(const Wave& w, Rec& r, I2& cnt, const U4* input = nullptr) {
+// (by value + flag: a pointer to a caller's local would force that local into scratch memory)
+ARCLE_DEV void init_state(const Wave& w, Rec& r, I2& cnt, bool have_input = false, U4 input = U4{0u, 0u, 0u, 0u}) {
   const StepParams& p = w.p;
-  const U4 in = input ? *input : w.load(ARCLE_PL_INPUT);
+  const U4 in = have_input ? input : w.load(ARCLE_PL_INPUT);
   w.store(ARCLE_PL_GRID, in);
   U4 z = u4_zero();
   if (p.plane[ARCLE_PL_SELECTED]) w.store(ARCLE_PL_SELECTED, z);
@@ -1095,7 +1096,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       U4 in = u4_zero();
       const bool resample = FEAT && (flags & ARCLE_STEP_RESAMPLE);
       if (resample) ok = load_sampled_task(w, r, w.env, in);
-      if (ok) init_state(w, r, cnt0, resample ? &in : nullptr);
+      if (ok) init_state(w, r, cnt0, resample, in);
       else xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
       out.term = 0;
       out.bytes = (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
@@ -1662,7 +1663,7 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
     return;
   }
   I2 cnt;
-  init_state(w, r, cnt, &in);
+  init_state(w, r, cnt, true, in);
   store_rec(p, env, lane, r);
   store_cnt(p, env, lane, cnt);
 }
@@ -1699,7 +1700,10 @@ ARCLE_DEV void flat_plane(const Wave& w, FlatRow& fr, int pl) {
   fr.off += P;
 }
 ARCLE_DEV void flat_scalar(const Wave& w, FlatRow& fr, const Rec& r, int field, int n) {
-  if (w.lane < n) fr.row[fr.off + w.lane] = (int8_t)r.ub(field + (w.lane < n ? w.lane : 0));
+  // (n <= 2 bytes of one record dword — the 2-byte fields start at even offsets: a constant register index and a per-lane shift,
+  // not a per-lane index into the record, which would put the record into scratch memory)
+  const uint32_t word = r.w[field >> 2];
+  if (w.lane < n) fr.row[fr.off + w.lane] = (int8_t)((word >> (8 * ((field & 3) + (w.lane < n ? w.lane : 0)))) & 0xffu);
   fr.off += n;
 }
 ARCLE_HD int flat_obs_len(const StepParams& p, int filtered) {

@@ -18,7 +18,7 @@ for o in ops_list:
     batch = EnvBatch(n, 30, 30, -1, "o2arc", dev)
     batch.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
     batch.set_tasks_padded(*bench.make_tasks(n, 1)); batch.reset()
-    FL = batch.elide_flag | bench.STEP_AUTORESET  # the flags ARCVecEnv / bench.py step with
+    FL = batch.elide_flag | bench.STEP_AUTORESET | int(os.environ.get("OPPROF_EXTRA_FLAGS", "0"))  # the flags ARCVecEnv / bench.py step with (+ e.g. 64 to force the feature instantiation)
     ops = torch.from_numpy(op_np).to(dev) if o < 0 else torch.full((K, n), o, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     for i in range(K):
