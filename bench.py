@@ -258,6 +258,37 @@ def rollout_leg(batch, bbox, op, dev, T=128, reps=8):
             "note": "state stays on chip between steps; not comparable with the per-step HBM roofline above"}
 
 
+def host_actions_leg(batch, bbox, op, FL, dev, K=200, reps=3):
+    """NOT the headline metric: the same steps with the action batch (bbox int32 [N,4] + op int32 [N] = 20 B per env) copied from
+    pinned HOST memory before every step, on the launch stream (graph-replayed: 2 copy nodes + 1 kernel node per step) — the
+    PCIe-inclusive rate a host-resident policy would see."""
+    K = min(K, bbox.shape[0])
+    hb, ho = bbox[:K].cpu().pin_memory(), op[:K].cpu().pin_memory()
+    db, do = torch.empty_like(bbox[0]), torch.empty_like(op[0])
+    st = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        csh = torch.cuda.current_stream(dev).cuda_stream
+        for i in range(K):
+            db.copy_(hb[i], non_blocking=True)
+            do.copy_(ho[i], non_blocking=True)
+            batch.step_bbox_ptr(db.data_ptr(), do.data_ptr(), FL, csh)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1) * 1e-3 / K)
+    sec = float(np.median(ts))
+    return {"mode": "bbox + op copied from pinned host memory before every step (20 B per env)", "value": batch.N / sec,
+            "unit": "env-steps/s", "us_per_step_batch": sec * 1e6, "host_bytes_per_step": int(batch.N * 20)}
+
+
 def research_env_leg(dev, n, bbox, op, K=200, reps=3):
     """NOT the headline metric: the step the reference's training script runs (agents/env.py + agents/train.py:61-68) — op 33 =
     crop, dense reward, TimeLimit(100) truncation, next-step autoreset onto a NEW device-drawn task with colour-permutation +
@@ -562,7 +593,8 @@ def main():
             out["floodfill"] = {"share_of_actions": float(((op_np >= 10) & (op_np < 20)).mean()),
                                 "frontier_rounds": frontier_rounds_sample(grids, seeds)}
         if world == 1 and not a.no_extras and a.config == "c3":
-            out["extras"] = {"rollout": rollout_leg(batch, bbox, op, dev), "research_env": research_env_leg(dev, n, bbox, op)}
+            out["extras"] = {"rollout": rollout_leg(batch, bbox, op, dev), "research_env": research_env_leg(dev, n, bbox, op),
+                             "host_actions": host_actions_leg(batch, bbox, op, FL, dev)}
         if world == 1 and not a.no_cpu_baseline and a.config == "c3":
             out["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(out), flush=True)
