@@ -193,6 +193,8 @@ class ARCVecEnv:
         b = self.batch
         if self._host_slots and operation is not None:
             self._apply_host_ops(operation, action_of)
+            if self.flags & STEP_PACK_OBS:  # the step kernel packed its rows before the host callables ran: pack again
+                b.packed_obs(b.packed)
         if self.dense_reward:
             d = b.dense.to(torch.float32)
             reward = reward.to(torch.float32) * 100.0 - 1.0 + d[:, 0] / d[:, 1]
