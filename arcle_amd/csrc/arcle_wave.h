@@ -414,16 +414,29 @@ struct Sel {
   bool any_nz, any_pos;
   int x0, x1, y0, y1;  // _get_bbox of the truthy cells (object.py:49-58); valid iff any_nz
   bool is_rect;        // built from a bbox / point tuple: every cell of the bbox is 1
+  int one_cell;        // mask payload (16 <= W <= 32): flat index of the ONLY truthy cell, -1 if there are none or several
 };
 
 // Cell masks of the selection.  For a bbox / point tuple they are a rectangle mask built where an op needs it (most ops of
 // the O2ARC table read only the tuple: FloodFill, Copy, Paste, CropGrid, ResizeGrid), for a mask payload ingest_cells made them.
-ARCLE_DEV uint32_t sel_nz(const Wave& w, const Sel& s) { return s.is_rect ? w.rect16(s.x0, s.x1, s.y0, s.y1) : s.nz; }
-ARCLE_DEV uint32_t sel_pos(const Wave& w, const Sel& s) { return s.is_rect ? w.rect16(s.x0, s.x1, s.y0, s.y1) : s.pos; }
+ARCLE_DEV uint32_t sel_nz(const Wave& w, const Sel& s) {
+  return (s.is_rect && w.ingress != INGRESS_MASK) ? w.rect16(s.x0, s.x1, s.y0, s.y1) : s.nz;
+}
+// any cell with sel > 0 ?
+ARCLE_DEV bool sel_any_pos(const Wave& w, const Sel& s);
+ARCLE_DEV uint32_t sel_pos(const Wave& w, const Sel& s) {
+  if (w.ingress == INGRESS_MASK) return pos16(s.vals) & w.valid16;  // (derived where an op needs it: object ops, Copy, Paste)
+  return w.rect16(s.x0, s.x1, s.y0, s.y1);
+}
+
+ARCLE_DEV bool sel_any_pos(const Wave& w, const Sel& s) {
+  if (w.ingress != INGRESS_MASK) return s.any_pos;
+  return s.any_nz && w.any(sel_pos(w, s) != 0);
+}
 
 // the raw int8 selection values (`selected = sel`, keep_sel object.py:38; mask ingress keeps what it loaded)
 ARCLE_DEV U4 sel_values(const Wave& w, const Sel& s) {
-  if (!s.is_rect) return s.vals;
+  if (!s.is_rect || w.ingress == INGRESS_MASK) return s.vals;
   return u4_and1(w.expand16(sel_nz(w, s)), 0x01010101u);
 }
 
@@ -497,10 +510,12 @@ ARCLE_DEV bool ingest_scalar(const Wave& w, Sel& s, const U4& payload) {
     return true;
   }
   s.is_rect = true;
+  s.one_cell = -1;
   s.any_nz = s.any_pos = (s.x0 <= s.x1 && s.y0 <= s.y1);
   return ok;
 }
-ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload) {
+// `want_rect`: the op can take its rectangle shortcuts (object ops, Copy, Crop) — worth testing whether a mask IS its bounding box
+ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload, bool want_rect = false) {
   const StepParams& p = w.p;
   if (w.ingress != INGRESS_MASK) {  // (masks on demand: sel_nz / sel_pos)
     s.nz = s.pos = 0;
@@ -509,13 +524,35 @@ ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload) {
   }
   const U4 v = payload;
   s.is_rect = false;
+  s.one_cell = -1;
   s.vals = v;
   s.nz = nz16(v) & w.valid16;
-  s.pos = pos16(v) & w.valid16;
+  s.pos = 0;  // (masks: sel_pos / sel_any_pos derive it from `vals` on demand)
   s.any_nz = w.any(s.nz != 0);
-  s.any_pos = w.any(s.pos != 0);
+  s.any_pos = false;
   s.x0 = s.x1 = s.y0 = s.y1 = 0;
-  if (s.any_nz) {
+  if (s.any_nz && w.fw != FW_GENERIC) {
+    // _get_bbox (object.py:49-58) for 16 <= W <= 32, on the scalar unit: rows from the first / last truthy flat index (one ballot
+    // + two v_readlane), columns from the OR of every window's column bits (one DPP OR-reduction, no LDS round trips)
+    const unsigned long long lanes = xl::ballot(s.nz != 0);
+    const int l0 = __builtin_ctzll(lanes), l1 = 63 - __builtin_clzll(lanes);
+    const uint32_t m0 = xl::readlane(s.nz, l0), m1 = xl::readlane(s.nz, l1);
+    const int fmin = 16 * l0 + __builtin_ctz(m0), fmax = 16 * l1 + 31 - __builtin_clz(m1);
+    if (fmin == fmax) s.one_cell = fmin;
+    s.x0 = (int)(((uint32_t)fmin * p.div_magic) >> 16);
+    s.x1 = (int)(((uint32_t)fmax * p.div_magic) >> 16);
+    const uint32_t cols = xl::wave_or(((s.nz & w.lm) << w.c0) | (s.nz >> w.k1));  // first row segment at column c0, second at column 0
+    s.y0 = __builtin_ctz(cols);
+    s.y1 = 31 - __builtin_clz(cols);
+    if (want_rect) {
+      // a mask that is exactly its bounding box filled with ones (what BBoxWrapper / PointWrapper produce on the host,
+      // bbox.py:22-30,43-49) takes the rectangle paths of the ops: same results, far fewer instructions
+      const uint32_t rm = w.rect16(s.x0, s.x1, s.y0, s.y1);
+      const U4 ones = u4_and1(w.expand16(rm), 0x01010101u);
+      const bool same = s.nz == rm && v[0] == ones[0] && v[1] == ones[1] && v[2] == ones[2] && v[3] == ones[3];
+      s.is_rect = !w.any(!same);
+    }
+  } else if (s.any_nz) {
     // _get_bbox (object.py:49-58): rows via first/last truthy flat index, columns via min/max reduction
     int cmin = 127, cmax = -1, fmin = 4096, fmax = -1;
     int r = w.r0, c = w.c0, k = 0;
@@ -794,7 +831,15 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
   if (sel.is_rect) {  // np.sum(sel) == 1  <=>  1x1 rectangle
     if (!(sel.any_nz && sel.x0 == sel.x1 && sel.y0 == sel.y1)) return;
     seed = sel.x0 * p.W + sel.y0;
+  } else if (sel.one_cell >= 0) {
+    // one truthy cell: np.sum(sel) is its value — the fill happens iff that value is 1 (color.py:91), seeded there
+    seed = sel.one_cell;
+    const uint32_t mine = u4_byte(sel.vals, seed & 15);
+    if (xl::uniform(xl::shfl(mine, seed >> 4)) != 1u) return;
   } else {
+    if (!sel.any_nz) return;  // an all-zero mask sums to 0
+    // several truthy cells, none of them negative: the sum is at least 2 (the usual multi-cell selection — no reduction needed)
+    if (w.fw != FW_GENERIC && !w.any(sel.nz != sel_pos(w, sel))) return;
     int sum = 0, mx = -128;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -1130,7 +1175,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
 
   Sel sel;
   if (!ingest_scalar(w, sel, payload)) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
-  ingest_cells(w, sel, payload);
+  ingest_cells(w, sel, payload, kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP || kind == ARCLE_OP_COPY || kind == ARCLE_OP_CROP_GRID);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
   if (FEAT && ING == INGRESS_MASK && (flags & ARCLE_STEP_CONTINUE_RULE) &&
       (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
@@ -1301,7 +1346,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       break;
     }
     case ARCLE_OP_COPY: {  // object.py:291-312
-      if (!sel.any_pos) break;
+      if (!sel_any_pos(w, sel)) break;
       const int ss_h = arg ? r.gh() : r.in_h(), ss_w = arg ? r.gw() : r.in_w();
       if (sel.x1 > ss_h || sel.y1 > ss_w) break;  // :301 (sic: > not >=)
       U4 src;
@@ -1322,7 +1367,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       break;
     }
     case ARCLE_OP_PASTE: {  // object.py:317-348
-      if (!sel.any_pos) break;
+      if (!sel_any_pos(w, sel)) break;
       const int h = r.ch(), wd = r.cw();
       if (h == 0 || wd == 0) break;  // :334
       const int ex = imin(sel.x0 + h, p.H), ey = imin(sel.y0 + wd, p.W);  // :340-341 clipped to HxW, not grid_dim

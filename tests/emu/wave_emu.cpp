@@ -92,6 +92,10 @@ ARCLE_DEV uint32_t row_next(uint32_t v) {  // row_shl:K
   return (me & 15) + K > 15 ? 0u : r;
 }
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return shfl(v, lane); }
+ARCLE_DEV uint32_t wave_or(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v |= shfl(v, cur_lane ^ o);
+  return v;
+}
 typedef uint32_t U4 __attribute__((vector_size(16)));
 typedef uint32_t U2 __attribute__((vector_size(8)));
 // wave-uniform scalar loads: every lane reads the same address
