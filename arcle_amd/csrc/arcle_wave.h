@@ -455,9 +455,16 @@ ARCLE_DEV U4 load_payload(const Wave& w, int env, size_t step, const void* sel) 
   } else {
     const int8_t* src = reinterpret_cast<const int8_t*>(sel) + e * (size_t)p.P + 16 * w.lane;
     if ((p.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(sel) & 3) == 0)) {
+      // rows of P bytes are only 4-byte aligned: a lane whose 16 bytes lie inside the row issues ONE dword-aligned 16-byte load
+      // (unaligned vector access is legal on gfx9+ global memory), the lane holding the row's tail loads dword by dword
+      typedef U4 __attribute__((aligned(4))) U4a4;
+      if (16 * w.lane + 16 <= p.P) {
+        v = *reinterpret_cast<const U4a4*>(src);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (16 * w.lane + 4 * i < p.P) v[i] = *reinterpret_cast<const uint32_t*>(src + 4 * i);
+        for (int i = 0; i < 4; i++)
+          if (16 * w.lane + 4 * i < p.P) v[i] = *reinterpret_cast<const uint32_t*>(src + 4 * i);
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 16; k++)
