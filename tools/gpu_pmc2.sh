@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift
   rm -rf /tmp/pmc_$name
-  rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o p --output-format csv -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline > /tmp/pmc_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o p --output-format csv -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras --no-graph --no-ramp --regions 2 > /tmp/pmc_$name.log 2>&1
   python - "/tmp/pmc_$name" <<'PY'
 import sys, csv, glob, collections
 acc=collections.defaultdict(list)
