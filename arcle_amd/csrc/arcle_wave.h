@@ -522,7 +522,8 @@ ARCLE_DEV bool ingest_scalar(const Wave& w, Sel& s, const U4& payload) {
   return ok;
 }
 // `want_rect`: the op can take its rectangle shortcuts (object ops, Copy, Crop) — worth testing whether a mask IS its bounding box
-ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload, bool want_rect = false) {
+// `want_bbox`: the op reads the selection's bounding box at all (Color and FloodFill do not)
+ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload, bool want_rect = false, bool want_bbox = true) {
   const StepParams& p = w.p;
   if (w.ingress != INGRESS_MASK) {  // (masks on demand: sel_nz / sel_pos)
     s.nz = s.pos = 0;
@@ -546,6 +547,7 @@ ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload, bool want_
     const uint32_t m0 = xl::readlane(s.nz, l0), m1 = xl::readlane(s.nz, l1);
     const int fmin = 16 * l0 + __builtin_ctz(m0), fmax = 16 * l1 + 31 - __builtin_clz(m1);
     if (fmin == fmax) s.one_cell = fmin;
+    if (!want_bbox) return;
     s.x0 = (int)(((uint32_t)fmin * p.div_magic) >> 16);
     s.x1 = (int)(((uint32_t)fmax * p.div_magic) >> 16);
     const uint32_t cols = xl::wave_or(((s.nz & w.lm) << w.c0) | (s.nz >> w.k1));  // first row segment at column c0, second at column 0
@@ -1182,7 +1184,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
 
   Sel sel;
   if (!ingest_scalar(w, sel, payload)) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
-  ingest_cells(w, sel, payload, kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP || kind == ARCLE_OP_COPY || kind == ARCLE_OP_CROP_GRID);
+  ingest_cells(w, sel, payload, kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP || kind == ARCLE_OP_COPY || kind == ARCLE_OP_CROP_GRID,
+               kind != ARCLE_OP_COLOR && kind != ARCLE_OP_FLOODFILL);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
   if (FEAT && ING == INGRESS_MASK && (flags & ARCLE_STEP_CONTINUE_RULE) &&
       (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
