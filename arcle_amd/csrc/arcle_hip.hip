@@ -191,8 +191,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #endif
 }
 
-template <int ING, int FW>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams p) {
+template <int ING, int FW, int WC = 0>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams pa) {
+  StepParams p = pa;
+  if (WC == 30) {  // the standard 30 x 30 grid: dimensions as compile-time constants (as in arcle_step_kernel)
+    p.H = p.W = 30;
+    p.P = 900;
+    p.div_magic = 65536u / 30u + 1u;
+    p.nseg = 2;
+  }
   __shared__ BlockLDS lds;
   arcle::lut_init(lds.lut, (int)threadIdx.x);
   xl::wg_barrier();
@@ -596,7 +603,8 @@ static void launch_rollout_tbl(dim3 g, dim3 b, hipStream_t st, const StepParams&
 template <int ING>
 static int launch_rollout_ing(int fw, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   // (the rollout keeps planes in registers: lane predication does not matter, FW_FULL shares FW_FAST's code)
-  if (fw != arcle::FW_GENERIC) launch_rollout_tbl<ING, arcle::FW_FAST>(g, b, st, p);
+  if (fw != arcle::FW_GENERIC && p.H == 30 && p.W == 30) hipLaunchKernelGGL((arcle_rollout_kernel<ING, arcle::FW_FAST, 30>), g, b, 0, st, p);
+  else if (fw != arcle::FW_GENERIC) launch_rollout_tbl<ING, arcle::FW_FAST>(g, b, st, p);
   else launch_rollout_tbl<ING, arcle::FW_GENERIC>(g, b, st, p);
   return ARCLE_OK;
 }
