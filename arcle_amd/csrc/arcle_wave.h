@@ -826,11 +826,23 @@ ARCLE_DEV uint32_t rows_from16(const Wave& w, uint32_t m16, uint32_t Wb) {
   const uint32_t v = sh ? ((lo >> sh) | (c2 << (32u - sh))) : lo;
   return Wb == 32u ? v : (v & ((1u << Wb) - 1u));
 }
-ARCLE_DEV uint32_t rows_to16(const Wave& w, uint32_t rows, uint32_t Wb) {  // window = row r0 from column c0 (k1 cells), then row r0 + 1
-  const uint32_t R0 = xl::shfl(rows, w.r0 & 63), R1 = xl::shfl(rows, (w.r0 + 1) & 63);
-  const uint32_t lo = w.r0 > 63 ? 0u : (R0 >> (uint32_t)w.c0);
-  const uint32_t hi = (w.r0 + 1 > 63 || w.k1 >= 16) ? 0u : (R1 << (uint32_t)w.k1);
-  return (lo | hi) & 0xffffu;
+ARCLE_DEV uint32_t rows_to16(const Wave& w, uint32_t rows, uint32_t Wb) {  // window = row r0 from column c0 (k1 cells), then row r0 + 1 ...
+  if (Wb >= 16u) {  // at most two rows per window
+    const uint32_t R0 = xl::shfl(rows, w.r0 & 63), R1 = xl::shfl(rows, (w.r0 + 1) & 63);
+    const uint32_t lo = w.r0 > 63 ? 0u : (R0 >> (uint32_t)w.c0);
+    const uint32_t hi = (w.r0 + 1 > 63 || w.k1 >= 16) ? 0u : (R1 << (uint32_t)w.k1);
+    return (lo | hi) & 0xffffu;
+  }
+  uint32_t out = 0;  // narrow grids: a 16-cell window spans up to nseg rows
+  int k = 0, c = w.c0;
+  for (int sg = 0; sg < w.p.nseg; sg++) {
+    const int row = w.r0 + sg;
+    const uint32_t R = xl::shfl(rows, row & 63);
+    if (k < 16 && row <= 63) out |= ((R >> (uint32_t)c) << (uint32_t)k);
+    k += (int)Wb - c;
+    c = 0;
+  }
+  return out & 0xffffu;
 }
 
 template <int ACCT>
@@ -874,8 +886,8 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
   const uint32_t inside = w.rect16(0, gh - 1, 0, gw - 1);
   const uint32_t M16 = eq16(s.grid, col) & inside;  // fillable cells of this lane's window: same colour as the seed, inside grid_dim
   uint32_t vis;
-  if (w.fw != FW_GENERIC) {
-    // 16 <= W <= 32 (so H <= 64): ROW BOARD — lane i holds row i as a W-bit word.  A vertical step is two DPP wave shifts; a
+  if (w.fw != FW_GENERIC || (p.W <= 32 && p.H <= 64)) {
+    // W <= 32 and H <= 64 (always so for 16 <= W): ROW BOARD — lane i holds row i as a W-bit word.  A vertical step is two DPP wave shifts; a
     // horizontal fill closes every run of a row in ONE pass with the carry trick: adding the filled bits to the fillable mask
     // ripples a carry up through each run of ones that contains one, (M ^ (M + F)) & M are the cells it passed, and the same on the
     // bit-reversed words fills downwards.  The two alternate until neither adds a cell: the number of passes follows the number of
