@@ -28,6 +28,54 @@ def _table_of(env_cls):
     return list(probe.create_operations())
 
 
+class _LazyInfo(dict):
+    """A dict whose registered entries are computed on first access (d[k], d.get(k), `k in d`, iteration all see them)."""
+
+    def __init__(self, base):
+        super().__init__(base)
+        self._thunks = {}
+
+    def lazy(self, key, thunk):
+        self._thunks[key] = thunk
+
+    def _force(self, key=None):
+        for k in ([key] if key is not None else list(self._thunks)):
+            if k in self._thunks:
+                dict.__setitem__(self, k, self._thunks.pop(k)())
+
+    def __missing__(self, key):
+        if key in self._thunks:
+            self._force(key)
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        self._force(key)
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._thunks
+
+    def keys(self):
+        self._force()
+        return dict.keys(self)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._force()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._thunks)
+
+
 class ARCVecEnv:
     def __init__(self, env_cls, num_envs, data_loader=None, max_grid_size=(30, 30), colors=10, max_trial=None,
                  device=None, autoreset=False, operations=None, rng=None, seed=None, env_base=0,
@@ -39,7 +87,9 @@ class ARCVecEnv:
         seed / env_base: key of the device-side task draws (global env id = env_base + local index).
         max_episode_steps: TimeLimit — `truncated` turns True once an env has taken that many steps (agents/train.py:67).
         dense_reward: the research env's reward, sparse*100 - 1 + correct/total (agents/env.py:44-58), as float32.
-        augment: subset of ("permute", "rot90") — task augmentation at every (re)start (agents/env.py:31-42)."""
+        augment: subset of ("permute", "rot90") — task augmentation at every (re)start (agents/env.py:31-42).
+        Everything `reset` / `step_*` return lives on the device and is a VIEW of this env's buffers (obs planes, reward,
+        terminated, truncated, info entries): the next step overwrites them in place — copy what must outlive it."""
         self.env_cls, self.N = env_cls, int(num_envs)
         self.H, self.W = int(max_grid_size[0]), int(max_grid_size[1])
         self.colors = colors
@@ -96,14 +146,18 @@ class ARCVecEnv:
         return obs
 
     def _info(self):
+        """`info` of reset / step: zero-copy device views; the two entries that need a gather through the task table
+        (`task_index`, `subprob_index`) are produced when first read — a step that nobody asks for them launches nothing extra."""
         b = self.batch
-        info = {"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
-                "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1]}
+        if getattr(self, "_info_views", None) is None:  # the views themselves never change: built once
+            self._info_views = {"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
+                                "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1]}
+        info = _LazyInfo(self._info_views)
         if hasattr(b, "cur_task"):  # device tensors: which task-table entry / problem / pair every env runs right now
-            t = b.cur_task.long().clamp_min(0)
             info["table_index"] = b.cur_task
-            info["task_index"] = self._entry_problem[t]
-            info["subprob_index"] = self._entry_sub[t]
+            entry = lambda: b.cur_task.long().clamp_min(0)  # noqa: E731
+            info.lazy("task_index", lambda: self._entry_problem[entry()])
+            info.lazy("subprob_index", lambda: self._entry_sub[entry()])
         return info
 
     # ---- task table: Loader.parse's output, uploaded once -----------------------------------------------
@@ -198,8 +252,8 @@ class ARCVecEnv:
         if self.dense_reward:
             d = b.dense.to(torch.float32)
             reward = reward.to(torch.float32) * 100.0 - 1.0 + d[:, 0] / d[:, 1]
-        trunc = b.trunc.bool() if self.max_episode_steps is not None else self._no_trunc
-        return self._obs, reward, term.bool(), trunc, self._info()
+        trunc = b.trunc.view(torch.bool) if self.max_episode_steps is not None else self._no_trunc  # (0/1 bytes: zero-copy)
+        return self._obs, reward, term.view(torch.bool), trunc, self._info()
 
     def enable_packed_rows(self):
         """From now on every step also writes `batch.packed` ([N, R] uint8: grid | grid_dim | reward | terminated per env) from
