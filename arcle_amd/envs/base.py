@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import actions, spaces
-from ..engine import EnvBatch, ST_BAD_OP, ST_ROTATE_DOMAIN, STEP_RESET_ON_SUBMIT
+from ..engine import EnvBatch, ST_BAD_OP, ST_ROTATE_DOMAIN, STEP_FLAT_OBS, STEP_RESET_ON_SUBMIT
 from ..loaders import Loader
 
 
@@ -61,6 +61,59 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         if self._batch is None:
             self._batch = self._new_batch(1)
         return self._batch
+
+    # ---- one-env fast path: the whole state crosses PCIe as ONE flattened row (written by the step kernel itself) ---------
+    def _io(self):
+        """Persistent staging buffers of the single env: pinned host + device tensors for the action, the flattened
+        observation row (arcle_set_flat_output) and the step outputs."""
+        if getattr(self, "_io_bufs", None) is None:
+            b = self.batch
+            flat = b.set_flat_output(False)
+            pin = torch.cuda.is_available()
+            mk = lambda shape, dt: torch.zeros(shape, dtype=dt, pin_memory=pin)  # noqa: E731
+            self._io_bufs = dict(flat=flat, h_flat=mk(tuple(flat.shape), torch.int8), h_sel=mk((1, self.H, self.W), torch.int8),
+                                 d_sel=torch.zeros((1, self.H, self.W), dtype=torch.int8, device=b.device), h_op=mk((1,), torch.int32),
+                                 d_op=torch.zeros(1, dtype=torch.int32, device=b.device), h_cnt=mk((1, 2), torch.int32),
+                                 h_reward=mk((1,), torch.int32))
+        return self._io_bufs
+
+    def _flat_layout(self):
+        """(key path, length) of the full flattened row in the order arcle_flatten_obs writes it (FlattenObservation's sorted
+        keys, arcle_amd/csrc/arcle_wave.h `flat_row`)."""
+        P, kind = self.H * self.W, self.KIND
+        lay = []
+        if kind != "raw":
+            lay += [(("clip",), P), (("clip_dim",), 2)]
+        lay += [(("grid",), P), (("grid_dim",), 2), (("input",), P), (("input_dim",), 2)]
+        if kind == "o2arc":
+            o = "object_states"
+            lay += [((o, "active"), 1), ((o, "background"), P), ((o, "object"), P), ((o, "object_dim"), 2), ((o, "object_pos"), 2),
+                    ((o, "object_sel"), P), ((o, "rotation_parity"), 1), (("selected",), P)]
+        lay += [(("terminated",), 1), (("trials_remain",), 1)]
+        return lay
+
+    def _state_from_row(self, row):
+        """The reference's obs dict (fresh numpy int8 arrays) from one flattened row (numpy int8 [L])."""
+        P, st, off = self.H * self.W, {}, 0
+        for path, n in self._flat_layout():
+            v = row[off:off + n].copy()
+            off += n
+            if n == P:
+                v = v.reshape(self.H, self.W)
+            d = st
+            for k in path[:-1]:
+                d = d.setdefault(k, {})
+            d[path[-1]] = v
+        return st
+
+    def _fetch_state(self, b, launch=True):
+        """Current state as the obs dict through one device->host copy of the flattened row."""
+        io = self._io()
+        if launch:
+            b.flat_obs(out=b._flat_buf, filtered=False)
+        io["h_flat"].copy_(io["flat"], non_blocking=True)
+        torch.cuda.synchronize(b.device)
+        return self._state_from_row(io["h_flat"][0].numpy())
 
     @staticmethod
     def _state_from_device(b, n=0):
@@ -134,7 +187,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         b = self.batch
         b.set_tasks([self.input_], [self.answer])
         b.reset()
-        self.current_state = self._state_from_device(b)
+        self.current_state = self._fetch_state(b)
         self.info = self.init_info()
         if self.render_mode:
             self.render()
@@ -165,14 +218,33 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             state = self._state_from_device(b)
             fn(state, action)
             self._state_to_device(b, state)
-        sel_t = torch.as_tensor(sel.astype(np.int8, copy=False), device=b.device).reshape(1, self.H, self.W)
-        reward, term = b.step_mask(sel_t, torch.tensor([op], dtype=torch.int32, device=b.device), self._step_flags())
+        # action in: pinned staging -> device (asynchronous); step with the fused observation row; row, counters and reward out
+        # (asynchronous); the status read synchronises the stream
+        if b is not self._batch:  # the scratch env of transition(): plain path, the caller fetches the state itself
+            sel_t = torch.as_tensor(sel.astype(np.int8, copy=False), device=b.device).reshape(1, self.H, self.W)
+            reward, term = b.step_mask(sel_t, torch.tensor([op], dtype=torch.int32, device=b.device), self._step_flags())
+            st = b.status()
+            if st & ST_ROTATE_DOMAIN:
+                raise ValueError("Rotate/Flip outside its domain (the reference raises here too: object.py:45 / int8 overflow)")
+            if st & ST_BAD_OP:
+                raise IndexError("list index out of range")
+            return int(reward[0]), bool(term[0])
+        io = self._io()
+        io["h_sel"][0].copy_(torch.from_numpy(np.ascontiguousarray(sel.astype(np.int8, copy=False))))
+        io["h_op"][0] = op
+        io["d_sel"].copy_(io["h_sel"], non_blocking=True)
+        io["d_op"].copy_(io["h_op"], non_blocking=True)
+        reward, term = b.step_mask(io["d_sel"], io["d_op"], self._step_flags() | STEP_FLAT_OBS)
+        io["h_flat"].copy_(io["flat"], non_blocking=True)
+        io["h_cnt"].copy_(b.cnt, non_blocking=True)
+        io["h_reward"].copy_(reward, non_blocking=True)
         st = b.status()
         if st & ST_ROTATE_DOMAIN:
             raise ValueError("Rotate/Flip outside its domain (the reference raises here too: object.py:45 / int8 overflow)")
         if st & ST_BAD_OP:
             raise IndexError("list index out of range")
-        return int(reward[0]), bool(term[0])
+        self._row_ready = True
+        return int(io["h_reward"][0]), bool(io["h_flat"][0, -2] != 0)  # (terminated is the row's last-but-one byte)
 
     def step(self, action):
         """o2arcenv.py:130-147 / arcenv.py:60-76,155-172."""
@@ -193,9 +265,9 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             dev_reward, term = self._device_step(b, action)
             self.last_action_op = int(action["operation"]) % len(self.operations)
             self.last_action = action
-            self.current_state = self._state_from_device(b)
-            cnt = b.cnt[0].cpu().numpy()
-            self.action_steps, self.submit_count = int(cnt[0]), int(cnt[1])
+            io = self._io()
+            self.current_state = self._state_from_row(io["h_flat"][0].numpy())  # (copied out by _device_step)
+            self.action_steps, self.submit_count = int(io["h_cnt"][0, 0]), int(io["h_cnt"][0, 1])
             # a subclass that overrides reward() (e.g. the dense reward of agents/env.py:44-58) is evaluated on the host;
             # so is the reward of a host-applied last op
             host_reward = type(self).reward is not AbstractARCEnv.reward or not isinstance(
