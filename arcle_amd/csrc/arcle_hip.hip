@@ -436,6 +436,14 @@ extern "C" int arcle_set_task_table(arcle_env* e, const int8_t* in_planes, const
   if (n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "empty task table");
   if ((reinterpret_cast<uintptr_t>(in_planes) & 15) || (reinterpret_cast<uintptr_t>(ans_planes) & 15))
     return fail(e, ARCLE_ERR_ARG, "task table planes must be 16-byte aligned");
+  // (the table stays caller-owned and must outlive its last use; what CAN be checked here: all four are device-accessible memory)
+  for (const void* ptr : {(const void*)in_planes, (const void*)in_dims, (const void*)ans_planes, (const void*)ans_dims}) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {
+      (void)hipGetLastError();
+      return fail(e, ARCLE_ERR_ARG, "task table arrays must be device memory");
+    }
+  }
   e->base.tbl_in = in_planes;
   e->base.tbl_in_dim = in_dims;
   e->base.tbl_ans = ans_planes;
