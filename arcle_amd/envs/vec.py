@@ -38,6 +38,10 @@ class _LazyInfo(dict):
     def lazy(self, key, thunk):
         self._thunks[key] = thunk
 
+    def __setitem__(self, key, value):
+        self._thunks.pop(key, None)  # an explicit assignment replaces a pending entry
+        dict.__setitem__(self, key, value)
+
     def _force(self, key=None):
         for k in ([key] if key is not None else list(self._thunks)):
             if k in self._thunks:

@@ -124,3 +124,29 @@ def test_spaces_fallback_sampling():
     assert b.sample().shape == (3, 3) and b.sample().dtype == np.int8
     dd = spaces.Dict({"selection": b, "operation": d})
     assert set(dd.sample()) == {"selection", "operation"} and dd["operation"].n == 5
+
+
+def test_lazy_info_dict_semantics():
+    """ARCVecEnv's info: entries registered lazily behave like ordinary dict entries and are computed once, on first access."""
+    from arcle_amd.envs.vec import _LazyInfo
+    calls = []
+    d = _LazyInfo({"steps": 3})
+    d.lazy("task_index", lambda: calls.append(1) or 7)
+    assert "task_index" in d and "steps" in d and "nope" not in d and len(d) == 2 and calls == []
+    assert d["steps"] == 3 and calls == []          # eager entries never trigger the thunk
+    assert d["task_index"] == 7 and d["task_index"] == 7 and calls == [1]
+    e = _LazyInfo({"a": 1})
+    e.lazy("b", lambda: 2)
+    assert e.get("b") == 2 and e.get("c", 5) == 5
+    f = _LazyInfo({"a": 1})
+    f.lazy("b", lambda: 2)
+    assert sorted(f.keys()) == ["a", "b"] and dict(f.items()) == {"a": 1, "b": 2} and sorted(f) == ["a", "b"]
+    g = _LazyInfo({"a": 1})
+    g.lazy("b", lambda: 2)
+    g["b"] = 9  # an explicit assignment wins over the pending thunk
+    assert g["b"] == 9 and dict(g.items()) == {"a": 1, "b": 9}
+    try:
+        g["zzz"]
+        raise AssertionError("KeyError expected")
+    except KeyError:
+        pass
