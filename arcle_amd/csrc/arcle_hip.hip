@@ -105,6 +105,25 @@ ARCLE_DEV uint32_t wave_or(uint32_t v) {
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// sum over the 64 lanes (same DPP ladder as wave_or), uniform result
+ARCLE_DEV uint32_t wave_add(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// v_dot4_u32_u8: sum of the four byte products a.b[k] * b.b[k], plus c — turns four per-byte flags into a nibble in ONE
+// instruction (weights 1, 2, 4, 8), see arcle::flags16
+ARCLE_DEV uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+// 16 B load from an arbitrary byte address (flattened state rows: plane segments start at any offset of the row); global memory
+// takes unaligned vector accesses
+ARCLE_DEV U4 load16u(const int8_t* p) {
+  typedef U4 __attribute__((aligned(1))) U4a1;
+  return *reinterpret_cast<const ARCLE_AS_GLOBAL U4a1*>((uintptr_t)p);
+}
 ARCLE_DEV uint32_t bfrev(uint32_t v) { return __builtin_bitreverse32(v); }  // v_bfrev_b32
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }  // full-rate 24-bit multiply
@@ -167,6 +186,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     p.div_magic = 65536u / 30u + 1u;
     p.nseg = 2;
   }
+  if (FL >= 0) {  // the launch's flag set is a compile-time constant of this instantiation (the launcher checked that it applies)
+    p.flags = (uint32_t)FL & 0xffffu;
+    if (FL & ARCLE_STEP_FLAT_OBS) {  // ... and so are the shape of the fused observation rows: every segment offset folds
+      p.flat_filter = (FL & ARCLE_STEPX_FLAT_FILTERED) ? 1 : 0;
+      p.flat_tail = 0;
+      if (WC == 30) p.flat_stride = (FL & ARCLE_STEPX_FLAT_FILTERED) ? ARCLE_ROW30_FILTERED_STRIDE : ARCLE_ROW30_FULL_STRIDE;
+    }
+  }
   // (leading scalar arguments = what a wave needs to find and request its env's inputs; built with -amdgpu-kernarg-preload-count they
   // are in SGPRs at wave start.  They repeat p.rec / p.cnt / p.op / p.sel / p.n_envs / p.wpw.)
   __shared__ BlockLDS lds;
@@ -176,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   const int wv = wave_of_launch(wpw, nb8);
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = valid ? wv : 0;
-  arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false);
+  arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0);
   arcle::StepInputs in = arcle::load_inputs<ING>(w, env, rec, cnt, op, sel);  // in flight while the expansion table is built
   arcle::lut_init(lds.lut, (int)threadIdx.x);
   xl::wg_barrier();
@@ -220,6 +247,34 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_pack_kernel(const Ste
   const int env = wave_of_launch();
   if (env >= p.n_envs) return;
   arcle::wave_pack_obs(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
+}
+
+// int8 [N][P] selection masks -> bit-packed uint8 [N][128] rows (the INGRESS_BITS form): bit f of a row = cell f truthy
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_pack_bits_kernel(const StepParams p, uint8_t* bits) {
+  __shared__ BlockLDS lds;
+  const int env = wave_of_launch();
+  if (env >= p.n_envs) return;
+  arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), arcle::INGRESS_MASK, arcle::FW_GENERIC, false);
+  const arcle::U4 v = arcle::load_payload(w, env, 0, p.sel);
+  const uint32_t m = arcle::nz16(v) & w.valid16;
+  *reinterpret_cast<uint16_t*>(bits + (size_t)env * ARCLE_BITS_STRIDE + 2 * w.lane) = (uint16_t)m;
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_set_state_rows_kernel(const StepParams p) {
+  __shared__ BlockLDS lds;
+  const int env = wave_of_launch();
+  if (env >= p.n_envs) return;
+  arcle::wave_set_state_row(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
+}
+
+template <int ING, int FW>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_transition_rows_kernel(const StepParams p) {
+  __shared__ BlockLDS lds;
+  arcle::lut_init(lds.lut, (int)threadIdx.x);
+  xl::wg_barrier();
+  const int row = wave_of_launch();
+  if (row >= p.n_envs) return;
+  arcle::wave_transition_row<ING, FW>(p, &lds.wave[threadIdx.x >> 6], lds.lut, row, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_reset_kernel(const StepParams p) {
@@ -266,6 +321,9 @@ struct arcle_env {
   int8_t* pack_out;  // ARCLE_STEP_PACK_OBS destination (arcle_set_packed_output)
   int32_t flat_stride;
   int flat_filtered;
+  int flat_tail;
+  uint32_t* retired_ops[64];  // op tables replaced by arcle_set_op_table: launches in flight (and captured graphs) may still read them
+  int n_retired;
   uint32_t* d_acct;
   uint64_t acct_steps;
   int device;
@@ -391,6 +449,7 @@ extern "C" int arcle_destroy(arcle_env* e) {
   }
   if (e->d_status) (void)hipFree(e->d_status);
   if (e->d_ops) (void)hipFree(e->d_ops);
+  for (int i = 0; i < e->n_retired; i++) (void)hipFree(e->retired_ops[i]);
   if (e->d_acct) (void)hipFree(e->d_acct);
   delete e;
   return ARCLE_OK;
@@ -422,10 +481,30 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
         (k == ARCLE_OP_COPY && a > 1) || (k == ARCLE_OP_PASTE && a > 1))
       return fail(e, ARCLE_ERR_CONFIG, "op argument out of range");
   }
-  HIP_TRY(e, hipDeviceSynchronize());  // no launch of this handle may still read the old table
+  // Every launch receives its parameters BY VALUE (StepParams is a kernel argument), the table pointer included: launches already
+  // enqueued — and hipGraphs already captured — keep reading the table they were launched / captured with.  So a new table goes into
+  // a NEW device buffer and the old one is only retired (freed in arcle_destroy); no synchronisation, nothing in flight is disturbed.
+  uint32_t* fresh = nullptr;
+  if (e->base.n_ops > 0) {
+    if (e->n_retired >= (int)(sizeof(e->retired_ops) / sizeof(e->retired_ops[0]))) {
+      HIP_TRY(e, hipDeviceSynchronize());  // (64 replacements later: recycle — nothing can still be reading the oldest ones)
+      for (int i = 0; i < e->n_retired; i++) (void)hipFree(e->retired_ops[i]);
+      e->n_retired = 0;
+    }
+    HIP_TRY(e, hipMalloc((void**)&fresh, sizeof(uint32_t) * (ARCLE_MAX_OPS + 1)));
+  }
   memset(e->ops_host, 0, sizeof(e->ops_host));
   memcpy(e->ops_host, descs, sizeof(uint32_t) * (size_t)n_ops);
-  HIP_TRY(e, hipMemcpy(e->d_ops, e->ops_host, sizeof(e->ops_host), hipMemcpyHostToDevice));  // synchronous
+  uint32_t staged[ARCLE_MAX_OPS + 1];
+  memset(staged, 0, sizeof(staged));  // (slot n_ops .. ARCLE_MAX_OPS stay empty)
+  memcpy(staged, descs, sizeof(uint32_t) * (size_t)n_ops);
+  uint32_t* dst = fresh ? fresh : e->d_ops;
+  HIP_TRY(e, hipMemcpy(dst, staged, sizeof(staged), hipMemcpyHostToDevice));  // synchronous: `staged` may go out of scope
+  if (fresh) {
+    e->retired_ops[e->n_retired++] = e->d_ops;
+    e->d_ops = fresh;
+    e->base.d_ops = fresh;
+  }
   e->base.n_ops = n_ops;
   return ARCLE_OK;
 }
@@ -491,27 +570,34 @@ extern "C" int arcle_reset(arcle_env* e, const uint8_t* mask, void* stream) {
 
 static int launch_flatten(arcle_env* e, int8_t* out, int32_t out_stride, int filtered, hipStream_t st);
 
-// ---- instantiation dispatch: (ingress, width class, table, accounting) -> kernel ----------------------------------
+// ---- instantiation dispatch: (ingress, width class, flags, accounting) -> kernel --------------------------------------
 static int width_class(const StepParams& p) {
   if (p.W < 16 || p.W > 32) return arcle::FW_GENERIC;
   return p.PS == ARCLE_MAX_CELLS ? arcle::FW_FULL : arcle::FW_FAST;
 }
 #define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p
+#define LAUNCH_STEP(...) hipLaunchKernelGGL((arcle_step_kernel<__VA_ARGS__>), g, b, 0, st, STEP_ARGS)
 // the flag combination ARCVecEnv steps with (next-step autoreset, elided zero-fill of `selected`) has its own instantiation
 // with the flags as a compile-time constant
 static constexpr int HOT_FLAGS = ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED;
 // ... and the same plus the fused packed row (what a ShardedVecEnv steps with): lean 30 x 30 instantiation
 static constexpr int HOT_PACK_FLAGS = HOT_FLAGS | ARCLE_STEP_PACK_OBS;
-#ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiation exists (seconds instead of a minute)
+// ... and the research env's step (agents/env.py:23-58 + agents/train.py:61-68 as ARCVecEnv(autoreset="resample", dense_reward,
+// max_episode_steps) runs it): episode end -> new device-drawn task, TimeLimit, dense reward pair, fused FilterO2ARC rows
+static constexpr int RESEARCH_FLAGS = ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_TRUNCATE | ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_FLAT_OBS;
+static constexpr int RESEARCH_FL = RESEARCH_FLAGS | ARCLE_STEPX_FLAT_FILTERED;
+static bool research_shape(const StepParams& p) {
+  return p.flags == (uint32_t)RESEARCH_FLAGS && p.flat_filter == 1 && p.flat_tail == 0 && p.flat_stride == ARCLE_ROW30_FILTERED_STRIDE;
+}
+#ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiations exist (seconds instead of a minute)
 template <int ING>
 static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
-  if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || feat) return ARCLE_ERR_CONFIG;
-  if (acct) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 0>), g, b, 0, st, STEP_ARGS);
-#ifndef ARCLE_NO_HOT_FLAGS
-  else if (p.flags == (uint32_t)HOT_FLAGS && p.H == 30 && p.W == 30) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS, 30>), g, b, 0, st, STEP_ARGS);
-  else if (p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
-#endif
-  else hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0>), g, b, 0, st, STEP_ARGS);
+  if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || p.H != 30 || p.W != 30) return ARCLE_ERR_CONFIG;
+  if (feat || acct) {
+    if (!acct && research_shape(p)) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 1, RESEARCH_FL, 30);
+    else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 1);
+  } else if (p.flags == (uint32_t)HOT_FLAGS) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS, 30);
+  else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, -1, 30);
   return ARCLE_OK;
 }
 #else
@@ -519,15 +605,16 @@ template <int ING, int FW>
 static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if constexpr (FW == arcle::FW_FULL) {  // the standard 30 x 30 grid: lean instantiations with the dimensions as compile-time constants
     if (p.H == 30 && p.W == 30 && !acct) {
-      if (p.flags == (uint32_t)HOT_PACK_FLAGS) { hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_PACK_FLAGS, 30>), g, b, 0, st, STEP_ARGS); return; }
-      if (p.flags == (uint32_t)HOT_FLAGS) { hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS, 30>), g, b, 0, st, STEP_ARGS); return; }
-      if (!feat) { hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, -1, 30>), g, b, 0, st, STEP_ARGS); return; }
+      if (p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_PACK_FLAGS, 30); return; }
+      if (p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_FLAGS, 30); return; }
+      if (research_shape(p)) { LAUNCH_STEP(ING, FW, 0, 1, RESEARCH_FL, 30); return; }
+      if (!feat) { LAUNCH_STEP(ING, FW, 0, 0, -1, 30); return; }
     }
   }
-  if (feat) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 1>), g, b, 0, st, STEP_ARGS);  // (the feature instantiation has no accounting)
-  else if (acct) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 1, 0>), g, b, 0, st, STEP_ARGS);
-  else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS>), g, b, 0, st, STEP_ARGS);
-  else hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0>), g, b, 0, st, STEP_ARGS);
+  // the feature instantiation also carries the byte accounting (it adds up scalars; stored only when the handle has a counter buffer)
+  if (feat || acct) LAUNCH_STEP(ING, FW, 1, 1);
+  else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) LAUNCH_STEP(ING, FW, 0, 0, HOT_FLAGS);
+  else LAUNCH_STEP(ING, FW, 0, 0);
 }
 template <int ING>
 static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
@@ -540,13 +627,14 @@ static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStre
 
 static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t* op, int32_t* reward, uint8_t* term,
                        uint32_t flags, void* stream) {
-  if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
+  if (!e || !sel || (!op && ingress != arcle::INGRESS_BBOX5) || !reward || !term) return ARCLE_ERR_ARG;
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
   if ((flags & ARCLE_STEP_TRUNCATE) && !e->base.trunc) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_TRUNCATE without arcle_set_truncation");
   if ((flags & ARCLE_STEP_RESAMPLE) && e->base.n_problems <= 0) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_RESAMPLE without arcle_set_sampler");
   if ((flags & ARCLE_STEP_DENSE) && (!e->base.dense || !e->bufs.plane[ARCLE_PL_ANSWER])) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_DENSE without arcle_set_dense_output");
-  if ((flags & ARCLE_STEP_CONTINUE_RULE) && (ingress != arcle::INGRESS_MASK || !e->bufs.plane[ARCLE_PL_SELECTED]))
+  if ((flags & ARCLE_STEP_CONTINUE_RULE) && (!arcle::is_cells(ingress) || !e->bufs.plane[ARCLE_PL_SELECTED]))
     return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_CONTINUE_RULE needs mask ingress and the `selected` plane");
+  if (flags & ~0x1ffu) return fail(e, ARCLE_ERR_ARG, "unknown step flag");
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.ingress = ingress;
@@ -566,6 +654,7 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     p.flat_out = e->flat_out;
     p.flat_stride = e->flat_stride;
     p.flat_filter = e->flat_filtered ? 1 : 0;
+    p.flat_tail = e->flat_tail ? 1 : 0;
   }
   if (flags & ARCLE_STEP_PACK_OBS) {
     if (!e->pack_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output");
@@ -576,11 +665,15 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   const int fw = width_class(p);
   const bool acct = e->d_acct != nullptr;
   const bool feat = (flags & ARCLE_STEP_FEATURE_FLAGS) != 0;
-  if (feat && acct) return fail(e, ARCLE_ERR_CONFIG, "byte accounting is not available together with ARCLE_STEP_FEATURE_FLAGS");
   int rc;
-  if (ingress == arcle::INGRESS_BBOX) rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, acct, feat, g, b, st, p);
-  else if (ingress == arcle::INGRESS_POINT) rc = launch_step_ing<arcle::INGRESS_POINT>(fw, acct, feat, g, b, st, p);
-  else rc = launch_step_ing<arcle::INGRESS_MASK>(fw, acct, feat, g, b, st, p);
+  switch (ingress) {
+    case arcle::INGRESS_BBOX: rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, acct, feat, g, b, st, p); break;
+    case arcle::INGRESS_POINT: rc = launch_step_ing<arcle::INGRESS_POINT>(fw, acct, feat, g, b, st, p); break;
+    case arcle::INGRESS_MASK: rc = launch_step_ing<arcle::INGRESS_MASK>(fw, acct, feat, g, b, st, p); break;
+    case arcle::INGRESS_BBOX5: rc = launch_step_ing<arcle::INGRESS_BBOX5>(fw, acct, feat, g, b, st, p); break;
+    case arcle::INGRESS_BITS: rc = launch_step_ing<arcle::INGRESS_BITS>(fw, acct, feat, g, b, st, p); break;
+    default: return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  }
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
@@ -598,6 +691,50 @@ extern "C" int arcle_step_bbox(arcle_env* e, const int32_t* bbox, const int32_t*
 extern "C" int arcle_step_point(arcle_env* e, const int32_t* xy, const int32_t* op, int32_t* reward, uint8_t* term,
                                 uint32_t flags, void* stream) {
   return launch_step(e, arcle::INGRESS_POINT, xy, op, reward, term, flags, stream);
+}
+extern "C" int arcle_step_bbox5(arcle_env* e, const int32_t* act5, int32_t* reward, uint8_t* term, uint32_t flags, void* stream) {
+  return launch_step(e, arcle::INGRESS_BBOX5, act5, nullptr, reward, term, flags, stream);
+}
+extern "C" int arcle_step_bits(arcle_env* e, const uint8_t* bits, const int32_t* op, int32_t* reward, uint8_t* term,
+                               uint32_t flags, void* stream) {
+  return launch_step(e, arcle::INGRESS_BITS, bits, op, reward, term, flags, stream);
+}
+
+// bytes of one step's selection payload / op array for the whole batch (arcle_step_many strides)
+static size_t payload_bytes(const arcle_env* e, int ingress) {
+  const size_t n = (size_t)e->cfg.n_envs;
+  switch (ingress) {
+    case arcle::INGRESS_MASK: return n * (size_t)e->base.P;
+    case arcle::INGRESS_BBOX: return n * 16;
+    case arcle::INGRESS_POINT: return n * 8;
+    case arcle::INGRESS_BBOX5: return n * 20;
+    default: return n * ARCLE_BITS_STRIDE;
+  }
+}
+
+extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
+                               uint8_t* term, uint32_t flags, void* stream) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
+  if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  const size_t n = (size_t)e->cfg.n_envs, pb = payload_bytes(e, ingress);
+  for (int32_t t = 0; t < n_steps; t++) {
+    const int rc = launch_step(e, ingress, (const char*)sel + (size_t)t * pb, op ? op + (size_t)t * n : nullptr,
+                               reward ? reward + (size_t)t * n : nullptr, term ? term + (size_t)t * n : nullptr, flags, stream);
+    if (rc != ARCLE_OK) return rc;
+  }
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_pack_mask_bits(arcle_env* e, const int8_t* sel, uint8_t* bits, void* stream) {
+  if (!e || !sel || !bits) return ARCLE_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(bits) & 1) return fail(e, ARCLE_ERR_ARG, "bit-packed mask rows must be 2-byte aligned");
+  DeviceGuard guard(e->device);
+  StepParams p = e->base;
+  p.sel = sel;
+  hipLaunchKernelGGL(arcle_pack_bits_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p, bits);
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
 }
 
 #ifdef ARCLE_FAST_BUILD
@@ -760,6 +897,119 @@ extern "C" int arcle_set_flat_output(arcle_env* e, int8_t* out, int32_t out_stri
   e->flat_out = out;
   e->flat_stride = out_stride;
   e->flat_filtered = filtered ? 1 : 0;
+  e->flat_tail = 0;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_set_flat_output_ex(arcle_env* e, int8_t* out, int32_t out_stride, int filtered, int tail) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (out && tail) {
+    const int len = arcle_flat_obs_size(e, filtered);
+    if (len >= 0 && out_stride < ((len + 15) & ~15) + 16)
+      return fail(e, ARCLE_ERR_ARG, "flat rows with a tail: stride >= arcle_flat_obs_size() rounded up to 16, plus 16");
+  }
+  const int rc = arcle_set_flat_output(e, out, out_stride, filtered);
+  if (rc == ARCLE_OK) e->flat_tail = (out && tail) ? 1 : 0;
+  return rc;
+}
+
+// ---- state rows at the boundary: ingest (inverse of arcle_flatten_obs), stateless batched transition, plane copies ----------
+static int check_rows(arcle_env* e, const void* rows, int32_t stride, int extra) {
+  const int len = arcle::flat_obs_len(e->base, 0);
+  if (!rows || stride < len + extra) return fail(e, ARCLE_ERR_ARG, "state rows: stride >= arcle_flat_obs_size(env, 0)");
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_set_state_rows(arcle_env* e, const int8_t* rows, int32_t stride, const uint8_t* mask, void* stream) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (int rc = check_rows(e, rows, stride, 0)) return rc;
+  DeviceGuard guard(e->device);
+  StepParams p = e->base;
+  p.rows_in = rows;
+  p.rows_in_stride = stride;
+  p.rmask = mask;
+  hipLaunchKernelGGL(arcle_set_state_rows_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_get_state_rows(arcle_env* e, int8_t* rows, int32_t stride, void* stream) {
+  if (!e || !rows) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
+  return launch_flatten(e, rows, stride, 0, (hipStream_t)stream);
+}
+
+template <int ING>
+static void launch_transition_ing(int fw, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
+  // (planes live in registers: lane predication does not matter, FW_FULL shares FW_FAST's code — as in the rollout kernels)
+  if (fw != arcle::FW_GENERIC) hipLaunchKernelGGL((arcle_transition_rows_kernel<ING, arcle::FW_FAST>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_transition_rows_kernel<ING, arcle::FW_GENERIC>), g, b, 0, st, p);
+}
+
+extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t* rows_in, int32_t in_stride, int ingress,
+                                     const void* sel, const int32_t* op, const int32_t* src_env, int8_t* rows_out,
+                                     int32_t out_stride, int tail, int32_t* reward, uint8_t* term, uint32_t flags, void* stream) {
+  if (!e || !sel || !op || !reward || !term || !rows_out) return ARCLE_ERR_ARG;
+  if (n_rows <= 0) return fail(e, ARCLE_ERR_ARG, "n_rows must be positive");
+  if (!src_env && n_rows > e->cfg.n_envs) return fail(e, ARCLE_ERR_ARG, "more rows than envs: pass src_env (which env's answer every row uses)");
+  if ((uint64_t)n_rows * ARCLE_MAX_CELLS >= (1ull << 32)) return fail(e, ARCLE_ERR_ARG, "too many rows");
+  if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
+  if (flags & ~(ARCLE_STEP_RESET_ON_SUBMIT | ARCLE_STEP_DENSE | ARCLE_STEP_CONTINUE_RULE))
+    return fail(e, ARCLE_ERR_ARG, "arcle_transition_rows takes ARCLE_STEP_RESET_ON_SUBMIT / _DENSE / _CONTINUE_RULE only");
+  if ((flags & ARCLE_STEP_DENSE) && !e->base.dense) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_DENSE without arcle_set_dense_output");
+  if ((flags & ARCLE_STEP_DENSE) && n_rows > e->cfg.n_envs) return fail(e, ARCLE_ERR_ARG, "ARCLE_STEP_DENSE: the dense output has one pair per env, n_rows <= n_envs");
+  if ((flags & ARCLE_STEP_CONTINUE_RULE) && ingress != arcle::INGRESS_MASK) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_CONTINUE_RULE needs mask ingress");
+  if (int rc = check_rows(e, rows_in, in_stride, 0)) return rc;
+  const int len = arcle::flat_obs_len(e->base, 0);
+  if ((out_stride & 15) || (reinterpret_cast<uintptr_t>(rows_out) & 15) || out_stride < ((len + 15) & ~15) + (tail ? 16 : 0))
+    return fail(e, ARCLE_ERR_ARG, "output rows: 16-byte aligned, stride a multiple of 16 >= the row length (+16 with a tail)");
+  DeviceGuard guard(e->device);
+  StepParams p = e->base;
+  p.n_resident = p.n_envs;
+  p.n_envs = n_rows;
+  p.ingress = ingress;
+  p.sel = sel;
+  p.op = op;
+  p.reward = reward;
+  p.term = term;
+  p.flags = flags;
+  p.acct = nullptr;
+  p.rmask = nullptr;
+  p.task_idx = src_env;
+  p.rows_in = rows_in;
+  p.rows_in_stride = in_stride;
+  p.flat_out = rows_out;
+  p.flat_stride = out_stride;
+  p.flat_filter = 0;
+  p.flat_tail = tail ? 1 : 0;
+  const dim3 g = grid_for(n_rows), b(64 * WAVES_PER_WG);
+  hipStream_t st = (hipStream_t)stream;
+  const int fw = width_class(e->base);
+  switch (ingress) {
+    case arcle::INGRESS_BBOX: launch_transition_ing<arcle::INGRESS_BBOX>(fw, g, b, st, p); break;
+    case arcle::INGRESS_POINT: launch_transition_ing<arcle::INGRESS_POINT>(fw, g, b, st, p); break;
+    case arcle::INGRESS_MASK: launch_transition_ing<arcle::INGRESS_MASK>(fw, g, b, st, p); break;
+    default: return fail(e, ARCLE_ERR_ARG, "arcle_transition_rows takes mask, bbox or point selections");
+  }
+  HIP_TRY(e, hipGetLastError());
+  return ARCLE_OK;
+}
+
+// plane <-> dense [n_envs][H*W] array (device or pinned host memory): a strided 2-D copy on the stream
+extern "C" int arcle_get_plane(arcle_env* e, int plane, int8_t* dst, void* stream) {
+  if (!e || !dst || plane < 0 || plane >= ARCLE_N_PLANES) return ARCLE_ERR_ARG;
+  if (!e->bufs.plane[plane]) return fail(e, ARCLE_ERR_CONFIG, "this env kind has no such plane");
+  DeviceGuard guard(e->device);
+  HIP_TRY(e, hipMemcpy2DAsync(dst, (size_t)e->base.P, e->bufs.plane[plane], (size_t)e->base.PS, (size_t)e->base.P, (size_t)e->cfg.n_envs,
+                              hipMemcpyDefault, (hipStream_t)stream));
+  return ARCLE_OK;
+}
+extern "C" int arcle_set_plane(arcle_env* e, int plane, const int8_t* src, void* stream) {
+  if (!e || !src || plane < 0 || plane >= ARCLE_N_PLANES) return ARCLE_ERR_ARG;
+  if (!e->bufs.plane[plane]) return fail(e, ARCLE_ERR_CONFIG, "this env kind has no such plane");
+  DeviceGuard guard(e->device);
+  HIP_TRY(e, hipMemcpy2DAsync(e->bufs.plane[plane], (size_t)e->base.PS, src, (size_t)e->base.P, (size_t)e->base.P, (size_t)e->cfg.n_envs,
+                              hipMemcpyDefault, (hipStream_t)stream));
   return ARCLE_OK;
 }
 
@@ -827,26 +1077,32 @@ extern "C" int arcle_debug_copy_trace(arcle_env* e, uint64_t* host_out) {  // di
 }
 #endif
 
-extern "C" int arcle_get_accounting(arcle_env* e, uint64_t* bytes, uint64_t* steps, int clear, void* stream) {
-  if (!e || !bytes || !steps) return ARCLE_ERR_ARG;
+extern "C" int arcle_get_accounting_ex(arcle_env* e, uint64_t* bytes, uint64_t* issued, uint64_t* steps, int clear, void* stream) {
+  if (!e || !bytes || !issued || !steps) return ARCLE_ERR_ARG;
   if (!e->d_acct) return fail(e, ARCLE_ERR_CONFIG, "accounting is not enabled");
   DeviceGuard guard(e->device);
   const size_t n = (size_t)e->cfg.n_envs;
-  uint32_t* h = (uint32_t*)malloc(n * 4);
+  uint32_t* h = (uint32_t*)malloc(2 * n * 4);
   if (!h) return ARCLE_ERR_ARG;
-  hipError_t err = hipMemcpyAsync(h, e->d_acct, n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
-  if (err == hipSuccess && clear) err = hipMemsetAsync(e->d_acct, 0, n * 4, (hipStream_t)stream);
+  hipError_t err = hipMemcpyAsync(h, e->d_acct, 2 * n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (err == hipSuccess && clear) err = hipMemsetAsync(e->d_acct, 0, 2 * n * 4, (hipStream_t)stream);
   if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
   if (err != hipSuccess) {
     free(h);
     snprintf(e->err, sizeof(e->err), "accounting copy failed: %s", hipGetErrorString(err));
     return ARCLE_ERR_HIP;
   }
-  uint64_t tot = 0;
-  for (size_t i = 0; i < n; i++) tot += h[i];
+  uint64_t tot = 0, iss = 0;
+  for (size_t i = 0; i < n; i++) tot += h[i], iss += h[n + i];
   free(h);
   *bytes = tot + e->acct_extra;
+  *issued = iss + e->acct_extra;
   *steps = e->acct_steps;
   if (clear) e->acct_steps = 0, e->acct_extra = 0;
   return ARCLE_OK;
+}
+
+extern "C" int arcle_get_accounting(arcle_env* e, uint64_t* bytes, uint64_t* steps, int clear, void* stream) {
+  uint64_t issued = 0;
+  return arcle_get_accounting_ex(e, bytes, &issued, steps, clear, stream);
 }

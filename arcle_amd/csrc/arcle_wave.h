@@ -34,7 +34,19 @@
 
 namespace arcle {
 
-enum { INGRESS_MASK = 0, INGRESS_BBOX = 1, INGRESS_POINT = 2 };
+enum { INGRESS_MASK = 0,    // int8 [N][P] selection masks as given (action['selection'], base.py:134-138)
+       INGRESS_BBOX = 1,    // int32 [N][4] BBoxWrapper corners (bbox.py:22-30)
+       INGRESS_POINT = 2,   // int32 [N][2] PointWrapper cell (bbox.py:43-49)
+       INGRESS_BBOX5 = 3,   // int32 [N][5] the BBoxWrapper action as ONE record (x1, y1, x2, y2, operation): selection form = BBOX
+       INGRESS_BITS = 4 };  // uint8 [N][128] bit-packed boolean masks (bit f of the row = cell f truthy; base.py:136 accepts bool)
+#define ARCLE_BITS_STRIDE (ARCLE_MAX_CELLS / 8)
+// launcher-internal bit of a compile-time flag set (FL template parameter): the fused flat rows are the FilterO2ARC subset
+#define ARCLE_STEPX_FLAT_FILTERED 0x10000
+// row strides of the 30 x 30 lean instantiations: 3*900 + 10 and 7*900 + 14, rounded up to 16
+#define ARCLE_ROW30_FILTERED_STRIDE 2720
+#define ARCLE_ROW30_FULL_STRIDE 6320
+ARCLE_HD constexpr bool is_tuple(int ing) { return ing == INGRESS_BBOX || ing == INGRESS_POINT || ing == INGRESS_BBOX5; }
+ARCLE_HD constexpr bool is_cells(int ing) { return ing == INGRESS_MASK || ing == INGRESS_BITS; }
 // FW (instantiation parameter): grid-width class of the launch
 enum { FW_GENERIC = 0,  // any W
        FW_FAST = 1,     // 16 <= W <= 32: a lane's 16-cell window spans at most two rows (cheap rectangle masks, DPP flood fill)
@@ -46,7 +58,7 @@ struct StepParams {
   int8_t* rec;
   int32_t* cnt;
   const int32_t* op;
-  const void* sel;  // ingress payload: int8 [N][P] | int32 [N][4] | int32 [N][2]
+  const void* sel;  // ingress payload: int8 [N][P] | int32 [N][4] | int32 [N][2] | int32 [N][5] | uint8 [N][128]
   int32_t* reward;
   uint8_t* term;
   int32_t n_envs, H, W, P;
@@ -83,6 +95,10 @@ struct StepParams {
   const uint8_t* aug_perm;  // explicit colour permutation per env, uint8 [N][16] (perm[c], c < 10)
   int32_t n_problems;
   int32_t wpw;  // step kernel: waves per workgroup of this launch (set by the launcher)
+  int32_t flat_tail;       // 1 = the last 16 bytes of every flat row's stride hold the step outputs (arcle_set_flat_output_ex)
+  const int8_t* rows_in;   // state-row kernels: flattened state rows to read (arcle_transition_rows / arcle_set_state_rows)
+  int32_t rows_in_stride;
+  int32_t n_resident;      // state-row kernels: envs of the handle (src_env range check); n_envs = rows of the launch
 };
 
 // 16 bytes of a plane = 4 VGPRs; a first-class vector value so that it always lives in registers
@@ -122,21 +138,17 @@ ARCLE_DEV uint32_t bits_range(int a, int b) { return (2u << b) - (1u << a); }  /
 ARCLE_DEV uint32_t nzflags(uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
 // bit7-per-byte flags: byte > 0 as int8 (non-zero and sign bit clear)
 ARCLE_DEV uint32_t posflags(uint32_t x) { return ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) & ~x & 0x80808080u; }
-// 0x80 flags -> 4-bit nibble
-ARCLE_DEV uint32_t flags2nib(uint32_t t) {
-  uint32_t y = t >> 7;
-  y |= y >> 7;
-  y |= y >> 14;
-  return y & 0xfu;
+// sixteen 0x80-per-byte flags (four dwords) -> 16-bit mask, bit k <-> byte k: v_dot4_u32_u8 with the weights 1, 2, 4, 8 (and 16 ..
+// 128 for the second dword) sums 128 * 2^k over the flagged bytes — 4 dot products + 2 shifts instead of ~28 shift / or / and steps
+ARCLE_DEV uint32_t flags16(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+  uint32_t lo = xl::dot4(t0, 0x08040201u, 0u);
+  lo = xl::dot4(t1, 0x80402010u, lo);
+  uint32_t hi = xl::dot4(t2, 0x08040201u, 0u);
+  hi = xl::dot4(t3, 0x80402010u, hi);
+  return (lo >> 7) | (hi << 1);  // lo, hi = 128 * (8-bit value)
 }
-ARCLE_DEV uint32_t nz16(const U4& v) {
-  return flags2nib(nzflags(v[0])) | (flags2nib(nzflags(v[1])) << 4) | (flags2nib(nzflags(v[2])) << 8) |
-         (flags2nib(nzflags(v[3])) << 12);
-}
-ARCLE_DEV uint32_t pos16(const U4& v) {
-  return flags2nib(posflags(v[0])) | (flags2nib(posflags(v[1])) << 4) | (flags2nib(posflags(v[2])) << 8) |
-         (flags2nib(posflags(v[3])) << 12);
-}
+ARCLE_DEV uint32_t nz16(const U4& v) { return flags16(nzflags(v[0]), nzflags(v[1]), nzflags(v[2]), nzflags(v[3])); }
+ARCLE_DEV uint32_t pos16(const U4& v) { return flags16(posflags(v[0]), posflags(v[1]), posflags(v[2]), posflags(v[3])); }
 // 0xff for every byte that is > 0 as int8
 ARCLE_DEV U4 posbytes(const U4& v) {
   U4 r;
@@ -194,10 +206,8 @@ ARCLE_DEV U4 u4_sel1(const U4& m, uint32_t a, const U4& b) {  // m ? a(uniform d
   return r;
 }
 ARCLE_DEV uint32_t eq16(const U4& v, uint32_t byte) {  // bytes == byte
-  uint32_t c = (byte & 0xffu) * 0x01010101u, m = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) m |= (flags2nib(nzflags(v[i] ^ c)) ^ 0xfu) << (4 * i);
-  return m;
+  const uint32_t c = (byte & 0xffu) * 0x01010101u;
+  return flags16(nzflags(v[0] ^ c), nzflags(v[1] ^ c), nzflags(v[2] ^ c), nzflags(v[3] ^ c)) ^ 0xffffu;
 }
 ARCLE_DEV uint32_t u4_byte(const U4& v, int k) {  // dynamic byte extract
   uint32_t w = (k & 8) ? ((k & 4) ? v[3] : v[2]) : ((k & 4) ? v[1] : v[0]);
@@ -262,10 +272,16 @@ struct Wave {
   bool resident;
   mutable U4 cache[ARCLE_N_PLANES];
   mutable uint32_t dirty;  // planes of `cache` that differ from HBM
+  // accounting instantiations: bytes of global-memory accesses this wave ISSUED (every plane / table / row access, whole 16-byte
+  // lanes incl. row padding) — next to the algorithmic figure of SURVEY.md 8d it shows what the implementation really moves
+  bool count;
+  mutable uint32_t issued;
 
-  ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, const U2* lut_, int lane_, int ingress_, int fw_, bool resident_)
+  ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, const U2* lut_, int lane_, int ingress_, int fw_, bool resident_, bool count_ = false)
       : p(p_), lds(l), lut(lut_), lane(lane_) {
-    ingress = ingress_;
+    count = count_;
+    issued = 0;
+    ingress = ingress_ == INGRESS_BBOX5 ? INGRESS_BBOX : ingress_;  // (the record form only differs in where the kernel loads it from)
     fw = fw_;
     resident = resident_;
     dirty = 0;
@@ -289,10 +305,12 @@ struct Wave {
   ARCLE_DEV U4 load_hbm(int pl) const {
     U4 v = u4_zero();
     if (live) v = xl::load16(p.plane[pl], poff);
+    if (count) issued += (uint32_t)p.PS;
     return v;
   }
   ARCLE_DEV void store_hbm(int pl, const U4& v) const {
     if (live) xl::store16(p.plane[pl], poff, v);
+    if (count) issued += (uint32_t)p.PS;
   }
   ARCLE_DEV U4 load(int pl) const { return resident ? cache[pl] : load_hbm(pl); }
   ARCLE_DEV void store(int pl, const U4& v) const {
@@ -420,24 +438,26 @@ struct Sel {
 // Cell masks of the selection.  For a bbox / point tuple they are a rectangle mask built where an op needs it (most ops of
 // the O2ARC table read only the tuple: FloodFill, Copy, Paste, CropGrid, ResizeGrid), for a mask payload ingest_cells made them.
 ARCLE_DEV uint32_t sel_nz(const Wave& w, const Sel& s) {
-  return (s.is_rect && w.ingress != INGRESS_MASK) ? w.rect16(s.x0, s.x1, s.y0, s.y1) : s.nz;
+  return (s.is_rect && is_tuple(w.ingress)) ? w.rect16(s.x0, s.x1, s.y0, s.y1) : s.nz;
 }
 // any cell with sel > 0 ?
 ARCLE_DEV bool sel_any_pos(const Wave& w, const Sel& s);
 ARCLE_DEV uint32_t sel_pos(const Wave& w, const Sel& s) {
   if (w.ingress == INGRESS_MASK) return pos16(s.vals) & w.valid16;  // (derived where an op needs it: object ops, Copy, Paste)
+  if (w.ingress == INGRESS_BITS) return s.nz;                        // boolean masks: truthy == positive
   return w.rect16(s.x0, s.x1, s.y0, s.y1);
 }
 
 ARCLE_DEV bool sel_any_pos(const Wave& w, const Sel& s) {
-  if (w.ingress != INGRESS_MASK) return s.any_pos;
+  if (is_tuple(w.ingress)) return s.any_pos;
+  if (w.ingress == INGRESS_BITS) return s.any_nz;
   return s.any_nz && w.any(sel_pos(w, s) != 0);
 }
 
 // the raw int8 selection values (`selected = sel`, keep_sel object.py:38; mask ingress keeps what it loaded)
 ARCLE_DEV U4 sel_values(const Wave& w, const Sel& s) {
-  if (!s.is_rect || w.ingress == INGRESS_MASK) return s.vals;
-  return u4_and1(w.expand16(sel_nz(w, s)), 0x01010101u);
+  if (w.ingress == INGRESS_MASK) return s.vals;
+  return u4_and1(w.expand16(sel_nz(w, s)), 0x01010101u);  // tuples and bit masks: ones where selected
 }
 
 // The selection payload of this env.  bbox = 4 ints, point = 2 ints: wave-uniform scalar loads; mask = this lane's
@@ -452,6 +472,9 @@ ARCLE_DEV U4 load_payload(const Wave& w, int env, size_t step, const void* sel) 
     const U2 b = xl::uload2(reinterpret_cast<const int32_t*>(sel) + 2 * e);
     v[0] = b[0];
     v[1] = b[1];
+  } else if (w.ingress == INGRESS_BITS) {
+    // this lane's 16 cells are 16 consecutive bits of the env's 128-byte row: one 2-byte load, no byte -> bit reduction at all
+    v[0] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(sel) + e * (size_t)ARCLE_BITS_STRIDE + 2 * w.lane);
   } else {
     const int8_t* src = reinterpret_cast<const int8_t*>(sel) + e * (size_t)p.P + 16 * w.lane;
     if ((p.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(sel) & 3) == 0)) {
@@ -525,16 +548,19 @@ ARCLE_DEV bool ingest_scalar(const Wave& w, Sel& s, const U4& payload) {
 // `want_bbox`: the op reads the selection's bounding box at all (Color and FloodFill do not)
 ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload, bool want_rect = false, bool want_bbox = true) {
   const StepParams& p = w.p;
-  if (w.ingress != INGRESS_MASK) {  // (masks on demand: sel_nz / sel_pos)
+  if (is_tuple(w.ingress)) {  // (masks on demand: sel_nz / sel_pos)
     s.nz = s.pos = 0;
     s.vals = u4_zero();
     return;
   }
+  const bool bits = w.ingress == INGRESS_BITS;
   const U4 v = payload;
   s.is_rect = false;
   s.one_cell = -1;
-  s.vals = v;
-  s.nz = nz16(v) & w.valid16;
+  s.nz = (bits ? v[0] : nz16(v)) & w.valid16;
+  // (bit masks: the int8 view — ones where selected — is only materialised where something reads it: sel_values, and here for the
+  // generic-width FloodFill that sums the values)
+  s.vals = bits ? (w.fw == FW_GENERIC ? u4_and1(w.expand16(s.nz), 0x01010101u) : u4_zero()) : v;
   s.pos = 0;  // (masks: sel_pos / sel_any_pos derive it from `vals` on demand)
   s.any_nz = w.any(s.nz != 0);
   s.any_pos = false;
@@ -557,8 +583,8 @@ ARCLE_DEV void ingest_cells(const Wave& w, Sel& s, const U4& payload, bool want_
       // a mask that is exactly its bounding box filled with ones (what BBoxWrapper / PointWrapper produce on the host,
       // bbox.py:22-30,43-49) takes the rectangle paths of the ops: same results, far fewer instructions
       const uint32_t rm = w.rect16(s.x0, s.x1, s.y0, s.y1);
-      const U4 ones = u4_and1(w.expand16(rm), 0x01010101u);
-      const bool same = s.nz == rm && v[0] == ones[0] && v[1] == ones[1] && v[2] == ones[2] && v[3] == ones[3];
+      const U4 ones = bits ? u4_zero() : u4_and1(w.expand16(rm), 0x01010101u);
+      const bool same = s.nz == rm && (bits || (v[0] == ones[0] && v[1] == ones[1] && v[2] == ones[2] && v[3] == ones[3]));
       s.is_rect = !w.any(!same);
     }
   } else if (s.any_nz) {
@@ -855,8 +881,10 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
   } else if (sel.one_cell >= 0) {
     // one truthy cell: np.sum(sel) is its value — the fill happens iff that value is 1 (color.py:91), seeded there
     seed = sel.one_cell;
-    const uint32_t mine = u4_byte(sel.vals, seed & 15);
-    if (xl::uniform(xl::shfl(mine, seed >> 4)) != 1u) return;
+    if (w.ingress != INGRESS_BITS) {  // (a boolean mask's one truthy cell IS 1)
+      const uint32_t mine = u4_byte(sel.vals, seed & 15);
+      if (xl::uniform(xl::shfl(mine, seed >> 4)) != 1u) return;
+    }
   } else {
     if (!sel.any_nz) return;  // an all-zero mask sums to 0
     // several truthy cells, none of them negative: the sum is at least 2 (the usual multi-cell selection — no reduction needed)
@@ -1026,7 +1054,8 @@ ARCLE_DEV U4 rot90_plane(const Wave& w, const U4& v, int& h, int& wd, int k) {
 
 // Copies table entry `t` (augmented by perm / rot_k) into the env's input + answer planes and the record's dims.
 // Returns false (nothing written) when a rot90 does not fit the H x W plane (non-square max_grid_size).
-ARCLE_DEV bool load_task(const Wave& w, Rec& r, int t, int rot_k, uint64_t perm, U4& input_out) {
+// `soften`: a quarter turn that does not fit is dropped (k &= 2) instead of failing — device-drawn augmentations never fail.
+ARCLE_DEV bool load_task(const Wave& w, Rec& r, int t, int rot_k, uint64_t perm, U4& input_out, bool soften = false) {
   const StepParams& p = w.p;
   U4 in = u4_zero(), an = u4_zero();
   if (w.live) {
@@ -1039,8 +1068,10 @@ ARCLE_DEV bool load_task(const Wave& w, Rec& r, int t, int rot_k, uint64_t perm,
     in = u4_and(permute_colours(in, perm), w.expand16(w.rect16(0, ih - 1, 0, iw - 1)));
     an = u4_and(permute_colours(an, perm), w.expand16(w.rect16(0, ah - 1, 0, aw - 1)));
   }
-  if (rot_k & 1) {
-    if (iw > p.H || ih > p.W || aw > p.H || ah > p.W) return false;
+  if (w.count) w.issued += 2u * (uint32_t)p.PS + 4u;
+  if ((rot_k & 1) && (iw > p.H || ih > p.W || aw > p.H || ah > p.W)) {
+    if (!soften) return false;
+    rot_k &= 2;
   }
   if (rot_k) {
     in = rot90_plane(w, in, ih, iw, rot_k);
@@ -1054,18 +1085,21 @@ ARCLE_DEV bool load_task(const Wave& w, Rec& r, int t, int rot_k, uint64_t perm,
   return true;
 }
 
-// A new episode for `env` with a task drawn on the device: bumps the env's episode counter, records the table index.
+// A new episode for `env` with a task drawn on the device: bumps the env's episode counter, records the table index.  Cannot fail:
+// a drawn quarter turn that does not fit a non-square H x W plane is dropped (the draw's k becomes k & 2; arcle_amd/sampling.py
+// documents the same rule), so episode / cur_task are committed for a task that really was loaded.
 ARCLE_DEV bool load_sampled_task(const Wave& w, Rec& r, int env, U4& input_out) {
   const StepParams& p = w.p;
   const uint32_t ep = xl::uniform((uint32_t)p.episode[env]);
   const TaskDraw d = draw_task(p.seed, (uint64_t)(p.env_base + env), ep, p.n_problems, p.pair_cnt, p.aug_flags);
   const int t = p.pair_off[d.problem] + d.sub;
+  const bool ok = load_task(w, r, t, d.rot_k, d.perm, input_out, true);
   xl::lanes_converged();
-  if (w.lane == 0) {
+  if (ok && w.lane == 0) {
     p.episode[env] = (int32_t)(ep + 1u);
     if (p.cur_task) p.cur_task[env] = t;
   }
-  return load_task(w, r, t, d.rot_k, d.perm, input_out);
+  return ok;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1135,7 +1169,20 @@ struct StepOut {
   int reward;      // 0/1
   bool term;       // bool(state['terminated'])
   uint32_t bytes;  // algorithmic HBM bytes of the step (0 for skipped steps)
+  uint32_t status; // ARCLE_ST_* bits this env raised in this step (also OR-ed into the handle's sticky status word)
 };
+ARCLE_DEV void raise_status(const StepParams& p, StepOut& out, uint32_t bits) {
+  xl::atomic_or(p.status, bits);
+  out.status |= bits;
+}
+// ARCLE_STEP_DENSE for a step that did not execute an action (auto-reset, skipped step): the pair (0, 0) — "no dense term";
+// the host layer turns it into reward 0 (Gymnasium next-step autoreset: the reset step's reward is 0)
+ARCLE_DEV void dense_none(const Wave& w) {
+  if (w.lane == 0) {
+    w.p.dense[2 * (size_t)w.env] = 0;
+    w.p.dense[2 * (size_t)w.env + 1] = 0;
+  }
+}
 
 // Everything of step() between "record/op/payload are in registers" and "record/counters/outputs go back to
 // memory": autoreset, op decode, the operation itself, reward.  Planes are read/written through w.load/w.store, so
@@ -1150,9 +1197,10 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   StepOut out;
   out.reward = 0;
   out.bytes = 0;
+  out.status = 0;
   // FL >= 0: the launch's step flags are this compile-time constant (the launcher picks the instantiation for the common
   // combination), so the flag tests below fold away
-  const uint32_t flags = FL >= 0 ? (uint32_t)FL : p.flags;
+  const uint32_t flags = FL >= 0 ? ((uint32_t)FL & 0xffffu) : p.flags;
   if (flags & (ARCLE_STEP_AUTORESET | (FEAT ? ARCLE_STEP_RESAMPLE : 0u))) {
     // next-step autoreset: an env whose episode ended (terminated, or — with ARCLE_STEP_TRUNCATE — out of steps) is
     // re-initialised instead of executing the action; ARCLE_STEP_RESAMPLE first draws a new task on the device
@@ -1163,9 +1211,10 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       const bool resample = FEAT && (flags & ARCLE_STEP_RESAMPLE);
       if (resample) ok = load_sampled_task(w, r, w.env, in);
       if (ok) init_state(w, r, cnt0, resample, in);
-      else xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+      else raise_status(p, out, ARCLE_ST_AUG_DOMAIN);
+      if (FEAT && (flags & ARCLE_STEP_DENSE)) dense_none(w);
       out.term = 0;
-      out.bytes = (uint32_t)(7 * P + 2 * ARCLE_REC_BYTES);
+      out.bytes = (uint32_t)((resample ? 9 : 7) * P + 2 * ARCLE_REC_BYTES);
       return out;
     }
   }
@@ -1175,7 +1224,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   const bool bad_op = ARCLE_OP_KIND(desc) == ARCLE_OP_NONE;
   if (bad_op) {
     // reference: IndexError / TypeError before any mutation
-    xl::atomic_or(p.status, ARCLE_ST_BAD_OP);
+    raise_status(p, out, ARCLE_ST_BAD_OP);
+    if (FEAT && (flags & ARCLE_STEP_DENSE)) dense_none(w);
     out.term = r.term() != 0;
     return out;
   }
@@ -1195,19 +1245,21 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   int eq = -1;  // grid == answer, evaluated at most once (Submit and reward see the same state)
 
   Sel sel;
-  if (!ingest_scalar(w, sel, payload)) xl::atomic_or(p.status, ARCLE_ST_BAD_SELECTION);
+  if (!ingest_scalar(w, sel, payload)) raise_status(p, out, ARCLE_ST_BAD_SELECTION);
   ingest_cells(w, sel, payload, kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP || kind == ARCLE_OP_COPY || kind == ARCLE_OP_CROP_GRID,
                kind != ARCLE_OP_COLOR && kind != ARCLE_OP_FLOODFILL);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
-  if (FEAT && ING == INGRESS_MASK && (flags & ARCLE_STEP_CONTINUE_RULE) &&
+  if (ING == INGRESS_BITS) ARCLE_ACCT((P + 7) >> 3);
+  if (FEAT && is_cells(ING) && (flags & ARCLE_STEP_CONTINUE_RULE) &&
       (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
     // the O2ARC trace harness (tests/o2arc_check.py:169-170): an object op whose logged selection equals the env's
     // current `selected` plane continues the active object, i.e. is sent with an empty selection
     const U4 cur = w.load(ARCLE_PL_SELECTED);
     const U4 vm = w.expand16(w.valid16);
     uint32_t diff = 0;
+    const U4 given = sel_values(w, sel);
 #pragma unroll
-    for (int i = 0; i < 4; i++) diff |= (cur[i] ^ sel.vals[i]) & vm[i];
+    for (int i = 0; i < 4; i++) diff |= (cur[i] ^ given[i]) & vm[i];
     if (!w.any(diff != 0)) {
       sel.nz = sel.pos = 0;
       sel.vals = u4_zero();
@@ -1478,7 +1530,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   return out;
 #endif
   if (domain_error) {  // the reference raised inside the op: the step did not happen (nothing was written yet)
-    xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+    raise_status(p, out, ARCLE_ST_ROTATE_DOMAIN);
+    if (FEAT && (flags & ARCLE_STEP_DENSE)) dense_none(w);
     r.w[3] = w3_before;
     out.term = r.term() != 0;
     return out;
@@ -1499,13 +1552,13 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     // the host forms  sparse*100 - 1 + correct/total
     need_grid<ACCT>(w, s);
     const U4 a = w.load(ARCLE_PL_ANSWER);
+    ARCLE_ACCT(P + 8);
     const int gh = r.gh(), gw = r.gw(), ah = r.ah(), aw = r.aw();
     const int mh = imin(gh, ah), mw = imin(gw, aw);
-    const U4 m = w.expand16(w.rect16(0, mh - 1, 0, mw - 1));
-    uint32_t same = 0;  // bit k: byte k of this lane matches inside the common rectangle
-#pragma unroll
-    for (int i = 0; i < 4; i++) same |= (flags2nib(nzflags((s.grid[i] ^ a[i]) | ~m[i])) ^ 0xfu) << (4 * i);
-    const int correct = w.wave_sum(__builtin_popcount(same & 0xffffu));
+    // cells of this lane's window that match inside the common rectangle
+    const uint32_t same = (flags16(nzflags(s.grid[0] ^ a[0]), nzflags(s.grid[1] ^ a[1]), nzflags(s.grid[2] ^ a[2]), nzflags(s.grid[3] ^ a[3])) ^ 0xffffu) &
+                          w.rect16(0, mh - 1, 0, mw - 1);
+    const int correct = (int)xl::wave_add((uint32_t)__builtin_popcount(same));
     int total = mh * mw;
     if ((gh <= ah) == (gw <= aw)) total += ah * aw > gh * gw ? ah * aw - gh * gw : gh * gw - ah * aw;
     else total += (gh > ah ? gh - ah : ah - gh) * mw + (gw > aw ? gw - aw : aw - gw) * mh;
@@ -1523,6 +1576,9 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
 }
 
 ARCLE_DEV void flat_row(const Wave& w, const Rec& r);  // (the observation writers, below)
+struct StepOut;
+ARCLE_DEV void flat_tail(const Wave& w, const StepOut& out, const I2& cnt, bool truncated);
+ARCLE_HD int flat_obs_len(const StepParams& p, int filtered);
 ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride);
 ARCLE_HD int packed_stride(int P);
 
@@ -1542,9 +1598,12 @@ ARCLE_DEV StepInputs load_inputs(const Wave& w, int env, const int8_t* rec, cons
   // 32-bit unsigned byte offsets: the scalar loads take them as an SGPR offset (no 64-bit address arithmetic per array)
   const uint32_t e = (uint32_t)env;
   in.rec = xl::uload4(at(rec, e * (uint32_t)ARCLE_REC_BYTES));
-  in.op = xl::uload1(at(op, e * 4u));
+  if (ING != INGRESS_BBOX5) in.op = xl::uload1(at(op, e * 4u));
   in.cnt = xl::uload2(at(cnt, e * 8u));
-  if (ING == INGRESS_BBOX) {
+  if (ING == INGRESS_BBOX5) {  // one 20-byte record per env: the four corners, then the operation (rows are only dword aligned)
+    in.payload = xl::uload4(at(sel, e * 20u));
+    in.op = xl::uload1(at(sel, e * 20u + 16u));
+  } else if (ING == INGRESS_BBOX) {
     in.payload = xl::uload4(at(sel, e * 16u));
   } else if (ING == INGRESS_POINT) {
     const U2 b = xl::uload2(at(sel, e * 8u));
@@ -1568,7 +1627,9 @@ template <int ING, int FW, int ACCT, int FEAT, int FL = -1>
 ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0, uint64_t t_lut = 0) {
   const StepParams& p = w.p;
   const int lane = w.lane;
-  if (ING != INGRESS_MASK) xl::arrived(in.rec, in.cnt, in.op, in.payload);  // one wait for all four scalar loads
+  // (FL >= 0: the kernel wrote the compile-time flag set into its copy of the parameters, so p.flags folds as well)
+  const uint32_t flags = FL >= 0 ? ((uint32_t)FL & 0xffffu) : p.flags;
+  if (is_tuple(ING)) xl::arrived(in.rec, in.cnt, in.op, in.payload);  // one wait for all four scalar loads
   else xl::arrived3(in.rec, in.cnt, in.op);
 #ifdef ARCLE_TRACE_WAVES  // diagnostic build: per-wave shader clocks into the acct buffer (as uint64[N][8])
   const uint64_t t_in = xl::clock();
@@ -1586,11 +1647,12 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   xl::sink_s(r.w[0] + r.w[1] + r.w[2] + r.w[3] + (uint32_t)cnt0.x + (uint32_t)cnt0.y + in.op + in.payload[0] + in.payload[3]);
   return;
 #endif
-  const StepOut out = step_core<ING, FW, ACCT, FEAT, FL>(w, r, cnt0, in.payload, (int)in.op);
+  StepOut out = step_core<ING, FW, ACCT, FEAT, FL>(w, r, cnt0, in.payload, (int)in.op);
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_core = xl::clock();
 #endif
-  // ---- epilogue: record (only when it changed), counters and the step outputs ------------------------
+  // ---- epilogue: record, counters and the step outputs ------------------------------------------------
+  const bool truncated = (flags & ARCLE_STEP_TRUNCATE) && cnt0.x >= p.step_limit;
   xl::lanes_converged();  // (emulator: every lane has read the record / counters before lane 0 rewrites them)
   if (lane == 0) {
     // (the 16 B record is written back unconditionally: comparing it with what was loaded costs 13 scalar instructions per wave,
@@ -1605,7 +1667,37 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
     *reinterpret_cast<I2*>(at(p.cnt, e * 8u)) = cnt0;
     *at(p.reward, e * 4u) = out.reward;
     *at(p.term, e) = (uint8_t)out.term;
-    if ((FL >= 0 ? (uint32_t)FL : p.flags) & ARCLE_STEP_TRUNCATE) *at(p.trunc, e) = (uint8_t)(cnt0.x >= p.step_limit);
+    if (flags & ARCLE_STEP_TRUNCATE) *at(p.trunc, e) = (uint8_t)truncated;
+  }
+  if (ACCT) {  // what the wave moved besides planes: record + counters in and out, action in, outputs out
+    const uint32_t act = ING == INGRESS_MASK ? (uint32_t)p.P : ING == INGRESS_BITS ? 2u * 64u : ING == INGRESS_POINT ? 12u : 20u;
+    w.issued += 2u * ARCLE_REC_BYTES + 16u + act + 5u;
+    if (flags & ARCLE_STEP_TRUNCATE) { w.issued += 1u; out.bytes += 1u; }
+    if (FEAT && (flags & ARCLE_STEP_DENSE)) w.issued += 8u;
+  }
+  if (FEAT && (flags & ARCLE_STEP_FLAT_OBS)) {
+    // fused observation writer: the flattened row of the state this step just produced (FlattenObservation, optionally after
+    // FilterO2ARC), written by the same wave — no second launch, no re-read of
+    // the record.  The planes are read back through the wave's own L1 path (program order, see xl::own_stores_visible).
+    xl::own_stores_visible();
+    flat_row(w, r);
+    if (p.flat_tail) flat_tail(w, out, cnt0, truncated);
+    if (ACCT) {
+      out.bytes += 2u * (uint32_t)flat_obs_len(p, p.flat_filter) + ARCLE_REC_BYTES;  // planes + record read once, row written once
+      w.issued += (uint32_t)p.flat_stride;
+    }
+  }
+  // fused packed row for the multi-GPU gather (grid | grid_dim | reward | terminated): in the feature instantiations, and in
+  // the lean ones whose compile-time flags ask for it
+  if ((FEAT || FL >= 0) && (flags & ARCLE_STEP_PACK_OBS)) {
+    xl::own_stores_visible();
+    pack_row(w, r, (uint32_t)out.reward, (uint32_t)out.term, p.pack_out, packed_stride(p.P));
+    if (ACCT) {
+      out.bytes += (uint32_t)(p.P + packed_stride(p.P));
+      w.issued += (uint32_t)packed_stride(p.P);
+    }
+  }
+  if (lane == 0) {
 #ifdef ARCLE_TRACE_WAVES
     if (ACCT) {
       uint64_t* tr = reinterpret_cast<uint64_t*>(p.acct) + 8 * (size_t)env;
@@ -1616,21 +1708,11 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
       tr[4] = xl::clock();
     }
 #else
-    if (ACCT) p.acct[env] += out.bytes;
+    if (ACCT && p.acct) {  // [0, N): algorithmic bytes, [N, 2N): bytes of the accesses actually issued
+      p.acct[env] += out.bytes;
+      p.acct[(size_t)p.n_envs + env] += w.issued;
+    }
 #endif
-  }
-  if (FEAT && (p.flags & ARCLE_STEP_FLAT_OBS)) {
-    // fused observation writer: the flattened row of the state this step just produced (FlattenObservation, optionally after
-    // FilterO2ARC), written by the same wave — no second launch, no re-read of
-    // the record.  The planes are read back through the wave's own L1 path (program order, see xl::own_stores_visible).
-    xl::own_stores_visible();
-    flat_row(w, r);
-  }
-  // fused packed row for the multi-GPU gather (grid | grid_dim | reward | terminated): in the feature instantiations, and in
-  // the lean ones whose compile-time flags ask for it
-  if ((FEAT || FL >= 0) && ((FL >= 0 ? (uint32_t)FL : p.flags) & ARCLE_STEP_PACK_OBS)) {
-    xl::own_stores_visible();
-    pack_row(w, r, (uint32_t)out.reward, (uint32_t)out.term, p.pack_out, packed_stride(p.P));
   }
 }
 
@@ -1658,7 +1740,7 @@ ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, const U2* lut, in
   uint32_t next_op = (uint32_t)p.op[env];
   for (int t = 0; t < p.n_steps; t++) {
     U4 payload = next_payload;
-    if (ING != INGRESS_MASK) {
+    if (is_tuple(ING)) {
 #pragma unroll
       for (int i = 0; i < 4; i++) payload[i] = xl::uniform(payload[i]);
     }
@@ -1668,7 +1750,7 @@ ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, const U2* lut, in
       next_op = (uint32_t)p.op[((size_t)t + 1) * N + env];
     }
     // (the feature flags a rollout accepts — continuation rule, reset_on_submit — belong to mask-ingress trace replay)
-    const StepOut out = step_core<ING, FW, 0, ING == INGRESS_MASK ? 1 : 0>(w, r, cnt, payload, op);
+    const StepOut out = step_core<ING, FW, 0, is_cells(ING) ? 1 : 0>(w, r, cnt, payload, op);
     if (lane == 0) {
       p.reward[(size_t)t * N + env] = out.reward;
       p.term[(size_t)t * N + env] = (uint8_t)out.term;
@@ -1726,7 +1808,7 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
     ok = load_sampled_task(w, r, env, in);
   }
   if (!ok) {
-    xl::atomic_or(p.status, ARCLE_ST_ROTATE_DOMAIN);
+    xl::atomic_or(p.status, ARCLE_ST_AUG_DOMAIN);
     return;
   }
   I2 cnt;
@@ -1754,7 +1836,7 @@ struct FlatRow {
 ARCLE_DEV void flat_plane(const Wave& w, FlatRow& fr, int pl) {
   if (!w.p.plane[pl]) return;
   const int P = w.p.P, off = fr.off, lane = w.lane;
-  w.stage(w.lds->a, w.load_hbm(pl));
+  w.stage(w.lds->a, w.load(pl));  // (the state-row kernels keep the planes in registers: `load` serves them from there)
   const int c0 = (off + 15) >> 4, S = 16 * c0 - off;  // first whole chunk of the row inside the segment; its plane byte offset
   const int n_full = ((off + P) >> 4) - c0;           // whole chunks (<= 64); negative: the segment ends inside its first chunk
   const U4 o = w.shifted(w.lds->a, S);
@@ -1819,6 +1901,134 @@ ARCLE_DEV void flat_row(const Wave& w, const Rec& r) {
   if (lane < 16 && fr.off + lane < p.flat_stride) fr.row[fr.off + lane] = 0;  // row padding up to the stride
 }
 
+// Optional tail of a flat row (arcle_set_flat_output_ex, tail = 1): the last 16 bytes of the row's stride carry the step outputs, so
+// that ONE copy of the row brings everything a caller of step() needs —
+//   int32 reward | int32 action_steps | int32 submit_count | uint8 terminated | uint8 truncated | uint8 status (ARCLE_ST_* raised by
+//   THIS env in THIS step) | 0
+ARCLE_DEV void flat_tail(const Wave& w, const StepOut& out, const I2& cnt, bool truncated) {
+  const StepParams& p = w.p;
+  if (w.lane == 0) {
+    U4 t;
+    t[0] = (uint32_t)out.reward;
+    t[1] = (uint32_t)cnt.x;
+    t[2] = (uint32_t)cnt.y;
+    t[3] = (uint32_t)out.term | ((uint32_t)truncated << 8) | ((out.status & 0xffu) << 16);
+    *reinterpret_cast<U4*>(p.flat_out + (size_t)w.env * p.flat_stride + (p.flat_stride - 16)) = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// state rows IN: the inverse of flat_row (full layout) — a flattened state row becomes planes + record again.  This is what makes
+// transition(state, action) (o2arcenv.py:149-151; README.md:55 `env.transition(deepcopy(state), action)`) a stateless, batched
+// device operation, and what a checkpoint restores from.
+// ------------------------------------------------------------------------------------------------
+// this lane's 16 cells of the plane segment that starts at byte `off` of the row (any alignment); bytes >= P are zero
+ARCLE_DEV U4 row_plane(const Wave& w, const int8_t* row, int off) {
+  const int P = w.p.P, f0 = 16 * w.lane;
+  U4 v = u4_zero();
+  if (f0 + 16 <= P) {
+    v = xl::load16u(row + off + f0);
+  } else if (f0 < P) {  // the lane holding the segment's tail: byte by byte, never past the segment (the row may end right behind it)
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if (f0 + k < P) v[k >> 2] |= (uint32_t)(uint8_t)row[off + f0 + k] << (8 * (k & 3));
+  }
+  if (w.count) w.issued += (uint32_t)P;
+  return v;
+}
+ARCLE_DEV uint32_t row_byte(const int8_t* row, int off) { return xl::uniform((uint32_t)(uint8_t)row[off]); }
+// `sink(plane id, bytes)` receives every plane of the row; the record's state fields are filled in (answer_dim untouched)
+template <typename Sink>
+ARCLE_DEV void read_state_row(const Wave& w, const int8_t* row, Rec& r, Sink&& sink) {
+  const StepParams& p = w.p;
+  const int P = p.P;
+  const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
+  int off = 0;
+  auto plane = [&](int pl) __attribute__((always_inline)) {
+    sink(pl, row_plane(w, row, off));
+    off += P;
+  };
+  auto scalar = [&](int field, int n) __attribute__((always_inline)) {
+    r.put(field, (int)row_byte(row, off));
+    if (n == 2) r.put(field + 1, (int)row_byte(row, off + 1));
+    off += n;
+  };
+  if (clip) {
+    plane(ARCLE_PL_CLIP);
+    scalar(ARCLE_REC_CLIP_DIM, 2);
+  }
+  plane(ARCLE_PL_GRID);
+  scalar(ARCLE_REC_GRID_DIM, 2);
+  plane(ARCLE_PL_INPUT);
+  scalar(ARCLE_REC_INPUT_DIM, 2);
+  if (o2) {
+    scalar(ARCLE_REC_ACTIVE, 1);
+    plane(ARCLE_PL_BACKGROUND);
+    plane(ARCLE_PL_OBJECT);
+    scalar(ARCLE_REC_OBJECT_DIM, 2);
+    scalar(ARCLE_REC_OBJECT_POS, 2);
+    plane(ARCLE_PL_OBJECT_SEL);
+    scalar(ARCLE_REC_PARITY, 1);
+    plane(ARCLE_PL_SELECTED);
+  }
+  scalar(ARCLE_REC_TERMINATED, 1);
+  scalar(ARCLE_REC_TRIALS, 1);
+}
+
+// arcle_set_state_rows: row `env` of p.rows_in -> the resident state of env `env` (planes + record; the task's answer / answer_dim
+// and the counters are not part of a state row and stay)
+ARCLE_DEV void wave_set_state_row(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
+  if (p.rmask && !xl::uniform((uint32_t)p.rmask[env])) return;
+  Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
+  w.set_env(env);
+  Rec r = load_rec(p, env);
+  read_state_row(w, p.rows_in + (size_t)env * p.rows_in_stride, r, [&](int pl, const U4& v) { w.store_hbm(pl, v); });
+  xl::lanes_converged();
+  store_rec(p, env, lane, r);
+}
+
+// arcle_transition_rows: ONE operation applied to the state held in row `row` of p.rows_in, result written as row `row` of
+// p.flat_out — transition(state, action) of the reference for a whole batch of (state, action) pairs, none of which touches the
+// handle's resident envs.  The task-side data a transition can read (answer, answer_dim: Submit and the reward) come from resident
+// env p.task_idx[row] (NULL: env `row`).  reward / terminated as step(); the row's optional tail (p.flat_tail) carries them as
+// well, with action_steps = 1 and submit_count = 1 iff the op was a Submit that counted (base.py:174-175).
+template <int ING, int FW>
+ARCLE_DEV void wave_transition_row(const StepParams& p, WaveLDS* lds, const U2* lut, int row, int lane) {
+  Wave w(p, lds, lut, lane, ING, FW, false);
+  int src = row;
+  if (p.task_idx) src = (int)xl::uniform((uint32_t)p.task_idx[row]);
+  StepOut out;
+  out.reward = 0;
+  out.term = false;
+  out.bytes = 0;
+  out.status = 0;
+  I2 cnt;
+  cnt.x = cnt.y = 0;
+  const int8_t* rin = p.rows_in + (size_t)row * p.rows_in_stride;
+  if (src < 0 || src >= p.n_resident) {  // no such env to take the answer from: the row is passed through untouched
+    raise_status(p, out, ARCLE_ST_BAD_TASK);
+    src = 0;
+  }
+  w.set_env(src);
+#pragma unroll
+  for (int pl = 0; pl < ARCLE_N_PLANES; pl++) w.cache[pl] = u4_zero();
+  w.cache[ARCLE_PL_ANSWER] = w.load_hbm(ARCLE_PL_ANSWER);
+  Rec r = load_rec(p, src);  // (answer_dim; every state field is overwritten from the row)
+  read_state_row(w, rin, r, [&](int pl, const U4& v) { w.cache[pl] = v; });
+  w.resident = true;
+  w.env = row;  // outputs (dense pair, flat row) are indexed by the row
+  const U4 pay = load_payload(w, row, 0, p.sel);
+  const int op = (int)xl::uniform((uint32_t)p.op[row]);
+  if (!out.status) out = step_core<ING, FW, 0, 1>(w, r, cnt, pay, op);
+  xl::lanes_converged();
+  if (lane == 0) {
+    p.reward[row] = out.reward;
+    p.term[row] = (uint8_t)out.term;
+  }
+  flat_row(w, r);
+  if (p.flat_tail) flat_tail(w, out, cnt, false);
+}
+
 ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
   Wave w(p, lds, lut, lane, INGRESS_BBOX, FW_GENERIC, false);
   w.set_env(env);
@@ -1836,7 +2046,7 @@ ARCLE_HD int packed_stride(int P) { return (P + 7 + 15) & ~15; }
 ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride) {
   const int P = w.p.P, lane = w.lane;
   if (16 * lane >= stride) return;
-  U4 v = w.load_hbm(ARCLE_PL_GRID);  // (bytes >= P of the plane row are zero padding)
+  U4 v = w.load(ARCLE_PL_GRID);  // (bytes >= P of the plane row are zero padding)
   if (16 * lane + 16 > P) {          // this lane's window holds the metadata bytes
     // the 7 metadata bytes as one little-endian word: grid_dim (2), reward int32 (4), terminated (1)
     const uint64_t meta = (uint64_t)(uint32_t)r.gh() | ((uint64_t)(uint32_t)r.gw() << 8) | ((uint64_t)reward << 16) | ((uint64_t)(term & 0xffu) << 48);

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ARCLE_ABI_VERSION 2
+#define ARCLE_ABI_VERSION 3
 #define ARCLE_MAX_OPS 64
 #define ARCLE_MAX_CELLS 1024 /* H*W <= 1024 (one 64-lane wavefront x 16 cells) */
 /* default per-env plane stride: H*W rounded up to a whole number of 128-byte lines (30x30 -> 1024 B), so that no two
@@ -162,6 +162,9 @@ enum arcle_op_kind {
                                     does not fit HxW (reference: ValueError/garbage,
                                     SURVEY.md A.6-2, A.6-6): step skipped                  */
 
+#define ARCLE_ST_AUG_DOMAIN 16u   /* arcle_reset_from_table_aug: an explicit rot90 by an odd count does not fit a non-square
+                                    H x W plane: env left untouched (device-drawn augmentations drop the quarter turn instead) */
+
 enum arcle_status {
   ARCLE_OK = 0,
   ARCLE_ERR_ARG = -1,     /* NULL / out-of-range argument                                */
@@ -235,6 +238,28 @@ int arcle_step_bbox(arcle_env* env, const int32_t* bbox, const int32_t* op, int3
 int arcle_step_point(arcle_env* env, const int32_t* xy, const int32_t* op, int32_t* reward,
                      uint8_t* term, uint32_t flags, void* stream);
 
+/* Two more forms of the action, same step():
+ *   _bbox5: act5 device int32[n_envs][5]   the BBoxWrapper action as ONE record per env (x1, y1, x2, y2, operation) — exactly the
+ *           5-tuple `BBoxWrapper.action` receives (bbox.py:22-30, examples/example_bbox.py:13-15); no separate op array, so a
+ *           host-resident policy moves its actions with one 20-byte-per-env copy (or none: act5 may be pinned host memory)
+ *   _bits : bits device uint8[n_envs][128] boolean selection masks, bit-packed: bit (f & 7) of byte (f >> 3) of row e = cell f
+ *           (row-major, f = row * W + col) of env e is selected; rows are ARCLE_MAX_CELLS / 8 = 128 bytes apart, 2-byte aligned.
+ *           `create_action_space` accepts boolean masks (base.py:134-138); packed they are 1/8 of the int8 traffic and need no
+ *           byte -> bit reduction in the kernel.  arcle_pack_mask_bits converts int8 [n_envs][H*W] masks (truthy = non-zero). */
+enum arcle_ingress { ARCLE_INGRESS_MASK = 0, ARCLE_INGRESS_BBOX = 1, ARCLE_INGRESS_POINT = 2, ARCLE_INGRESS_BBOX5 = 3, ARCLE_INGRESS_BITS = 4 };
+int arcle_step_bbox5(arcle_env* env, const int32_t* act5, int32_t* reward, uint8_t* term, uint32_t flags, void* stream);
+int arcle_step_bits(arcle_env* env, const uint8_t* bits, const int32_t* op, int32_t* reward, uint8_t* term, uint32_t flags,
+                    void* stream);
+int arcle_pack_mask_bits(arcle_env* env, const int8_t* sel, uint8_t* bits, void* stream);
+
+/* n_steps consecutive step() LAUNCHES enqueued by ONE call (the loop `for t in range(n): env.step(actions[t])` of a caller that
+ * holds the actions of the next n steps; every step is a full step(): state observable in between on the stream, all step flags
+ * valid).  `ingress`: arcle_ingress; sel: the form's payload [n_steps][n_envs][...]; op int32 [n_steps][n_envs] (NULL for BBOX5);
+ * reward int32 [n_steps][n_envs], term uint8 [n_steps][n_envs] out.  Per-handle outputs (truncated, dense, flat / packed rows) hold
+ * the LAST step's values afterwards.  Capturable into a hipGraph like the single-step calls (no synchronisation, no allocation). */
+int arcle_step_many(arcle_env* env, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
+                    uint8_t* term, uint32_t flags, void* stream);
+
 /* n_steps consecutive step()s of every env in ONE launch — a rollout / trace replay for callers that already hold
  * the whole action sequence (the loop `for a in trace: env.step(a)`, e.g. tests/o2arc_check.py:139-199 of the
  * reference).  Semantically identical to n_steps calls of arcle_step_bbox/_point; the env state is kept on chip
@@ -287,6 +312,38 @@ int arcle_flatten_obs(arcle_env* env, int8_t* out, int32_t out_stride, int filte
  * produced (same stream, one ABI call per step, no host round trip).  out == NULL removes it. */
 int arcle_set_flat_output(arcle_env* env, int8_t* out, int32_t out_stride, int filtered);
 
+/* The same with tail != 0: the LAST 16 bytes of every row's stride then carry the step outputs of the env —
+ *   int32 reward | int32 action_steps | int32 submit_count | uint8 terminated | uint8 truncated | uint8 status | 0
+ * (status: the ARCLE_ST_* bits THIS env raised in THIS step) — so that one copy of the row (or none, when `out` is pinned host
+ * memory) returns everything step() returns.  out_stride >= arcle_flat_obs_size() rounded up to 16, plus 16. */
+int arcle_set_flat_output_ex(arcle_env* env, int8_t* out, int32_t out_stride, int filtered, int tail);
+
+/* ---- state rows at the boundary -------------------------------------------------------------------------------------------
+ * A "state row" is the full (unfiltered) flattened observation of one env: the reference's state dict (base.py:155-166,
+ * o2arcenv.py:16-34) as arcle_flat_obs_size(env, 0) bytes in FlattenObservation order.
+ *   arcle_get_state_rows   = arcle_flatten_obs(.., filtered = 0): resident state -> rows (16-byte aligned, stride multiple of 16)
+ *   arcle_set_state_rows   rows -> resident state of env e for every e with mask[e] != 0 (mask NULL = all); any row alignment /
+ *                          stride >= the row length.  The inverse of the above: get + set is a checkpoint / restore of the state
+ *                          dict (the task side — answer, answer_dim — and the counters are not part of a row and stay).
+ *   arcle_transition_rows  the reference's `transition(state, action)` (o2arcenv.py:149-151; README.md:55
+ *                          `env.transition(deepcopy(state), action)`) for a BATCH of (state, action) pairs: row r of rows_in + action r
+ *                          -> row r of rows_out; the handle's resident envs are not touched, so any number of hypothetical states
+ *                          (planning / search) can be expanded per launch.  Submit and the reward compare with the answer of resident
+ *                          env src_env[r] (device int32[n_rows]; NULL = env r, then n_rows <= n_envs).  ingress: ARCLE_INGRESS_MASK /
+ *                          _BBOX / _POINT with the matching `sel` array [n_rows][...]; op int32[n_rows]; reward int32[n_rows],
+ *                          term uint8[n_rows] out; tail as arcle_set_flat_output_ex (action_steps = 1, submit_count = 1 iff the
+ *                          Submit counted, base.py:174-175).  flags: ARCLE_STEP_RESET_ON_SUBMIT | _DENSE | _CONTINUE_RULE.
+ *                          rows_out may equal rows_in when the strides agree (in place). */
+int arcle_get_state_rows(arcle_env* env, int8_t* rows, int32_t stride, void* stream);
+int arcle_set_state_rows(arcle_env* env, const int8_t* rows, int32_t stride, const uint8_t* mask, void* stream);
+int arcle_transition_rows(arcle_env* env, int32_t n_rows, const int8_t* rows_in, int32_t in_stride, int ingress, const void* sel,
+                          const int32_t* op, const int32_t* src_env, int8_t* rows_out, int32_t out_stride, int tail,
+                          int32_t* reward, uint8_t* term, uint32_t flags, void* stream);
+/* One state plane as a dense [n_envs][H*W] int8 array (device or pinned host memory), a strided copy on the stream: the
+ * get_state()/set_state() of single keys of the reference's state dict. */
+int arcle_get_plane(arcle_env* env, int plane, int8_t* dst, void* stream);
+int arcle_set_plane(arcle_env* env, int plane, const int8_t* src, void* stream);
+
 /* Packed minimal observation for a central learner (what the multi-GPU gather moves): one row per env,
  *   grid (H*W bytes) | grid_dim (2) | reward int32 little-endian (4) | terminated (1) | zero padding
  * of arcle_packed_obs_size() bytes (H*W + 7 rounded up to 16; 912 for 30x30).  reward / term are the arrays the last step
@@ -298,8 +355,12 @@ int arcle_set_packed_output(arcle_env* env, uint8_t* out);
 
 /* Reads and (optionally) clears the sticky device status word (ARCLE_ST_*): one atomic exchange on the device, so a
  * bit raised by a kernel on another stream is never lost between the read and the clear.  Synchronises the stream.
- * (arcle_set_op_table / arcle_set_task_table / arcle_set_sampler change what later launches see: call them with no
- * launch of this handle in flight — arcle_set_op_table synchronises the device itself.) */
+ * Ordering of the setters (arcle_set_op_table, _task_table, _sampler, _truncation, _dense_output, _flat_output, _packed_output):
+ * every launch takes its parameters — table pointers included — BY VALUE at the moment it is enqueued (or captured into a
+ * hipGraph).  A setter therefore changes what LATER launches see and never what is already in flight or captured; the library's
+ * own op-table copy is versioned (a new device buffer per arcle_set_op_table, the old ones are freed in arcle_destroy), and
+ * caller-owned arrays (task table, sampler arrays, output buffers) must simply stay alive until the launches / graphs that were
+ * given them have finished.  No setter synchronises. */
 int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);
 
 /* Algorithmic HBM bytes (SURVEY.md §8d accounting) moved by all step launches (and the observation rows written by
@@ -308,6 +369,10 @@ int arcle_get_status(arcle_env* env, uint32_t* status, int clear, void* stream);
  * was created with accounting enabled via arcle_enable_accounting(env, 1). */
 int arcle_enable_accounting(arcle_env* env, int on);
 int arcle_get_accounting(arcle_env* env, uint64_t* bytes, uint64_t* steps, int clear, void* stream);
+/* ... and next to the algorithmic figure `issued`: the bytes of every global-memory access the step kernel actually issued for
+ * those steps (whole 16-byte lanes of every plane access incl. row padding, record / counters / action / outputs, observation rows,
+ * task-table reads) — elided writes are not in it, re-reads are. */
+int arcle_get_accounting_ex(arcle_env* env, uint64_t* bytes, uint64_t* issued, uint64_t* steps, int clear, void* stream);
 
 const char* arcle_last_error(const arcle_env* env);
 int arcle_abi_version(void);

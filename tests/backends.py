@@ -101,7 +101,8 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("env_base", ctypes.c_int64), ("episode", ctypes.c_void_p), ("cur_task", ctypes.c_void_p),
                 ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p), ("aug_k", ctypes.c_void_p),
                 ("aug_perm", ctypes.c_void_p), ("n_problems", ctypes.c_int32),
-                ("wpw", ctypes.c_int32)]
+                ("wpw", ctypes.c_int32), ("flat_tail", ctypes.c_int32), ("rows_in", ctypes.c_void_p),
+                ("rows_in_stride", ctypes.c_int32), ("n_resident", ctypes.c_int32)]
 
 
 _emu = None
@@ -138,7 +139,7 @@ class EmuBackend:
         self.reward = np.zeros(N, np.int32)
         self.term = np.zeros(N, np.uint8)
         self.stat = np.zeros(1, np.uint32)
-        self.acct = np.zeros(N, np.uint32)
+        self.acct = np.zeros(2 * N, np.uint32)  # [0, N) algorithmic bytes, [N, 2N) issued bytes
         self.ops = list(ops)
 
     def _params(self):

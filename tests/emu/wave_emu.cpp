@@ -96,8 +96,17 @@ ARCLE_DEV uint32_t wave_or(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v |= shfl(v, cur_lane ^ o);
   return v;
 }
+ARCLE_DEV uint32_t wave_add(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += shfl(v, cur_lane ^ o);
+  return v;
+}
+ARCLE_DEV uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
+  for (int k = 0; k < 4; k++) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+  return c;
+}
 typedef uint32_t U4 __attribute__((vector_size(16)));
 typedef uint32_t U2 __attribute__((vector_size(8)));
+ARCLE_DEV U4 load16u(const int8_t* p) { U4 v; memcpy(&v, p, 16); return v; }
 // wave-uniform scalar loads: every lane reads the same address
 ARCLE_DEV uint32_t uload1(const void* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 ARCLE_DEV U2 uload2(const void* p) { U2 v; memcpy(&v, p, 8); return v; }
@@ -133,11 +142,12 @@ const size_t STACK = 256 * 1024;
 
 #define RUN_STEP(I, F)                                                                      \
   do {                                                                                      \
-    arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, I, F, false);                      \
+    arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, I, F, false, true);                \
     arcle::StepInputs in = arcle::load_inputs<I>(w, g_env);                                 \
-    if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, 0, 1>(w, g_env, in);           \
+    if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, 1, 1>(w, g_env, in);           \
     else arcle::wave_step<I, F, 1, 0>(w, g_env, in);                                        \
   } while (0)
+#define RUN_TRANS(I, F) arcle::wave_transition_row<I, F>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane)
 #define RUN_ROLL(I, F) arcle::wave_rollout<I, F>(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane)
 
 // the same width classes the HIP library launches: FW_FULL when 16 <= W <= 32 and the plane stride is 1024
@@ -161,8 +171,35 @@ void lane_main(int lane) {
       case 5: RUN_STEP(1, 2); break;
       case 6: RUN_STEP(2, 0); break;
       case 7: RUN_STEP(2, 1); break;
-      default: RUN_STEP(2, 2); break;
+      case 8: RUN_STEP(2, 2); break;
+      case 9: RUN_STEP(3, 0); break;
+      case 10: RUN_STEP(3, 1); break;
+      case 11: RUN_STEP(3, 2); break;
+      case 12: RUN_STEP(4, 0); break;
+      case 13: RUN_STEP(4, 1); break;
+      default: RUN_STEP(4, 2); break;
     }
+  }
+  else if (g_kind == 6)
+    arcle::wave_set_state_row(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
+  else if (g_kind == 7) {
+    const int f = fw ? 1 : 0;  // (as the library: FW_FAST code for FW_FULL)
+    switch (g_p->ingress * 2 + f) {
+      case 0: RUN_TRANS(0, 0); break;
+      case 1: RUN_TRANS(0, 1); break;
+      case 2: RUN_TRANS(1, 0); break;
+      case 3: RUN_TRANS(1, 1); break;
+      case 4: RUN_TRANS(2, 0); break;
+      default: RUN_TRANS(2, 1); break;
+    }
+  }
+  else if (g_kind == 8) {  // arcle_pack_mask_bits
+    arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, arcle::INGRESS_MASK, arcle::FW_GENERIC, false);
+    const arcle::U4 v = arcle::load_payload(w, g_env, 0, g_p->sel);
+    const uint32_t m = arcle::nz16(v) & w.valid16;
+    uint8_t* bits = reinterpret_cast<uint8_t*>(g_p->flat_out) + (size_t)g_env * ARCLE_BITS_STRIDE + 2 * lane;
+    bits[0] = (uint8_t)m;
+    bits[1] = (uint8_t)(m >> 8);
   }
   else if (g_kind == 2)
     arcle::wave_reset_table(*g_p, &g_lds.wave[0], g_lds.lut, g_env, lane);
@@ -174,7 +211,9 @@ void lane_main(int lane) {
       case 2: RUN_ROLL(1, 0); break;
       case 3: RUN_ROLL(1, 1); break;
       case 4: RUN_ROLL(2, 0); break;
-      default: RUN_ROLL(2, 1); break;
+      case 5: RUN_ROLL(2, 1); break;
+      case 8: RUN_ROLL(4, 0); break;
+      default: RUN_ROLL(4, 1); break;
     }
   }
   else if (g_kind == 4)
@@ -231,7 +270,8 @@ void run_wave() {
 }
 }  // namespace
 
-// kind: 0 = step, 1 = reset, 2 = reset from the task table (task_idx NULL: device-drawn), 3 = rollout, 4 = flatten, 5 = pack.  Fills derived fields (P, div_magic, nseg) like
+// kind: 0 = step, 1 = reset, 2 = reset from the task table (task_idx NULL: device-drawn), 3 = rollout, 4 = flatten, 5 = pack,
+// 6 = set_state_rows, 7 = transition_rows (n_envs = rows, n_resident = envs), 8 = pack_mask_bits (flat_out = the bit rows).  Fills derived fields (P, div_magic, nseg) like
 // arcle_create does; PS (plane stride) comes from the caller (0 = default).
 extern "C" int emu_run(int kind, arcle::StepParams* p) {
   p->P = p->H * p->W;

@@ -16,7 +16,7 @@ HEADER = os.path.join(B.ROOT, "include", "arcle_hip.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(arcle_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(arcle_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_declares_expected_entry_points():
