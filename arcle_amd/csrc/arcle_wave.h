@@ -1898,7 +1898,8 @@ ARCLE_DEV void flat_row(const Wave& w, const Rec& r) {
     flat_scalar(w, fr, r, ARCLE_REC_TERMINATED, 1);
     flat_scalar(w, fr, r, ARCLE_REC_TRIALS, 1);
   }
-  if (lane < 16 && fr.off + lane < p.flat_stride) fr.row[fr.off + lane] = 0;  // row padding up to the stride
+  // row padding up to the stride (or up to the step-output tail)
+  if (lane < 16 && fr.off + lane < p.flat_stride - (p.flat_tail ? 16 : 0)) fr.row[fr.off + lane] = 0;
 }
 
 // Optional tail of a flat row (arcle_set_flat_output_ex, tail = 1): the last 16 bytes of the row's stride carry the step outputs, so

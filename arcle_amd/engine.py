@@ -35,7 +35,8 @@ STEP_RESET_ON_SUBMIT = 64
 STEP_FLAT_OBS = 128
 STEP_PACK_OBS = 256
 AUG_PERMUTE, AUG_ROT90 = 1, 2
-ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION = 1, 2, 4, 8
+ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION, ST_AUG_DOMAIN = 1, 2, 4, 8, 16
+ROW_TAIL = 16  # bytes of the optional step-output tail of a flat row (arcle_set_flat_output_ex)
 
 
 def _ptr(t):
@@ -92,7 +93,12 @@ class EnvBatch:
             raise ArcleHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        """Raw handle of torch's CURRENT stream on this device (the private accessor is several times cheaper than building a
+        Stream object per call; it is what torch's own inductor runtime uses)."""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:  # pragma: no cover - older / newer torch without the private accessor
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     def plane(self, name):
         """Zero-copy [N,H,W] int8 view of a state plane (row stride PS)."""
@@ -243,6 +249,45 @@ class EnvBatch:
             sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
         return self._step(self.L.arcle_step_mask, sel, op, flags)
 
+    def step_bbox5(self, act5, flags=0):
+        """act5 int32 [N,5] = the BBoxWrapper action (x1, y1, x2, y2, operation) as one record per env (bbox.py:22-30): no separate
+        op array.  `act5` may also be PINNED HOST memory (the kernel reads it over PCIe: no copy node in front of the step)."""
+        if act5.dtype != torch.int32 or not act5.is_contiguous() or not (act5.device == self.device or act5.is_pinned()):
+            act5 = act5.to(device=self.device, dtype=torch.int32).contiguous()
+        self._check(self.L.arcle_step_bbox5(self._h, _ptr(act5), _ptr(self.reward), _ptr(self.term), int(flags), self._stream()),
+                    "arcle_step_bbox5")
+        return self.reward, self.term
+
+    def step_bits(self, bits, op, flags=0):
+        """bits uint8 [N,128]: bit-packed boolean selection masks (bit f of row e = cell f of env e; `pack_mask_bits` makes them)."""
+        assert bits.dtype == torch.uint8 and bits.shape == (self.N, _lib.BITS_STRIDE) and bits.is_contiguous() and bits.device == self.device
+        return self._step(self.L.arcle_step_bits, bits, op, flags)
+
+    def pack_mask_bits(self, sel, out=None):
+        """int8/bool [N,H,W] selection masks -> uint8 [N,128] bit-packed rows (one launch)."""
+        if sel.dtype == torch.bool:
+            sel = sel.view(torch.int8) if sel.is_contiguous() else sel.to(torch.int8)
+        if sel.dtype != torch.int8 or not sel.is_contiguous() or sel.device != self.device:
+            sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
+        if out is None:
+            out = torch.empty((self.N, _lib.BITS_STRIDE), dtype=torch.uint8, device=self.device)
+        self._check(self.L.arcle_pack_mask_bits(self._h, _ptr(sel), _ptr(out), self._stream()), "arcle_pack_mask_bits")
+        return out
+
+    def step_many(self, form, payload, op=None, flags=0, reward=None, term=None):
+        """K step() launches enqueued by ONE call into the library (arcle_step_many): payload [K, N, ...] in the ingress form
+        `form` ("mask" | "bbox" | "point" | "bbox5" | "bits"), op int32 [K, N] (None for "bbox5") -> (reward int32 [K, N],
+        terminated uint8 [K, N]).  Every step is a full step; self.reward / self.term are not written."""
+        K = int(payload.shape[0])
+        assert payload.is_contiguous() and payload.device == self.device and (op is None or (op.is_contiguous() and op.dtype == torch.int32))
+        if reward is None:
+            reward = torch.empty((K, self.N), dtype=torch.int32, device=self.device)
+        if term is None:
+            term = torch.empty((K, self.N), dtype=torch.uint8, device=self.device)
+        self._check(self.L.arcle_step_many(self._h, _lib.INGRESS[form], K, _ptr(payload), _ptr(op), _ptr(reward), _ptr(term), int(flags),
+                                           self._stream()), "arcle_step_many")
+        return reward, term
+
     def step_bbox_ptr(self, bbox_ptr, op_ptr, flags=0, stream=0):
         """Lowest-overhead launch for rollout loops: raw device addresses (ints) of an int32 [N,4] bbox array
         and an int32 [N] op array, explicit stream handle.  Outputs land in self.reward / self.term."""
@@ -291,13 +336,81 @@ class EnvBatch:
         self._check(self.L.arcle_flatten_obs(self._h, _ptr(out), out.shape[1], int(filtered), self._stream()), "arcle_flatten_obs")
         return out[:, :L]
 
-    def set_flat_output(self, filtered=False):
-        """Installs the destination of STEP_FLAT_OBS: every step call with that flag also refreshes `self.flat` ([N, L])."""
-        self._flat_buf, L = self._flat_buffer(filtered)
-        self._check(self.L.arcle_set_flat_output(self._h, _ptr(self._flat_buf), self._flat_buf.shape[1], int(filtered)),
-                    "arcle_set_flat_output")
+    def set_flat_output(self, filtered=False, tail=False, host=False):
+        """Installs the destination of STEP_FLAT_OBS: every step call with that flag also refreshes `self.flat` ([N, L]).
+        tail=True: each row's stride ends with 16 bytes of step outputs (`self.flat_tail` int32 [N, 4] view: reward, action_steps,
+        submit_count, terminated | truncated << 8 | status << 16).  host=True: the rows live in PINNED HOST memory — the step kernel
+        writes them across PCIe itself, no device->host copy afterwards (single envs / small batches)."""
+        L = self.flat_obs_size(filtered)
+        stride = ((L + 15) & ~15) + (ROW_TAIL if tail else 0)
+        if host:
+            self._flat_buf = torch.zeros((self.N, stride), dtype=torch.int8).pin_memory()
+        else:
+            self._flat_buf = torch.zeros((self.N, stride), dtype=torch.int8, device=self.device)
+        self._check(self.L.arcle_set_flat_output_ex(self._h, _ptr(self._flat_buf), stride, int(filtered), int(tail)),
+                    "arcle_set_flat_output_ex")
         self.flat = self._flat_buf[:, :L]
+        self.flat_tail = self._flat_buf[:, stride - ROW_TAIL:].view(torch.int32) if tail else None
         return self.flat
+
+    # ---- state rows: checkpoint / restore and the stateless batched transition ------------------------------------------------
+    def state_row_size(self):
+        return self.flat_obs_size(False)
+
+    def get_state_rows(self, out=None):
+        """The state dict of every env as one row [N, L] int8 (full FlattenObservation layout) — see set_state_rows."""
+        return self.flat_obs(out, False)
+
+    def set_state_rows(self, rows, mask=None):
+        """rows int8 [N, >= L] (device or pinned host; any stride) -> the resident state of the (masked) envs: the inverse of
+        get_state_rows.  The task side (answer, answer_dim) and the counters are not part of a row and stay."""
+        assert rows.dtype == torch.int8 and rows.dim() == 2 and rows.shape[0] == self.N and rows.stride(1) == 1
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        self._check(self.L.arcle_set_state_rows(self._h, _ptr(rows), rows.stride(0), _ptr(m), self._stream()), "arcle_set_state_rows")
+        if m is not None:
+            torch.cuda.current_stream(self.device).synchronize()  # (m may be a temporary)
+
+    def transition_rows(self, rows, form, payload, op, src_env=None, out=None, tail=False, flags=0, reward=None, term=None):
+        """`transition(state, action)` of the reference (o2arcenv.py:149-151) for a batch of M (state row, action) pairs, none of
+        which touches the resident envs: rows int8 [M, >= L]; payload in the ingress form `form` ("mask" int8 [M,H,W] | "bbox" int32
+        [M,4] | "point" int32 [M,2]); op int32 [M]; src_env int32 [M] = the resident env whose answer a Submit / the reward compares
+        with (None: env r for row r).  Returns (rows_out [M, stride], reward int32 [M], terminated uint8 [M]); with tail=True the last
+        16 bytes of every output row carry (reward, 1, submit counted, terminated | status << 16).  All arrays device or pinned host."""
+        M = int(rows.shape[0])
+        L = self.flat_obs_size(False)
+        stride = ((L + 15) & ~15) + (ROW_TAIL if tail else 0)
+        if out is None:
+            out = torch.empty((M, stride), dtype=torch.int8, device=self.device)
+        assert out.shape == (M, stride) and out.dtype == torch.int8 and out.is_contiguous()
+        assert rows.dtype == torch.int8 and rows.stride(1) == 1 and payload.is_contiguous() and op.dtype == torch.int32 and op.is_contiguous()
+        if reward is None:
+            reward = torch.empty(M, dtype=torch.int32, device=self.device)
+        if term is None:
+            term = torch.empty(M, dtype=torch.uint8, device=self.device)
+        self._check(self.L.arcle_transition_rows(self._h, M, _ptr(rows), rows.stride(0), _lib.INGRESS[form], _ptr(payload), _ptr(op),
+                                                 _ptr(src_env), _ptr(out), stride, int(tail), _ptr(reward), _ptr(term), int(flags),
+                                                 self._stream()), "arcle_transition_rows")
+        return out, reward, term
+
+    def get_state(self):
+        """Checkpoint of everything that defines the batch's future: a dict of CLONED device tensors (state planes incl. the task's
+        input / answer, the per-env record, the counters, and — when a sampler is installed — the per-env episode numbers and
+        current task indices).  `set_state` restores it; trajectories continue bit-identically."""
+        st = {"planes": {k: v.clone() for k, v in self.planes.items()}, "rec": self.rec.clone(), "cnt": self.cnt.clone()}
+        if hasattr(self, "episode"):
+            st["episode"], st["cur_task"] = self.episode.clone(), self.cur_task.clone()
+        return st
+
+    def set_state(self, st):
+        for k, v in st["planes"].items():
+            self.planes[k].copy_(v)
+        self.rec.copy_(st["rec"])
+        self.cnt.copy_(st["cnt"])
+        if "episode" in st and hasattr(self, "episode"):
+            self.episode.copy_(st["episode"])
+            self.cur_task.copy_(st["cur_task"])
 
     def packed_obs_size(self):
         return int(self.L.arcle_packed_obs_size(self._h))
@@ -313,10 +426,15 @@ class EnvBatch:
                     "arcle_pack_obs")
         return out
 
-    def set_packed_output(self):
+    def set_packed_output(self, out=None):
         """Installs the destination of STEP_PACK_OBS: every step call with that flag also writes `self.packed` ([N, R] uint8 rows
-        grid | grid_dim | reward | terminated) from inside the step kernel — no packing launch before the multi-GPU gather."""
-        self.packed = torch.empty((self.N, self.packed_obs_size()), dtype=torch.uint8, device=self.device)
+        grid | grid_dim | reward | terminated) from inside the step kernel — no packing launch before the multi-GPU gather.
+        `out`: a caller-owned contiguous uint8 [N, R] device tensor (e.g. one slot of a double buffer); launches already enqueued
+        keep writing where they were told to (parameters are taken by value per launch)."""
+        if out is None:
+            out = torch.empty((self.N, self.packed_obs_size()), dtype=torch.uint8, device=self.device)
+        assert out.shape == (self.N, self.packed_obs_size()) and out.dtype == torch.uint8 and out.is_contiguous() and out.device == self.device
+        self.packed = out
         self._check(self.L.arcle_set_packed_output(self._h, _ptr(self.packed)), "arcle_set_packed_output")
         return self.packed
 
@@ -344,6 +462,13 @@ class EnvBatch:
 
     def enable_accounting(self, on=True):
         self._check(self.L.arcle_enable_accounting(self._h, int(on)), "arcle_enable_accounting")
+
+    def accounting_ex(self, clear=True):
+        """(algorithmic bytes, issued bytes, env-steps) since the last clear — arcle_get_accounting_ex."""
+        b, i, s = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.L.arcle_get_accounting_ex(self._h, ctypes.byref(b), ctypes.byref(i), ctypes.byref(s), int(clear), self._stream()),
+                    "arcle_get_accounting_ex")
+        return b.value, i.value, s.value
 
     def accounting(self, clear=True):
         b, s = ctypes.c_uint64(0), ctypes.c_uint64(0)

@@ -6,7 +6,7 @@ from .vec import ARCVecEnv
 
 from .. import spaces as _spaces
 
-if _spaces.HAVE_GYMNASIUM:  # pragma: no cover - gymnasium is optional
+if _spaces.HAVE_GYMNASIUM:
     from gymnasium.envs.registration import register, registry
     # the reference's ids (arcle/envs/__init__.py:7-25): `gym.make('ARCLE/O2ARCv2Env-v0', ...)` keeps working when this
     # package replaces the reference; the same entry points also under the ARCLE-AMD namespace (both packages installed)

@@ -62,19 +62,20 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self._batch = self._new_batch(1)
         return self._batch
 
-    # ---- one-env fast path: the whole state crosses PCIe as ONE flattened row (written by the step kernel itself) ---------
+    # ---- one-env fast path: ONE launch and ONE synchronisation per step(), no copies -----------------------------------------
+    # The action (selection mask + op index) is written into PINNED HOST memory the kernel reads directly, and the step kernel
+    # writes the flattened state row — with the step outputs (reward, counters, terminated, per-env status) in the row's 16-byte
+    # tail — straight into pinned host memory as well (arcle_set_flat_output_ex).  After the stream synchronisation everything
+    # step() returns is on the host.  (Round 2: 2 H2D copies + step + status kernel + 3 D2H copies + 2 synchronisations.)
     def _io(self):
-        """Persistent staging buffers of the single env: pinned host + device tensors for the action, the flattened
-        observation row (arcle_set_flat_output) and the step outputs."""
         if getattr(self, "_io_bufs", None) is None:
             b = self.batch
-            flat = b.set_flat_output(False)
-            pin = torch.cuda.is_available()
-            mk = lambda shape, dt: torch.zeros(shape, dtype=dt, pin_memory=pin)  # noqa: E731
-            self._io_bufs = dict(flat=flat, h_flat=mk(tuple(flat.shape), torch.int8), h_sel=mk((1, self.H, self.W), torch.int8),
-                                 d_sel=torch.zeros((1, self.H, self.W), dtype=torch.int8, device=b.device), h_op=mk((1,), torch.int32),
-                                 d_op=torch.zeros(1, dtype=torch.int32, device=b.device), h_cnt=mk((1, 2), torch.int32),
-                                 h_reward=mk((1,), torch.int32))
+            flat = b.set_flat_output(False, tail=True, host=True)
+            P = self.H * self.W
+            act = torch.zeros(((P + 3) & ~3) + 4, dtype=torch.int8).pin_memory()  # selection bytes, then the op as int32
+            self._io_bufs = dict(flat=flat, row=flat[0].numpy(), tail=b.flat_tail[0].numpy(), act=act, sel=act[:P].numpy(),
+                                 op=act[(P + 3) & ~3:].view(torch.int32).numpy(), sel_ptr=act.data_ptr(),
+                                 op_ptr=act.data_ptr() + ((P + 3) & ~3), L=flat.shape[1])
         return self._io_bufs
 
     def _flat_layout(self):
@@ -106,14 +107,24 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             d[path[-1]] = v
         return st
 
-    def _fetch_state(self, b, launch=True):
-        """Current state as the obs dict through one device->host copy of the flattened row."""
+    def _fetch_state(self, b):
+        """Current state as the obs dict: one flatten launch that writes the row into pinned host memory, one synchronisation."""
         io = self._io()
-        if launch:
-            b.flat_obs(out=b._flat_buf, filtered=False)
-        io["h_flat"].copy_(io["flat"], non_blocking=True)
-        torch.cuda.synchronize(b.device)
-        return self._state_from_row(io["h_flat"][0].numpy())
+        buf = b._flat_buf
+        b._check(b.L.arcle_flatten_obs(b._h, buf.data_ptr(), buf.shape[1], 0, b._stream()), "arcle_flatten_obs")
+        torch.cuda.current_stream(b.device).synchronize()
+        return self._state_from_row(io["row"])
+
+    def _row_from_state(self, state, out):
+        """Inverse of _state_from_row: writes the obs dict `state` into the numpy int8 row `out` (full layout)."""
+        off = 0
+        for path, n in self._flat_layout():
+            v = state
+            for k in path:
+                v = v[k]
+            out[off:off + n] = np.asarray(v, np.int8).reshape(-1)
+            off += n
+        return off
 
     @staticmethod
     def _state_from_device(b, n=0):
@@ -203,7 +214,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
     def _step_flags(self):
         return STEP_RESET_ON_SUBMIT if self.reset_on_submit else 0
 
-    def _device_step(self, b, action):
+    def _check_action(self, action):
         op = int(action["operation"])
         if not -len(self.operations) <= op < len(self.operations):
             raise IndexError("list index out of range")  # what self.operations[op] raises in the reference
@@ -211,6 +222,17 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         sel = np.asarray(action["selection"])
         if sel.shape != (self.H, self.W):
             raise ValueError(f"selection must have shape {(self.H, self.W)}")
+        return op, sel
+
+    @staticmethod
+    def _raise_status(st):
+        if st & ST_ROTATE_DOMAIN:
+            raise ValueError("Rotate/Flip outside its domain (the reference raises here too: object.py:45 / int8 overflow)")
+        if st & ST_BAD_OP:
+            raise IndexError("list index out of range")
+
+    def _device_step(self, b, action):
+        op, sel = self._check_action(action)
         fn = self.operations[op]
         if not isinstance(fn, actions.Operation) and not actions.is_submit(fn):
             # an arbitrary Python callable in the table (base.py:140-142 allows it; agents/wrapper.py:53-57): applied on the
@@ -218,33 +240,19 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             state = self._state_from_device(b)
             fn(state, action)
             self._state_to_device(b, state)
-        # action in: pinned staging -> device (asynchronous); step with the fused observation row; row, counters and reward out
-        # (asynchronous); the status read synchronises the stream
-        if b is not self._batch:  # the scratch env of transition(): plain path, the caller fetches the state itself
-            sel_t = torch.as_tensor(sel.astype(np.int8, copy=False), device=b.device).reshape(1, self.H, self.W)
-            reward, term = b.step_mask(sel_t, torch.tensor([op], dtype=torch.int32, device=b.device), self._step_flags())
-            st = b.status()
-            if st & ST_ROTATE_DOMAIN:
-                raise ValueError("Rotate/Flip outside its domain (the reference raises here too: object.py:45 / int8 overflow)")
-            if st & ST_BAD_OP:
-                raise IndexError("list index out of range")
-            return int(reward[0]), bool(term[0])
         io = self._io()
-        io["h_sel"][0].copy_(torch.from_numpy(np.ascontiguousarray(sel.astype(np.int8, copy=False))))
-        io["h_op"][0] = op
-        io["d_sel"].copy_(io["h_sel"], non_blocking=True)
-        io["d_op"].copy_(io["h_op"], non_blocking=True)
-        reward, term = b.step_mask(io["d_sel"], io["d_op"], self._step_flags() | STEP_FLAT_OBS)
-        io["h_flat"].copy_(io["flat"], non_blocking=True)
-        io["h_cnt"].copy_(b.cnt, non_blocking=True)
-        io["h_reward"].copy_(reward, non_blocking=True)
-        st = b.status()
-        if st & ST_ROTATE_DOMAIN:
-            raise ValueError("Rotate/Flip outside its domain (the reference raises here too: object.py:45 / int8 overflow)")
-        if st & ST_BAD_OP:
-            raise IndexError("list index out of range")
-        self._row_ready = True
-        return int(io["h_reward"][0]), bool(io["h_flat"][0, -2] != 0)  # (terminated is the row's last-but-one byte)
+        io["sel"][:] = sel.reshape(-1)  # (any integer / bool dtype -> int8, straight into the pinned buffer the kernel reads)
+        io["op"][0] = op
+        st = b._stream()
+        b._check(b.L.arcle_step_mask(b._h, io["sel_ptr"], io["op_ptr"], b._reward_ptr, b._term_ptr,
+                                     self._step_flags() | STEP_FLAT_OBS, st), "arcle_step_mask")
+        torch.cuda.current_stream(b.device).synchronize()  # the one synchronisation of the step: row + tail are on the host now
+        tail = io["tail"]
+        status = (int(tail[3]) >> 16) & 0xFF
+        if status:
+            b.status()  # (clears the handle's sticky word as well)
+            self._raise_status(status)
+        return int(tail[0]), bool(int(tail[3]) & 0xFF)
 
     def step(self, action):
         """o2arcenv.py:130-147 / arcenv.py:60-76,155-172."""
@@ -266,8 +274,8 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self.last_action_op = int(action["operation"]) % len(self.operations)
             self.last_action = action
             io = self._io()
-            self.current_state = self._state_from_row(io["h_flat"][0].numpy())  # (copied out by _device_step)
-            self.action_steps, self.submit_count = int(io["h_cnt"][0, 0]), int(io["h_cnt"][0, 1])
+            self.current_state = self._state_from_row(io["row"])  # (the kernel wrote it into pinned host memory)
+            self.action_steps, self.submit_count = int(io["tail"][1]), int(io["tail"][2])
             # a subclass that overrides reward() (e.g. the dense reward of agents/env.py:44-58) is evaluated on the host;
             # so is the reward of a host-applied last op
             host_reward = type(self).reward is not AbstractARCEnv.reward or not isinstance(
@@ -279,20 +287,48 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self.info["submit_count"] = self.submit_count
         return self.current_state, reward, term, self.truncated, self.info
 
+    def _tio(self):
+        """Pinned host staging of transition(): state row in, action in, state row + tail out — the kernel
+        (arcle_transition_rows) reads and writes all of it in place, nothing is copied and no resident env is touched."""
+        if getattr(self, "_tio_bufs", None) is None:
+            b = self.batch
+            L, P = b.state_row_size(), self.H * self.W
+            stride = ((L + 15) & ~15) + 16
+            rin = torch.zeros((1, stride), dtype=torch.int8).pin_memory()
+            rout = torch.zeros((1, stride), dtype=torch.int8).pin_memory()
+            act = torch.zeros(((P + 3) & ~3) + 4, dtype=torch.int8).pin_memory()
+            self._tio_bufs = dict(rin=rin, rout=rout, act=act, rin_np=rin[0].numpy(), rout_np=rout[0].numpy(), sel=act[:P].numpy(),
+                                  op=act[(P + 3) & ~3:].view(torch.int32).numpy(), tail=rout[0, stride - 16:].view(torch.int32).numpy(),
+                                  stride=stride, L=L, op_off=(P + 3) & ~3)
+        return self._tio_bufs
+
     def transition(self, state, action):
         """o2arcenv.py:149-151 — applies one operation to `state` IN PLACE (README usage:
-        `env.transition(deepcopy(state), action)`).  The given dict is uploaded into a scratch env,
-        stepped by the kernel and written back.  Like the reference, a Submit routed through here counts
-        (`self.submit_count`, base.py:175); `action_steps` does not move."""
-        if self._scratch is None:
-            self._scratch = self._new_batch(1)
-        s = self._scratch
-        s.set_tasks([self.input_], [self.answer])
-        self._state_to_device(s, state)
-        s.cnt.zero_()
-        self._device_step(s, action)
-        self.submit_count += int(s.cnt[0, 1])
-        new = self._state_from_device(s)
+        `env.transition(deepcopy(state), action)`).  One launch of the stateless row kernel: the dict becomes a state row in pinned
+        host memory, arcle_transition_rows applies the op, the result row is read back into the dict; the env's own device state is
+        not involved.  Like the reference, a Submit routed through here counts (`self.submit_count`, base.py:175); `action_steps`
+        does not move.  (Planning over many states at once: ARCVecEnv.transition — same kernel, any number of rows per launch.)"""
+        op, sel = self._check_action(action)
+        fn = self.operations[op]
+        if not isinstance(fn, actions.Operation) and not actions.is_submit(fn):
+            fn(state, action)  # a host callable in the table: it IS the transition
+            return
+        b = self.batch
+        t = self._tio()
+        self._row_from_state(state, t["rin_np"])
+        t["sel"][:] = sel.reshape(-1)
+        t["op"][0] = op
+        ap = t["act"].data_ptr()
+        b._check(b.L.arcle_transition_rows(b._h, 1, t["rin"].data_ptr(), t["stride"], 0, ap, ap + t["op_off"], None,
+                                           t["rout"].data_ptr(), t["stride"], 1, b._reward_ptr, b._term_ptr, self._step_flags(),
+                                           b._stream()), "arcle_transition_rows")
+        torch.cuda.current_stream(b.device).synchronize()
+        status = (int(t["tail"][3]) >> 16) & 0xFF
+        if status:
+            b.status()
+            self._raise_status(status)
+        self.submit_count += int(t["tail"][2])
+        new = self._state_from_row(t["rout_np"])
         for k, v in new.items():
             if k == "object_states":
                 state.setdefault("object_states", {}).update(v)

@@ -3,7 +3,7 @@ optional dependency: absent from the build image and the GPU box), otherwise a m
 supports what the reference's examples use: `.sample()`, `.n`, `.spaces`, `[]`."""
 import numpy as np
 
-try:  # pragma: no cover - depends on the environment
+try:  # (gymnasium is optional: tests/test_gym_registration.py covers this branch with a stand-in on the path)
     import gymnasium as gym
     from gymnasium import spaces as _sp
     Box, Discrete, MultiBinary, Tuple, Dict = _sp.Box, _sp.Discrete, _sp.MultiBinary, _sp.Tuple, _sp.Dict

@@ -239,6 +239,82 @@ def cpu_baseline(seed):
                               "(Xeon 2.10 GHz, BASELINE.md §2)"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# helpers shared by the legs: graph-replayed timing, kernel-counted bytes, a roofline block
+# ---------------------------------------------------------------------------------------------------------------
+def graph_time(dev, enqueue, K, reps=5, warm=3):
+    """Captures `enqueue(stream_handle)` (K step launches) into one hipGraph, replays it `reps` times, returns the median seconds
+    per step (HIP events around each replay, recorded on the stream the replay is launched on)."""
+    st = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        enqueue(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(warm):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1) * 1e-3 / K)
+    return float(np.median(ts)), g
+
+
+def counted_bytes(batch, enqueue, K, dev):
+    """The K launches of `enqueue` replayed from the batch's CURRENT state (restored afterwards) with the kernel's byte accounting on:
+    -> (algorithmic bytes per launch — SURVEY.md 8d, the roofline numerator —, bytes of the accesses the kernel actually issued per
+    launch, algorithmic bytes per env-step)."""
+    snap = batch.get_state()
+    torch.cuda.synchronize(dev)
+    batch.enable_accounting(True)
+    batch.accounting_ex(clear=True)
+    enqueue(torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    alg, issued, steps = batch.accounting_ex(clear=True)
+    batch.enable_accounting(False)
+    batch.set_state(snap)
+    torch.cuda.synchronize(dev)
+    return alg / K, issued / K, alg / max(steps, 1)
+
+
+def roofline_block(kernel, sec, alg, issued, n, PS=1024, planes=8, note=None):
+    """The JSON block of one kernel: achieved = algorithmic bytes / launch duration against the 8 TB/s HBM3E peak; `traffic` = the
+    bytes of the accesses the kernel itself counted as issued (kernel-counted, this run)."""
+    state = planes * n * PS + 24 * n
+    blk = {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK,
+           "traffic": issued, "traffic_source": "kernel-counted in this run (arcle_get_accounting_ex: every global-memory access the "
+           "step kernel issued, whole 16-byte lanes incl. row padding; elided writes excluded, re-reads included)",
+           "frac_by_traffic": issued / sec / HBM_PEAK, "kernel": kernel, "avg_launch_us": sec * 1e6,
+           "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_env_step": alg / n,
+           "frac_of_measured_copy_peak_6.29TBps": alg / sec / 6.29e12,
+           "note_cache": {"state_bytes": state, "infinity_cache_bytes": 256 << 20,
+                          "fits_infinity_cache": state < (256 << 20),
+                          "meaning": "when the state fits the 256 MiB Infinity Cache the bytes are moved, but not all of them reach "
+                                     "HBM: frac is then a fabric-level figure; extras.batch_sweep holds the out-of-cache fractions"}}
+    if note:
+        blk["note"] = note
+    return blk
+
+
+def make_batch(dev, n, seed=1000, kind="o2arc", H=30, W=30):
+    from arcle_amd import actions
+    from arcle_amd.engine import EnvBatch
+    from arcle_amd.envs import ARCEnv, O2ARCv2Env
+    batch = EnvBatch(n, H, W, -1, kind, dev)
+    cls = ARCEnv if kind == "arc" else O2ARCv2Env
+    batch.set_op_table(actions.table_descs(cls.default_operations()))
+    batch.set_tasks_padded(*make_tasks(n, seed, H, W))
+    batch.reset()
+    return batch
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# non-headline legs (extras): every one carries us_per_step_batch and — where a step kernel is what is timed — a roofline block
+# ---------------------------------------------------------------------------------------------------------------
 def rollout_leg(batch, bbox, op, dev, T=128, reps=8):
     """NOT the headline metric: the same action stream replayed with arcle_rollout_bbox (T steps per launch, env state
     resident in registers between the steps; only per-step reward/terminated and the final state reach HBM)."""
@@ -258,42 +334,62 @@ def rollout_leg(batch, bbox, op, dev, T=128, reps=8):
             "note": "state stays on chip between steps; not comparable with the per-step HBM roofline above"}
 
 
-def host_actions_leg(batch, bbox, op, FL, dev, K=200, reps=3):
-    """NOT the headline metric: the same steps with the action batch (bbox int32 [N,4] + op int32 [N] = 20 B per env) copied from
-    pinned HOST memory before every step, on the launch stream (graph-replayed: 2 copy nodes + 1 kernel node per step) — the
-    PCIe-inclusive rate a host-resident policy would see."""
+def vec_api_leg(dev, n, bbox, op, K=100):
+    """The product's front-end, ARCVecEnv, driven the three ways it offers: one Python call per step (`step_bbox`), K steps per call
+    into the library (`step_many`), K steps captured once and replayed (`capture` / `replay`: the action buffers are re-read at
+    replay time).  `value` = the captured form — what a training loop uses."""
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    v = ARCVecEnv(O2ARCv2Env, n, SyntheticLoader(n_tasks=400, seed=1, max_size=(30, 30)), device=dev, seed=7, autoreset=True)
+    v.reset()
     K = min(K, bbox.shape[0])
-    hb, ho = bbox[:K].cpu().pin_memory(), op[:K].cpu().pin_memory()
-    db, do = torch.empty_like(bbox[0]), torch.empty_like(op[0])
-    st = torch.cuda.Stream(dev)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=st):
-        csh = torch.cuda.current_stream(dev).cuda_stream
-        for i in range(K):
-            db.copy_(hb[i], non_blocking=True)
-            do.copy_(ho[i], non_blocking=True)
-            batch.step_bbox_ptr(db.data_ptr(), do.data_ptr(), FL, csh)
-    for _ in range(3):
-        g.replay()
+    bb, oo = bbox[:K].contiguous(), op[:K].contiguous()
+    out = {}
+    for i in range(10):
+        v.step_bbox(bb[i], oo[i])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(K):
+        v.step_bbox(bb[i], oo[i])
+    torch.cuda.synchronize(dev)
+    out["python_loop_us"] = (time.perf_counter() - t0) / K * 1e6
+    v.step_many(bb, oo)
     torch.cuda.synchronize(dev)
     ts = []
-    for _ in range(reps):
+    for _ in range(5):
+        t0 = time.perf_counter()
+        v.step_many(bb, oo)
+        torch.cuda.synchronize(dev)
+        ts.append((time.perf_counter() - t0) / K * 1e6)
+    out["step_many_us"] = float(np.median(ts))
+    cs = v.capture(bb, oo)
+    for _ in range(3):
+        cs.replay()
+    torch.cuda.synchronize(dev)
+    ts, ds = [], []
+    for _ in range(7):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
         e0.record()
-        g.replay()
+        cs.replay()
         e1.record()
         torch.cuda.synchronize(dev)
-        ts.append(e0.elapsed_time(e1) * 1e-3 / K)
-    sec = float(np.median(ts))
-    return {"mode": "bbox + op copied from pinned host memory before every step (20 B per env)", "value": batch.N / sec,
-            "unit": "env-steps/s", "us_per_step_batch": sec * 1e6, "host_bytes_per_step": int(batch.N * 20)}
+        ts.append((time.perf_counter() - t0) / K * 1e6)
+        ds.append(e0.elapsed_time(e1) * 1e-3 / K)
+    sec_host = float(np.median(ts)) * 1e-6  # host clock around replay + synchronize: what the caller's loop sees
+    b = v.batch
+    alg, issued, _ = counted_bytes(b, lambda sh: [b.step_bbox_ptr(bb[i].data_ptr(), oo[i].data_ptr(), v.flags, sh) for i in range(K)], K, dev)
+    v.check_errors()
+    out.update({"mode": f"ARCVecEnv.capture({K} steps) + replay(), host clock incl. the synchronisation", "value": n / sec_host,
+                "unit": "env-steps/s", "us_per_step_batch": sec_host * 1e6, "device_us_per_step_batch": float(np.median(ds)) * 1e6,
+                "steps_per_call": K, "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>", sec_host, alg, issued, n)})
+    return out
 
 
-def research_env_leg(dev, n, bbox, op, K=200, reps=3):
-    """NOT the headline metric: the step the reference's training script runs (agents/env.py + agents/train.py:61-68) — op 33 =
-    crop, dense reward, TimeLimit(100) truncation, next-step autoreset onto a NEW device-drawn task with colour-permutation +
-    rot90 augmentation, and the FilterO2ARC + FlattenObservation row of every env written by the step kernel — all in ONE launch
-    per step (feature instantiation), graph-replayed."""
+def research_env_leg(dev, n, bbox, op, K=200):
+    """The step the reference's training script runs (agents/env.py + agents/train.py:61-68) — op 33 = crop, dense reward,
+    TimeLimit(100) truncation, next-step autoreset onto a NEW device-drawn task with colour-permutation + rot90 augmentation, and
+    the FilterO2ARC + FlattenObservation row of every env written by the step kernel — all in ONE launch per step, graph-replayed."""
     from arcle_amd import actions
     from arcle_amd.engine import STEP_FLAT_OBS
     from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
@@ -310,28 +406,244 @@ def research_env_leg(dev, n, bbox, op, K=200, reps=3):
     rows = v.batch.set_flat_output(filtered=True)
     FL = v.flags | STEP_FLAT_OBS
     K = min(K, bbox.shape[0])
-    st = torch.cuda.Stream(dev)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=st):
-        csh = torch.cuda.current_stream(dev).cuda_stream
+    b = v.batch
+
+    def enqueue(sh):
         for i in range(K):
-            v.batch.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, csh)
-    for _ in range(3):
-        g.replay()
+            b.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, sh)
+    # desynchronise the episodes first (all envs start at step 0: left alone, every env would hit TimeLimit in the same launch —
+    # a training run is never in that state after its first episode)
+    b.cnt[:, 0] = torch.randint(0, 100, (n,), device=dev, dtype=torch.int32)
+    for i in range(100):
+        b.step_bbox_ptr(bbox[i % K].data_ptr(), op[(i * 7 + 3) % K].data_ptr(), FL, torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
-    ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        g.replay()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ts.append(e0.elapsed_time(e1) * 1e-3 / K)
-    sec = float(np.median(ts))
-    assert v.batch.status() == 0
+    alg, issued, _ = counted_bytes(b, enqueue, K, dev)
+    sec, _ = graph_time(dev, enqueue, K)
+    assert b.status() == 0
     return {"mode": "ARCVecEnv(autoreset='resample', augment, dense_reward, max_episode_steps=100) + fused FilterO2ARC rows",
             "value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6, "row_bytes": int(rows.shape[1]),
+            "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 1, research flags, 30>", sec, alg, issued, n,
+                                       note="algorithmic = the step's planes + 56 B, + the dense reward's answer read, + per row: its "
+                                            "three planes read once and 2710 B written (SURVEY.md 8d style); the kernel re-reads the "
+                                            "planes it just stored through its own L1/L2, so issued > HBM traffic here"),
             "note": "one launch per step; 2710-byte observation row per env and step written by the step kernel"}
+
+
+def ingress_leg(dev, n, bbox, op, K=64):
+    """The reference's native action type is a full H x W mask (base.py:134-138).  Same rectangles as the headline's bbox tuples, sent
+    as int8 masks (arcle_step_mask) and as bit-packed boolean masks (arcle_step_bits, 128 B per env)."""
+    K = min(K, bbox.shape[0])
+    bb = bbox[:K]
+    x1, x2 = torch.minimum(bb[..., 0], bb[..., 2]), torch.maximum(bb[..., 0], bb[..., 2])
+    y1, y2 = torch.minimum(bb[..., 1], bb[..., 3]), torch.maximum(bb[..., 1], bb[..., 3])
+    ii = torch.arange(30, device=dev)[None, None, :, None]
+    jj = torch.arange(30, device=dev)[None, None, None, :]
+    masks = ((ii >= x1[..., None, None]) & (ii <= x2[..., None, None]) & (jj >= y1[..., None, None]) & (jj <= y2[..., None, None])).to(torch.int8).contiguous()
+    out = {}
+    for form in ("mask", "bits"):
+        batch = make_batch(dev, n)
+        FL = batch.elide_flag | STEP_AUTORESET
+        if form == "bits":
+            pay = torch.stack([batch.pack_mask_bits(masks[i]) for i in range(K)])
+            fn = batch.L.arcle_step_bits
+        else:
+            pay, fn = masks, batch.L.arcle_step_mask
+
+        def enqueue(sh, pay=pay, fn=fn, batch=batch, FL=FL):
+            for i in range(K):
+                rc = fn(batch._h, pay[i].data_ptr(), op[i].data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh)
+                assert rc == 0
+        alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
+        sec, _ = graph_time(dev, enqueue, K)
+        out[form] = {"value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6,
+                     "payload_bytes_per_env": 900 if form == "mask" else 128,
+                     "roofline": roofline_block(f"arcle_step_kernel<{form}, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, n)}
+    batch = make_batch(dev, n)
+    sec, _ = graph_time(dev, lambda sh: [batch.pack_mask_bits(masks[i], pay[i]) for i in range(K)], K)
+    out["pack_mask_bits_us"] = sec * 1e6
+    out["mode"] = "full H x W selection masks: int8 [N,900] / bit-packed [N,128]"
+    out["value"], out["unit"], out["us_per_step_batch"] = out["mask"]["value"], "env-steps/s", out["mask"]["us_per_step_batch"]
+    return out
+
+
+def host_actions_leg(dev, n, bbox, op, K=200):
+    """PCIe-inclusive rates of a HOST-resident policy (never part of `value`): the action of every env is the BBoxWrapper 5-tuple
+    record (20 B per env, arcle_step_bbox5).  (a) zero-copy: the kernel reads the records straight from pinned host memory; (b) one
+    copy node (pinned host -> device) in front of every step; (c) round 2's form: two arrays, two copy nodes."""
+    K = min(K, bbox.shape[0])
+    act5 = torch.cat([bbox[:K], op[:K, :, None]], -1).contiguous()
+    h5 = act5.cpu().pin_memory()
+    hb, ho = bbox[:K].cpu().pin_memory(), op[:K].cpu().pin_memory()
+    out = {}
+    batch = make_batch(dev, n)
+    FL = batch.elide_flag | STEP_AUTORESET
+    L, h = batch.L, batch._h
+
+    def zero_copy(sh):
+        for i in range(K):
+            assert L.arcle_step_bbox5(h, h5[i].data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh) == 0
+    d5 = torch.empty_like(act5[0])
+
+    def one_copy(sh):
+        for i in range(K):
+            d5.copy_(h5[i], non_blocking=True)
+            assert L.arcle_step_bbox5(h, d5.data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh) == 0
+    db, do = torch.empty_like(bbox[0]), torch.empty_like(op[0])
+
+    def two_copies(sh):
+        for i in range(K):
+            db.copy_(hb[i], non_blocking=True)
+            do.copy_(ho[i], non_blocking=True)
+            batch.step_bbox_ptr(db.data_ptr(), do.data_ptr(), FL, sh)
+    for name, fn in (("zero_copy_pinned_records", zero_copy), ("one_copy_node_records", one_copy), ("two_copy_nodes_round2", two_copies)):
+        sec, _ = graph_time(dev, fn, K)
+        out[name] = {"us_per_step_batch": sec * 1e6, "value": n / sec}
+    alg, issued, _ = counted_bytes(batch, zero_copy, K, dev)
+    best = min(("zero_copy_pinned_records", "one_copy_node_records"), key=lambda k: out[k]["us_per_step_batch"])
+    sec = out[best]["us_per_step_batch"] * 1e-6
+    out.update({"mode": f"BBoxWrapper 5-tuple records from pinned host memory ({best})", "value": n / sec, "unit": "env-steps/s",
+                "us_per_step_batch": sec * 1e6, "host_bytes_per_step": int(n * 20),
+                "roofline": roofline_block("arcle_step_kernel<bbox5, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, n,
+                                           note="20 B per env of the issued bytes cross PCIe, not HBM")})
+    return out
+
+
+def single_env_leg(dev, reps=300):
+    """The single-env drop-in class (the reference's Gym API: numpy state dict on the host after every step): latency of step() and
+    of transition(deepcopy(state), action).  One env on a GPU is latency-bound by construction; the reference's CPU step: 27.6 us."""
+    import copy
+    from arcle_amd.envs import O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    env = O2ARCv2Env(data_loader=SyntheticLoader(n_tasks=20, seed=1), max_grid_size=(30, 30), device=dev)
+    obs, info = env.reset()
+    rng = np.random.default_rng(0)
+    acts = []
+    for _ in range(reps):
+        sel = np.zeros((30, 30), np.int8)
+        x, y = rng.integers(0, 25, 2)
+        sel[x:x + rng.integers(1, 5), y:y + rng.integers(1, 5)] = 1
+        acts.append({"selection": sel, "operation": int(rng.integers(0, 34))})
+    for a in acts[:20]:
+        env.step(a)
+    t0 = time.perf_counter()
+    for a in acts:
+        obs, r, term, trunc, info = env.step(a)
+    step_us = (time.perf_counter() - t0) / len(acts) * 1e6
+    st = copy.deepcopy(obs)
+    for a in acts[:10]:
+        env.transition(st, a)
+    t0 = time.perf_counter()
+    for a in acts[:100]:
+        env.transition(st, a)
+    tr_us = (time.perf_counter() - t0) / 100 * 1e6
+    return {"mode": "O2ARCv2Env.step / .transition, one env, numpy state dict on the host (ONE launch + ONE synchronisation per call; "
+                    "action and state row live in pinned host memory the kernel reads / writes directly)",
+            "us_per_step": step_us, "us_per_transition": tr_us, "value": 1e6 / step_us, "unit": "env-steps/s",
+            "us_per_step_batch": step_us, "reference_cpu_us_per_step": 27.6}
+
+
+def transition_leg(dev, n, bbox, op, K=32):
+    """The stateless batched transition (arcle_transition_rows): n (state row, action) pairs per launch, rows in and out in HBM,
+    no resident env touched — the planning / search primitive of README.md:55."""
+    batch = make_batch(dev, n)
+    FL = batch.elide_flag | STEP_AUTORESET
+    for i in range(20):
+        batch.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, torch.cuda.current_stream(dev).cuda_stream)
+    rows = batch.get_state_rows().clone()
+    stride = rows.stride(0)
+    out = torch.empty((n, ((batch.state_row_size() + 15) & ~15)), dtype=torch.int8, device=dev)
+    rw, tm = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+    K = min(K, bbox.shape[0])
+
+    def enqueue(sh):
+        for i in range(K):
+            rc = batch.L.arcle_transition_rows(batch._h, n, rows.data_ptr(), stride, 1, bbox[i].data_ptr(), op[i].data_ptr(), None,
+                                               out.data_ptr(), out.shape[1], 0, rw.data_ptr(), tm.data_ptr(), 0, sh)
+            assert rc == 0
+    sec, _ = graph_time(dev, enqueue, K)
+    L = batch.state_row_size()
+    moved = n * (2 * L + 1024 + 16 + 24)
+    return {"mode": f"arcle_transition_rows, {n} (row, bbox action) pairs per launch, rows {L} B", "value": n / sec, "unit": "transitions/s",
+            "us_per_step_batch": sec * 1e6,
+            "roofline": {"bound": "hbm", "achieved": moved / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": moved / sec / HBM_PEAK,
+                         "traffic": None, "algorithmic_bytes_per_launch": moved,
+                         "note": "algorithmic = row in + row out + answer plane + action/outputs per pair (every transition reads and writes "
+                                 "the WHOLE 6314-byte state: it has no resident copy to leave untouched planes in)"}}
+
+
+def batch_sweep_leg(dev, bbox, op, sizes=(32768, 131072), K=24):
+    """The headline kernel on batches whose state (8 planes x N x 1024 B) exceeds the 256 MiB Infinity Cache: the out-of-cache
+    HBM fraction, timed in this run."""
+    out = []
+    for N in sizes:
+        rep = (N + bbox.shape[1] - 1) // bbox.shape[1]
+        bb = bbox[:K].repeat(1, rep, 1)[:, :N].contiguous()
+        oo = op[:K].repeat(1, rep)[:, :N].contiguous()
+        batch = make_batch(dev, N, seed=1234)
+        FL = batch.elide_flag | STEP_AUTORESET
+
+        def enqueue(sh, batch=batch, bb=bb, oo=oo, FL=FL):
+            for i in range(K):
+                batch.step_bbox_ptr(bb[i].data_ptr(), oo[i].data_ptr(), FL, sh)
+        alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
+        sec, _ = graph_time(dev, enqueue, K, reps=3, warm=2)
+        out.append({"envs": N, "us_per_step_batch": sec * 1e6, "value": N / sec, "unit": "env-steps/s",
+                    "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, N)})
+        del batch, bb, oo
+        torch.cuda.empty_cache()
+    return out
+
+
+def other_configs_leg(dev, K=100):
+    """The other single-GPU workloads of BASELINE.json, timed by the same command (graph-replayed, HIP events): c2 (10x10, 1024
+    envs: one eighth of an occupancy round — bound by the launch floor, not by HBM), c4 on one rank (step + fused packed gather
+    row), c5 (ARCEnv flood fills: bound by the fill's dependent passes)."""
+    from arcle_amd import actions
+    from arcle_amd.engine import EnvBatch
+    from arcle_amd.envs import ARCEnv, O2ARCv2Env
+    out = {}
+    for name in ("c2", "c4", "c5"):
+        cfg = CONFIGS[name]
+        H, W, n, kind = cfg["H"], cfg["W"], cfg["envs"], cfg["kind"]
+        batch = EnvBatch(n, H, W, cfg["max_trial"], kind, dev)
+        batch.set_op_table(actions.table_descs((ARCEnv if kind == "arc" else O2ARCv2Env).default_operations()))
+        if name == "c5":
+            tasks, (bb, oo) = make_tasks_c5(n, 1000, H, W), make_actions_c5(K, n, 2000, H, W)
+        elif name == "c2":
+            tasks, (bb, oo) = make_tasks(n, 1000, H, W, lo=3, zero_frac=0.5), make_actions_c2(K, n, 2000)
+        else:
+            tasks, (bb, oo) = make_tasks(n, 1000, H, W), make_actions(K, n, 2000, H, W)
+        batch.set_tasks_padded(*tasks)
+        batch.reset()
+        FL = batch.elide_flag | cfg["flags"]
+        if name == "c4":
+            batch.set_packed_output()
+            FL |= STEP_PACK_OBS
+        bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
+
+        def enqueue(sh, batch=batch, bbd=bbd, ood=ood, FL=FL):
+            for i in range(K):
+                batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), FL, sh)
+        alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
+        sec, _ = graph_time(dev, enqueue, K)
+        leg = {"workload": cfg["name"], "envs": n, "us_per_step_batch": sec * 1e6, "value": n / sec, "unit": "env-steps/s"}
+        rl = roofline_block("arcle_step_kernel", sec, alg, issued, n, PS=batch.PS, planes=len(batch.planes))
+        if name == "c2":
+            rl.update({"bound": "launch-floor", "launch_floor_us": 2.5,
+                       "note": "1024 envs = 1024 waves = 1/8 of one occupancy round of the chip: the launch cannot be shorter than the "
+                               "~2.5 us an EMPTY kernel of this shape takes (profiles/round2_membench.txt); the HBM fraction is reported "
+                               "for completeness and is not the bound"})
+        if name == "c5":
+            seeds = [(int(bb[0, e, 0]), int(bb[0, e, 1])) for e in range(n) if 10 <= oo[0, e] < 20]
+            grids = [tasks[0][e] for e in range(n) if 10 <= oo[0, e] < 20]
+            rl.update({"bound": "iteration (dependent flood-fill passes)", "floodfill_share_of_actions": float(((oo >= 10) & (oo < 20)).mean()),
+                       "frontier_rounds": frontier_rounds_sample(grids, seeds),
+                       "note": "a fill is a chain of dependent passes over the row board (a pass per corridor leg) on half an occupancy "
+                               "round of waves; the HBM fraction is reported for completeness and is not the bound"})
+        leg["roofline"] = rl
+        out[name] = leg
+        del batch
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -528,45 +840,33 @@ def main():
     assert status == 0, f"device status {status}"
     total_steps = K * n * world
 
-    # ---- algorithmic bytes of the K launches of region 0: restore the snapshot and replay them (untimed) with the
-    #      kernel's per-env byte accounting switched on ----------------------------------------------------------
+    # ---- bytes of the K launches of region 0, counted by the kernel itself: restore the snapshot and replay them (untimed) with
+    #      the accounting instantiation — algorithmic bytes (the numerator of `frac`) and issued bytes (`traffic`) ----
     roofline = None
     if rank == 0:
         for k, v in snap.items():
             batch.planes[k].copy_(v)
         batch.rec.copy_(snap_rec)
         batch.cnt.copy_(snap_cnt)
-        batch.enable_accounting(True)
-        batch.accounting(clear=True)
-        for i in range(Wm, Wm + K):
-            j = i % S
-            batch.step_bbox_ptr(bptr[j], optr[j], FL & ~STEP_PACK_OBS, sh)  # (the accounting instantiation has no epilogues)
-        torch.cuda.synchronize(dev)
-        nbytes, nsteps = batch.accounting(clear=True)
-        batch.enable_accounting(False)
-        if FL & STEP_PACK_OBS:  # the packed row: the grid plane read once more, the row written once
-            nbytes += K * n * (H * W + batch.packed_obs_size())
-        per_launch_bytes = nbytes / K
-        achieved = per_launch_bytes / kernel_avg_s
-        traffic = traffic_src = frac_traffic = None
+
+        def replay_region0(sh_):
+            for i in range(Wm, Wm + K):
+                batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, sh_)
+        per_launch_bytes, issued_bytes, _ = counted_bytes(batch, replay_region0, K, dev)
+        kname = {"c3": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>",
+                 "c4": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|pack, 30> (fused packed-row epilogue; a multi-rank run has the all-gather inside the event pair)"}.get(a.config, "arcle_step_kernel")
+        roofline = roofline_block(kname, kernel_avg_s, per_launch_bytes, issued_bytes, n, PS=batch.PS, planes=len(batch.planes),
+                                  note="algorithmic bytes follow SURVEY.md 8d and include the reset_sel zero-fills of `selected` that "
+                                       "ARCLE_STEP_ELIDE_SELECTED never writes (about 14 % of the figure on this mix); `traffic` does not")
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path) and a.config == "c3" and n == CONFIGS["c3"]["envs"]:
             pmc = json.load(open(pmc_path))
-            traffic = pmc.get("hbm_bytes_per_launch")
-            traffic_src = "recorded (not measured in this run): " + str(pmc.get("source"))
-            if traffic:
-                frac_traffic = traffic / kernel_avg_s / HBM_PEAK
-        roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                    "frac_by_traffic": frac_traffic,
-                    "kernel": "arcle_step_kernel" + (" (feature instantiation with the fused packed-row epilogue; the all-gather is inside the event pair)"
-                                                     if gather is not None else ""),
-                    "avg_launch_us": kernel_avg_s * 1e6,
-                    "algorithmic_bytes_per_launch": per_launch_bytes,
-                    "algorithmic_bytes_per_env_step": nbytes / max(nsteps, 1),
-                    "note": "algorithmic bytes follow SURVEY.md 8d and include the reset_sel zero-fills of `selected` that "
-                            "ARCLE_STEP_ELIDE_SELECTED never writes (about 14 % of the figure on this mix)",
-                    "frac_of_measured_copy_peak_6.29TBps": achieved / 6.29e12}
+            roofline["pmc_crosscheck"] = {"hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"),
+                                          "source": "recorded, not measured in this run: " + str(pmc.get("source"))}
+        if a.config == "c2":
+            roofline.update({"bound": "launch-floor", "launch_floor_us": 2.5})
+        if a.config == "c5":
+            roofline.update({"bound": "iteration (dependent flood-fill passes)"})
 
     if rank == 0:
         out = {
@@ -593,8 +893,22 @@ def main():
             out["floodfill"] = {"share_of_actions": float(((op_np >= 10) & (op_np < 20)).mean()),
                                 "frontier_rounds": frontier_rounds_sample(grids, seeds)}
         if world == 1 and not a.no_extras and a.config == "c3":
-            out["extras"] = {"rollout": rollout_leg(batch, bbox, op, dev), "research_env": research_env_leg(dev, n, bbox, op),
-                             "host_actions": host_actions_leg(batch, bbox, op, FL, dev)}
+            ex = {}
+            for name, leg in (("vec_api", lambda: vec_api_leg(dev, n, bbox, op)),
+                              ("research_env", lambda: research_env_leg(dev, n, bbox, op)),
+                              ("mask_ingress", lambda: ingress_leg(dev, n, bbox, op)),
+                              ("host_actions", lambda: host_actions_leg(dev, n, bbox, op)),
+                              ("single_env", lambda: single_env_leg(dev)),
+                              ("transition_rows", lambda: transition_leg(dev, n, bbox, op)),
+                              ("rollout", lambda: rollout_leg(batch, bbox, op, dev)),
+                              ("batch_sweep", lambda: batch_sweep_leg(dev, bbox, op)),
+                              ("other_configs", lambda: other_configs_leg(dev))):
+                try:
+                    ex[name] = leg()
+                except Exception as exc:  # an extra must never cost the headline line
+                    ex[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.empty_cache()
+            out["extras"] = ex
         if world == 1 and not a.no_cpu_baseline and a.config == "c3":
             out["cpu_baseline"] = cpu_baseline(1000)
         print(json.dumps(out), flush=True)

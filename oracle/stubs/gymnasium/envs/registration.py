@@ -1,3 +1,7 @@
+import gymnasium
+
+registry = gymnasium._registry  # id -> entry point (the real package maps id -> EnvSpec; `id in registry` works on both)
+
+
 def register(id, entry_point, **kwargs):
-    import gymnasium
     gymnasium._registry[id] = entry_point

@@ -16,11 +16,18 @@ class Discrete(Space):
         super().__init__(n, *a, **k)
         self.n = n
 
+    def sample(self):
+        import random
+        return random.randrange(int(self.n))
+
 
 class Tuple(Space):
     def __init__(self, spaces, *a, **k):
         super().__init__(spaces, *a, **k)
         self.spaces = tuple(spaces)
+
+    def sample(self):
+        return tuple(s.sample() for s in self.spaces)
 
 
 class Dict(Space):

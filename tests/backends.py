@@ -50,6 +50,40 @@ def checksum(a):
         return (flat * _W[: flat.shape[1]]).sum(axis=1, dtype=np.uint64)
 
 
+BITS_STRIDE = 128
+
+
+def pack_bits(masks):
+    """[N,H,W] masks (truthy = non-zero) -> uint8 [N,128] rows, bit f of a row = cell f (the INGRESS_BITS form of include/arcle_hip.h)."""
+    m = np.asarray(masks)
+    n = m.shape[0]
+    flat = (m.reshape(n, -1) != 0)
+    out = np.zeros((n, BITS_STRIDE), np.uint8)
+    pk = np.packbits(flat, axis=1, bitorder="little")
+    out[:, :pk.shape[1]] = pk
+    return out
+
+
+def row_layout(kind, P):
+    """(field, length) of the full flattened state row in FlattenObservation order (arcle_wave.h flat_row; pinned on the reference's
+    FlattenObservation rows by features.flat)."""
+    lay = []
+    if kind != "raw":
+        lay += [("clip", P), ("clip_dim", 2)]
+    lay += [("grid", P), ("grid_dim", 2), ("input", P), ("input_dim", 2)]
+    if kind == "o2arc":
+        lay += [("active", 1), ("background", P), ("object", P), ("object_dim", 2), ("object_pos", 2), ("object_sel", P),
+                ("rotation_parity", 1), ("selected", P)]
+    lay += [("terminated", 1), ("trials_remain", 1)]
+    return lay
+
+
+def state_rows(be):
+    """The full flattened state rows of a backend, built on the host from its fields (int8 [N, L])."""
+    parts = [np.asarray(be.get(f)).reshape(be.N, -1) for f, _ in row_layout(be.kind, be.H * be.W)]
+    return np.ascontiguousarray(np.concatenate(parts, 1).astype(np.int8))
+
+
 # ---- oracle ------------------------------------------------------------------------------------------
 class OracleBackend:
     name = "oracle"
@@ -68,6 +102,9 @@ class OracleBackend:
         self.env.reset(mask)
 
     def step(self, ingress, payload, op, flags=0):
+        if ingress == "bbox5":  # (the oracle knows the three classic forms: the record form is bbox + op)
+            payload = np.asarray(payload)
+            ingress, payload, op = "bbox", payload[:, :4], payload[:, 4]
         fn = {"bbox": self.env.step_bbox, "point": self.env.step_point, "mask": self.env.step_mask}[ingress]
         r, t = fn(payload, op, flags)
         return r.copy(), t.copy()
@@ -124,7 +161,7 @@ def emu_lib():
 
 class EmuBackend:
     name = "emu"
-    INGRESS = {"mask": 0, "bbox": 1, "point": 2}
+    INGRESS = {"mask": 0, "bbox": 1, "point": 2, "bbox5": 3, "bits": 4}
 
     PLANE_STRIDE = None  # override: bytes between envs of a plane (default = the library's: H*W rounded up to 128)
 
@@ -231,6 +268,7 @@ class EmuBackend:
         if getattr(self, "_flat", None) is not None:  # destination of STEP_FLAT_OBS
             out, L, filtered = self._flat
             p.flat_out, p.flat_stride, p.flat_filter = out.ctypes.data, out.shape[1], int(filtered)
+            p.flat_tail = int(getattr(self, "_flat_tail", False))
 
     def set_packed_output(self):
         self._pack = np.full((self.N, (self.P + 7 + 15) & ~15), 0x55, np.uint8)
@@ -242,14 +280,60 @@ class EmuBackend:
         o2, clip = "selected" in self.buf, "clip" in self.buf
         return 3 * self.P + 10 if filtered else 2 * self.P + 6 + (self.P + 2 if clip else 0) + (4 * self.P + 6 if o2 else 0)
 
-    def set_flat_output(self, filtered=False):
+    def set_flat_output(self, filtered=False, tail=False):
         L = self._flat_len(filtered)
-        self._flat = (np.full((self.N, (L + 15) & ~15), 0x55, np.int8), L, filtered)
+        self._flat = (np.full((self.N, ((L + 15) & ~15) + (16 if tail else 0)), 0x55, np.int8), L, filtered)
+        self._flat_tail = tail
 
     def fused_flat(self):
         out, L, _ = self._flat
-        assert not out[:, L:].any()
+        assert not out[:, L:((L + 15) & ~15)].any()
         return out[:, :L].copy()
+
+    def fused_tail(self):
+        """int32 [N,4] view of the rows' tails: reward, action_steps, submit_count, terminated | truncated << 8 | status << 16."""
+        out = self._flat[0]
+        return np.ascontiguousarray(out[:, out.shape[1] - 16:]).view(np.int32).copy()
+
+    def pack_mask_bits(self, masks):
+        p = self._params()
+        pay = np.ascontiguousarray(np.asarray(masks).astype(np.int8)).reshape(self.N, self.P)
+        out = np.full((self.N, BITS_STRIDE), 0x55, np.uint8)
+        p.sel, p.flat_out = pay.ctypes.data, out.ctypes.data
+        rc = emu_lib().emu_run(8, ctypes.byref(p))
+        assert rc == 0
+        return out
+
+    def set_state_rows(self, rows, mask=None):
+        p = self._params()
+        rows = np.ascontiguousarray(rows, np.int8)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rows_in, p.rows_in_stride = rows.ctypes.data, rows.shape[1]
+        p.rmask = None if m is None else m.ctypes.data
+        rc = emu_lib().emu_run(6, ctypes.byref(p))
+        assert rc == 0
+
+    def transition_rows(self, rows, ingress, payload, op, src_env=None, tail=False, flags=0):
+        p = self._params()
+        self._extras(p)
+        rows = np.ascontiguousarray(rows, np.int8)
+        M = rows.shape[0]
+        L = self._flat_len(False)
+        out = np.full((M, ((L + 15) & ~15) + (16 if tail else 0)), 0x55, np.int8)
+        pay = (np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(M, self.P) if ingress == "mask"
+               else np.ascontiguousarray(payload, np.int32))
+        opa = np.ascontiguousarray(op, np.int32)
+        reward, term = np.zeros(M, np.int32), np.zeros(M, np.uint8)
+        src = None if src_env is None else np.ascontiguousarray(src_env, np.int32)
+        p.n_resident, p.n_envs = self.N, M
+        p.rows_in, p.rows_in_stride = rows.ctypes.data, rows.shape[1]
+        p.flat_out, p.flat_stride, p.flat_filter, p.flat_tail = out.ctypes.data, out.shape[1], 0, int(tail)
+        p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
+        p.reward, p.term = reward.ctypes.data, term.ctypes.data
+        p.task_idx = None if src is None else src.ctypes.data
+        rc = emu_lib().emu_run(7, ctypes.byref(p))
+        assert rc == 0, f"wave emulator reported error {rc}"
+        return out, reward, term
 
     def set_truncation(self, limit):
         self.trunc, self.step_limit = np.zeros(self.N, np.uint8), int(limit)
@@ -294,10 +378,14 @@ class EmuBackend:
         self._extras(p)
         if ingress == "mask":
             pay = np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(self.N, self.P)
+        elif ingress == "bits":
+            pay = np.ascontiguousarray(payload, np.uint8).reshape(self.N, BITS_STRIDE)
         else:
             pay = np.ascontiguousarray(payload, np.int32)
-        opa = np.ascontiguousarray(op, np.int32)
+        opa = np.ascontiguousarray(op if op is not None else np.zeros(self.N), np.int32)
         p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
+        if ingress == "bbox5":
+            p.op = None
         rc = emu_lib().emu_run(0, ctypes.byref(p))
         assert rc == 0, f"wave emulator reported error {rc} (divergent cross-lane op / non-uniform value)"
         return self.reward.copy(), self.term.copy()
@@ -342,7 +430,13 @@ class HipBackend:
     def step(self, ingress, payload, op, flags=0):
         t = self.torch
         dev = self.b.device
+        if ingress == "bbox5":
+            r, tm = self.b.step_bbox5(t.as_tensor(np.ascontiguousarray(payload, np.int32), device=dev), flags)
+            return r.cpu().numpy().copy(), tm.cpu().numpy().copy()
         opt = t.as_tensor(np.ascontiguousarray(op, np.int32), device=dev)
+        if ingress == "bits":
+            r, tm = self.b.step_bits(t.as_tensor(np.ascontiguousarray(payload, np.uint8), device=dev), opt, flags)
+            return r.cpu().numpy().copy(), tm.cpu().numpy().copy()
         if ingress == "mask":
             pay = t.as_tensor(np.ascontiguousarray(np.asarray(payload).astype(np.int8)), device=dev).reshape(self.N, self.H, self.W)
             r, tm = self.b.step_mask(pay, opt, flags)
@@ -392,14 +486,39 @@ class HipBackend:
     def flat_obs(self, filtered=False):
         return self.b.flat_obs(filtered=filtered).cpu().numpy().copy()
 
-    def set_flat_output(self, filtered=False):
-        self.b.set_flat_output(filtered)
+    def set_flat_output(self, filtered=False, tail=False):
+        self.b.set_flat_output(filtered, tail)
         self.b._flat_buf.fill_(0x55)
 
     def fused_flat(self):
         self.torch.cuda.synchronize()
-        assert not self.b._flat_buf[:, self.b.flat.shape[1]:].any()
+        L = self.b.flat.shape[1]
+        assert not self.b._flat_buf[:, L:(L + 15) & ~15].any()
         return self.b.flat.cpu().numpy().copy()
+
+    def fused_tail(self):
+        self.torch.cuda.synchronize()
+        return self.b.flat_tail.cpu().numpy().copy()
+
+    def pack_mask_bits(self, masks):
+        t = self.torch
+        return self.b.pack_mask_bits(t.as_tensor(np.ascontiguousarray(np.asarray(masks).astype(np.int8)), device=self.b.device)).cpu().numpy()
+
+    def set_state_rows(self, rows, mask=None):
+        t = self.torch
+        self.b.set_state_rows(t.as_tensor(np.ascontiguousarray(rows, np.int8), device=self.b.device),
+                              None if mask is None else t.as_tensor(np.ascontiguousarray(mask, np.uint8), device=self.b.device))
+
+    def transition_rows(self, rows, ingress, payload, op, src_env=None, tail=False, flags=0):
+        t, dev = self.torch, self.b.device
+        M = len(rows)
+        pay = (t.as_tensor(np.ascontiguousarray(np.asarray(payload).astype(np.int8)), device=dev).reshape(M, self.H, self.W) if ingress == "mask"
+               else t.as_tensor(np.ascontiguousarray(payload, np.int32), device=dev))
+        out, r, tm = self.b.transition_rows(t.as_tensor(np.ascontiguousarray(rows, np.int8), device=dev), ingress, pay,
+                                            t.as_tensor(np.ascontiguousarray(op, np.int32), device=dev),
+                                            None if src_env is None else t.as_tensor(np.ascontiguousarray(src_env, np.int32), device=dev),
+                                            tail=tail, flags=flags)
+        return out.cpu().numpy(), r.cpu().numpy(), tm.cpu().numpy()
 
     def packed_obs(self):
         return self.b.packed_obs().cpu().numpy().copy()
@@ -507,8 +626,10 @@ def replay_fixture(backend_cls, name, max_steps=None, flags=0):
 
 # ---- random differential traces (no reference needed: backend vs oracle) ---------------------------------
 def random_trace_compare(backend_cls, kind, ops, H, W, N, S, seed, max_trial=-1, flags=0, op_weights=None,
-                         bad_ops=False):
-    """Steps `backend_cls` and the oracle side by side on seeded random tasks/actions; returns mismatches."""
+                         bad_ops=False, new_forms=False):
+    """Steps `backend_cls` and the oracle side by side on seeded random tasks/actions; returns mismatches.
+    new_forms: the backend under test receives bbox actions as 5-tuple records (bbox5) and masks bit-packed (bits; the masks are
+    boolean then) — the oracle gets the classic forms of the same actions."""
     rng = np.random.default_rng(seed)
     be = backend_cls(N, H, W, max_trial, kind, ops)
     orc = OracleBackend(N, H, W, max_trial, kind, ops)
@@ -563,9 +684,14 @@ def random_trace_compare(backend_cls, kind, ops, H, W, N, S, seed, max_trial=-1,
                 elif t == 3:
                     x, y = rng.integers(0, H), rng.integers(0, W)
                     pay[n, x:x + rng.integers(1, 5), y:y + rng.integers(1, 5)] = 1
-        r1, t1 = be.step(ing, pay, op, flags)
+        if new_forms and ing == "bbox":
+            r1, t1 = be.step("bbox5", np.concatenate([pay, op[:, None]], 1), None, flags)
+        elif new_forms and ing == "mask":
+            r1, t1 = be.step("bits", pack_bits(pay), op, flags)
+        else:
+            r1, t1 = be.step(ing, pay, op, flags)
         r2, t2 = orc.step(ing, pay, op, flags)
-        tag = f"{kind} {H}x{W} seed {seed} step {s} ingress {ing}"
+        tag = f"{kind} {H}x{W} seed {seed} step {s} ingress {ing}{' (new form)' if new_forms else ''}"
         if not np.array_equal(r1, r2):
             errs.append(f"{tag}: reward mismatch envs {np.nonzero(r1 != r2)[0].tolist()}")
         if not np.array_equal(t1, t2):

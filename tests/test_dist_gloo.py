@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 import backends as B
 from oracle import oracle as O
 
-G, H, W, S = 12, 10, 10, 24
+G, H, W, S = 13, 10, 10, 24  # 13 envs over 2 ranks: shards of 7 and 6 (the short one is padded for the collective)
 
 
 class _PackedRows:
@@ -29,6 +29,8 @@ class _PackedRows:
         return (H * W + 7 + 15) & ~15
 
     def packed_obs(self, out):
+        if out.shape[0] == 0:
+            return out
         be, n = self.env.be, self.env.N
         rows = np.zeros((n, self.packed_obs_size()), np.uint8)
         rows[:, :H * W] = be.get("grid").reshape(n, -1).view(np.uint8)
@@ -44,6 +46,7 @@ class OracleVecEnv:
 
     def __init__(self, n, lo, hi, tasks):
         self.N = n
+        self.lo, self.hi = lo, hi
         self.be = B.OracleBackend(n, H, W, 3, "o2arc", O.o2arc_ops())
         inp, idim, ans, adim = tasks
         self.be.set_tasks(inp[lo:hi], idim[lo:hi], ans[lo:hi], adim[lo:hi])
@@ -75,8 +78,10 @@ def _worker(rank, world, port, out_q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from arcle_amd.dist import ShardedVecEnv, shard_range
     tasks, bbox, op = make_tasks_and_actions()
+    out = {}
+    # (1) synchronous gather after every step, unequal shards
     env = ShardedVecEnv(G, lambda n, lo, hi: OracleVecEnv(n, lo, hi, tasks))
-    assert (env.lo, env.hi) == shard_range(G, world, rank) and env.N == G // world
+    assert (env.lo, env.hi) == shard_range(G, world, rank) and env.N == env.hi - env.lo
     grids, rewards = [], []
     for s in range(S):
         obs, r, t, _, _ = env.step_bbox(env.local_slice(bbox[s]), env.local_slice(op[s]))  # local, no comm
@@ -84,8 +89,43 @@ def _worker(rank, world, port, out_q):
         assert ggrid.shape == (G, H, W) and gdim.shape == (G, 2) and gr.shape == (G,) and gt.dtype == torch.bool
         grids.append(ggrid.numpy().copy())
         rewards.append(gr.numpy().copy())
+    out["sync"] = (np.stack(grids), np.stack(rewards))
+    # (2) overlapped: the gather of step s is only waited for AFTER step s+1 has been issued (double-buffered rows)
+    env = ShardedVecEnv(G, lambda n, lo, hi: OracleVecEnv(n, lo, hi, tasks))
+    grids, pending = [], None
+    for s in range(S):
+        env.step_bbox(env.local_slice(bbox[s]), env.local_slice(op[s]))
+        work = env.gather_async()
+        if pending is not None:
+            grids.append(pending.wait()[0].numpy().copy())
+            env.release(pending)
+        pending = work
+    grids.append(pending.wait()[0].numpy().copy())
+    out["async"] = np.stack(grids)
+    # (3) two ping-pong groups: group B steps while group A's rows are in flight
+    env = ShardedVecEnv(G, lambda n, lo, hi: OracleVecEnv(n, lo, hi, tasks), groups=2)
+    per_group = [[], []]
+    for s in range(S):
+        works = []
+        for g in range(2):
+            env.step_bbox(env.local_slice(bbox[s], g), env.local_slice(op[s], g), group=g)
+            works.append(env.gather_async(g))
+        for g in range(2):
+            per_group[g].append(works[g].wait()[0].numpy().copy())
+    out["groups"] = ([np.stack(x) for x in per_group], [env.group_global_ids(g).numpy() for g in range(2)])
+    # (4) every = 4: rows of 4 steps travel in one collective
+    env = ShardedVecEnv(G, lambda n, lo, hi: OracleVecEnv(n, lo, hi, tasks), every=4)
+    chunks = []
+    for s in range(S):
+        env.step_bbox(env.local_slice(bbox[s]), env.local_slice(op[s]))
+        assert env.ready() == (s % 4 == 3)
+        if env.ready():
+            ggrid, gdim, gr, gt = env.gather()
+            assert ggrid.shape == (4, G, H, W) and gr.shape == (4, G)
+            chunks.append(ggrid.numpy().copy())
+    out["every"] = np.concatenate(chunks)
     if rank == 0:
-        out_q.put((np.stack(grids), np.stack(rewards)))
+        out_q.put(out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,16 +145,24 @@ def test_two_shards_equal_one_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    grids, rewards = q.get(timeout=120)
+    out = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     tasks, bbox, op = make_tasks_and_actions()
     single = OracleVecEnv(G, 0, G, tasks)
+    want = []
     for s in range(S):
         obs, r, t, _, _ = single.step_bbox(bbox[s], op[s])
-        assert np.array_equal(obs["grid"].numpy(), grids[s]), f"gathered grids differ from the 1-process run at step {s}"
-        assert np.array_equal(r.numpy(), rewards[s])
+        want.append(obs["grid"].numpy().copy())
+        assert np.array_equal(want[-1], out["sync"][0][s]), f"gathered grids differ from the 1-process run at step {s}"
+        assert np.array_equal(r.numpy(), out["sync"][1][s])
+    want = np.stack(want)
+    assert np.array_equal(out["async"], want), "overlapped gathers (waited one step late) differ from the 1-process run"
+    (ga, gb), (ia, ib) = out["groups"]
+    assert sorted(ia.tolist() + ib.tolist()) == list(range(G))
+    assert np.array_equal(ga, want[:, ia]) and np.array_equal(gb, want[:, ib]), "ping-pong groups differ from the 1-process run"
+    assert np.array_equal(out["every"], want), "every=4 gathers differ from the 1-process run"
 
 
 def test_shard_ranges():

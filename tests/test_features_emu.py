@@ -4,10 +4,20 @@ import pytest
 
 import backends as B
 import features as F
+import rows as R
 
 
 @pytest.mark.parametrize("check", [F.wrappers, F.augment, F.dense, F.reset_on_submit, F.flat, F.continue_rule, F.sampler,
                                    F.truncation, F.packed, F.bad_selection], ids=lambda f: f.__name__)
 def test_emulated_kernel_feature(check):
+    errs = check(B.EmuBackend)
+    assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("check", [R.new_ingress_forms, R.mask_bits_packer, R.state_rows_roundtrip, R.transition_rows, R.flat_tail,
+                                   R.dense_on_autoreset], ids=lambda f: f.__name__)
+def test_emulated_round3_boundary(check):
+    """bbox5 / bit-packed ingress, state rows in, stateless batched transition, row tail, dense on auto-reset steps — the kernel
+    bodies run lock-step on the CPU against the oracle."""
     errs = check(B.EmuBackend)
     assert not errs, "\n".join(errs[:10])

@@ -10,6 +10,7 @@ import pytest
 
 import backends as B
 import features as F
+import rows as R
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -27,6 +28,13 @@ def _gpu():
 @pytest.mark.parametrize("check", [F.wrappers, F.augment, F.dense, F.reset_on_submit, F.flat, F.continue_rule, F.sampler,
                                    F.truncation, F.packed, F.bad_selection], ids=lambda f: f.__name__)
 def test_hip_feature(check):
+    errs = check(B.HipBackend)
+    assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("check", [R.new_ingress_forms, R.mask_bits_packer, R.state_rows_roundtrip, R.transition_rows, R.flat_tail,
+                                   R.dense_on_autoreset], ids=lambda f: f.__name__)
+def test_hip_round3_boundary(check):
     errs = check(B.HipBackend)
     assert not errs, "\n".join(errs[:10])
 

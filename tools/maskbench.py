@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The C3 action stream through the three ingress forms (bbox tuples, point tuples, full H x W int8 masks built from the same
-rectangles), graph-replayed: us per launch of 8192 envs."""
+"""The C3 action stream through the ingress forms (bbox tuples, point tuples, full H x W int8 masks built from the same
+rectangles, the same masks bit-packed, 5-tuple records, 5-tuple records read straight from pinned host memory), graph-replayed:
+us per launch of 8192 envs."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,17 +18,27 @@ masks = ((ii >= x1[..., None, None]) & (ii <= x2[..., None, None]) & (jj >= y1[.
 pay = {"bbox": torch.from_numpy(bbox_np).to(dev), "point": torch.from_numpy(np.ascontiguousarray(bbox_np[..., :2])).to(dev),
        "mask": torch.from_numpy(masks).to(dev)}
 ops = torch.from_numpy(op_np).to(dev)
-for ing in ("bbox", "point", "mask"):
+act5 = np.concatenate([bbox_np, op_np[..., None]], -1).astype(np.int32)
+pay["bbox5"] = torch.from_numpy(act5).to(dev)
+pay["bbox5_host"] = torch.from_numpy(act5).pin_memory()
+for ing in ("bbox", "point", "mask", "bits", "bbox5", "bbox5_host"):
     batch = EnvBatch(n, 30, 30, -1, "o2arc", dev)
     batch.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
     batch.set_tasks_padded(*bench.make_tasks(n, 1)); batch.reset()
     FL = batch.elide_flag | bench.STEP_AUTORESET
-    fn = {"bbox": batch.L.arcle_step_bbox, "point": batch.L.arcle_step_point, "mask": batch.L.arcle_step_mask}[ing]
+    if ing == "bits":
+        pay["bits"] = torch.stack([batch.pack_mask_bits(pay["mask"][i]) for i in range(K)])
+        torch.cuda.synchronize()
+    fn = {"bbox": batch.L.arcle_step_bbox, "point": batch.L.arcle_step_point, "mask": batch.L.arcle_step_mask,
+          "bits": batch.L.arcle_step_bits}.get(ing)
     st = torch.cuda.Stream(dev); g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=st):
         sh = torch.cuda.current_stream(dev).cuda_stream
         for i in range(K):
-            rc = fn(batch._h, pay[ing][i].data_ptr(), ops[i].data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh)
+            if fn is None:
+                rc = batch.L.arcle_step_bbox5(batch._h, pay[ing][i].data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh)
+            else:
+                rc = fn(batch._h, pay[ing][i].data_ptr(), ops[i].data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh)
             assert rc == 0
     for _ in range(20): g.replay()
     torch.cuda.synchronize()
