@@ -260,4 +260,5 @@ class ShardedVecEnv:
                 return grid.reshape(K, G, b.H, b.W), gdim.reshape(K, G, 2), rew.reshape(K, G), tm.reshape(K, G)
         c = _Captured()
         c.graph, c.payload, c.operation = g, payload, operation
+        c._keep = (packed, full, reward, term, trunc, dense)  # everything the captured launches write stays alive with the graph
         return c

@@ -107,10 +107,11 @@ class CapturedSteps:
       terminated   [K, N] bool,  truncated [K, N] bool
     A captured graph keeps the tables / outputs it was captured with (every launch holds its parameters by value)."""
 
-    def __init__(self, venv, graph, payload, operation, reward, term, trunc):
+    def __init__(self, venv, graph, payload, operation, reward, term, trunc, keep=()):
         self.venv, self.graph, self.payload, self.operation = venv, graph, payload, operation
         self.reward, self.terminated, self.truncated = reward, term, trunc
         self.steps = int(payload.shape[0])
+        self._keep = keep  # every buffer the captured launches write (raw rewards, dense pairs, ...) lives as long as the graph
 
     def replay(self):
         self.graph.replay()
@@ -484,7 +485,7 @@ class ARCVecEnv:
             self._enqueue_steps(form, payload, operation, reward, term, trunc, dense)
             r = self._dense(reward, dense) if dense is not None else reward
         tr = trunc.view(torch.bool) if trunc is not None else torch.zeros_like(term, dtype=torch.bool)
-        return CapturedSteps(self, g, payload, operation, r, term.view(torch.bool), tr)
+        return CapturedSteps(self, g, payload, operation, r, term.view(torch.bool), tr, keep=(reward, term, trunc, dense))
 
     # ---- state in / out ------------------------------------------------------------------------------------
     def state_rows(self, out=None):
