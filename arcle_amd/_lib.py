@@ -23,7 +23,7 @@ EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buff
            "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_step_bbox5", "arcle_step_bits", "arcle_pack_mask_bits",
            "arcle_step_many", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation",
            "arcle_packed_obs_size", "arcle_pack_obs", "arcle_set_packed_output", "arcle_set_sampler", "arcle_reset_sampled",
-           "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_flat_obs_size", "arcle_flatten_obs",
+           "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_invalidate", "arcle_flat_obs_size", "arcle_flatten_obs",
            "arcle_set_flat_output", "arcle_set_flat_output_ex", "arcle_get_state_rows", "arcle_set_state_rows",
            "arcle_transition_rows", "arcle_get_plane", "arcle_set_plane", "arcle_get_status",
            "arcle_enable_accounting", "arcle_get_accounting", "arcle_get_accounting_ex", "arcle_last_error"]
@@ -102,6 +102,7 @@ def lib():
     L.arcle_reset_sampled.argtypes = [vp, vp, vp]
     L.arcle_reset_from_table_aug.argtypes = [vp, vp, vp, vp, vp, vp]
     L.arcle_set_dense_output.argtypes = [vp, vp]
+    L.arcle_invalidate.argtypes = [vp, vp]
     L.arcle_packed_obs_size.argtypes = [vp]
     L.arcle_pack_obs.argtypes = [vp, vp, vp, vp, vp]
     L.arcle_set_packed_output.argtypes = [vp, vp]

@@ -324,6 +324,7 @@ struct arcle_env {
   int flat_tail;
   uint32_t* retired_ops[64];  // op tables replaced by arcle_set_op_table: launches in flight (and captured graphs) may still read them
   int n_retired;
+  int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
   uint32_t* d_acct;
   uint64_t acct_steps;
   int device;
@@ -450,6 +451,7 @@ extern "C" int arcle_destroy(arcle_env* e) {
   if (e->d_status) (void)hipFree(e->d_status);
   if (e->d_ops) (void)hipFree(e->d_ops);
   for (int i = 0; i < e->n_retired; i++) (void)hipFree(e->retired_ops[i]);
+  if (e->d_dense_cache) (void)hipFree(e->d_dense_cache);
   if (e->d_acct) (void)hipFree(e->d_acct);
   delete e;
   return ARCLE_OK;
@@ -586,8 +588,9 @@ static constexpr int HOT_PACK_FLAGS = HOT_FLAGS | ARCLE_STEP_PACK_OBS;
 // max_episode_steps) runs it): episode end -> new device-drawn task, TimeLimit, dense reward pair, fused FilterO2ARC rows
 static constexpr int RESEARCH_FLAGS = ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_TRUNCATE | ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_FLAT_OBS;
 static constexpr int RESEARCH_FL = RESEARCH_FLAGS | ARCLE_STEPX_FLAT_FILTERED;
-static bool research_shape(const StepParams& p) {
-  return p.flags == (uint32_t)RESEARCH_FLAGS && p.flat_filter == 1 && p.flat_tail == 0 && p.flat_stride == ARCLE_ROW30_FILTERED_STRIDE;
+static constexpr int RESEARCH_INC_FL = RESEARCH_FL | ARCLE_STEP_ROWS_INCREMENTAL;  // ... with incremental rows (what ARCVecEnv runs)
+static bool research_shape(const StepParams& p, uint32_t extra = 0) {
+  return p.flags == ((uint32_t)RESEARCH_FLAGS | extra) && p.flat_filter == 1 && p.flat_tail == 0 && p.flat_stride == ARCLE_ROW30_FILTERED_STRIDE;
 }
 #ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiations exist (seconds instead of a minute)
 template <int ING>
@@ -595,6 +598,7 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
   if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || p.H != 30 || p.W != 30) return ARCLE_ERR_CONFIG;
   if (feat || acct) {
     if (!acct && research_shape(p)) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 1, RESEARCH_FL, 30);
+    else if (!acct && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 1, RESEARCH_INC_FL, 30);
     else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 1);
   } else if (p.flags == (uint32_t)HOT_FLAGS) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS, 30);
   else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, -1, 30);
@@ -608,6 +612,7 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
       if (p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_PACK_FLAGS, 30); return; }
       if (p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_FLAGS, 30); return; }
       if (research_shape(p)) { LAUNCH_STEP(ING, FW, 0, 1, RESEARCH_FL, 30); return; }
+      if (research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) { LAUNCH_STEP(ING, FW, 0, 1, RESEARCH_INC_FL, 30); return; }
       if (!feat) { LAUNCH_STEP(ING, FW, 0, 0, -1, 30); return; }
     }
   }
@@ -634,7 +639,8 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if ((flags & ARCLE_STEP_DENSE) && (!e->base.dense || !e->bufs.plane[ARCLE_PL_ANSWER])) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_DENSE without arcle_set_dense_output");
   if ((flags & ARCLE_STEP_CONTINUE_RULE) && (!arcle::is_cells(ingress) || !e->bufs.plane[ARCLE_PL_SELECTED]))
     return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_CONTINUE_RULE needs mask ingress and the `selected` plane");
-  if (flags & ~0x1ffu) return fail(e, ARCLE_ERR_ARG, "unknown step flag");
+  if (flags & ~0x3ffu) return fail(e, ARCLE_ERR_ARG, "unknown step flag");
+  if ((flags & ARCLE_STEP_ROWS_INCREMENTAL) && !(flags & ARCLE_STEP_FLAT_OBS)) return fail(e, ARCLE_ERR_ARG, "ARCLE_STEP_ROWS_INCREMENTAL without ARCLE_STEP_FLAT_OBS");
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.ingress = ingress;
@@ -846,7 +852,22 @@ extern "C" int arcle_reset_from_table_aug(arcle_env* e, const int32_t* task_idx,
 
 extern "C" int arcle_set_dense_output(arcle_env* e, int32_t* dense_out) {
   if (!e) return ARCLE_ERR_ARG;
+  if (dense_out && !e->d_dense_cache) {  // the per-env cache of the current grid's pair; (0, 0) = unknown
+    DeviceGuard guard(e->device);
+    HIP_TRY(e, hipMalloc((void**)&e->d_dense_cache, (size_t)e->cfg.n_envs * 8));
+    HIP_TRY(e, hipMemset(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8));
+    e->base.dense_cache = e->d_dense_cache;
+  }
   e->base.dense = dense_out;
+  return ARCLE_OK;
+}
+
+extern "C" int arcle_invalidate(arcle_env* e, void* stream) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (e->d_dense_cache) {
+    DeviceGuard guard(e->device);
+    HIP_TRY(e, hipMemsetAsync(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8, (hipStream_t)stream));
+  }
   return ARCLE_OK;
 }
 

@@ -99,6 +99,7 @@ struct StepParams {
   const int8_t* rows_in;   // state-row kernels: flattened state rows to read (arcle_transition_rows / arcle_set_state_rows)
   int32_t rows_in_stride;
   int32_t n_resident;      // state-row kernels: envs of the handle (src_env range check); n_envs = rows of the launch
+  int32_t* dense_cache;    // library-owned int32 [N][2]: the dense pair of the env's CURRENT grid, (0, 0) = unknown (see step_core)
 };
 
 // 16 bytes of a plane = 4 VGPRs; a first-class vector value so that it always lives in registers
@@ -276,11 +277,13 @@ struct Wave {
   // lanes incl. row padding) — next to the algorithmic figure of SURVEY.md 8d it shows what the implementation really moves
   bool count;
   mutable uint32_t issued;
+  mutable uint32_t stored;  // planes written (through `store`) since the wave picked up its env: what changed in this step
 
   ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, const U2* lut_, int lane_, int ingress_, int fw_, bool resident_, bool count_ = false)
       : p(p_), lds(l), lut(lut_), lane(lane_) {
     count = count_;
     issued = 0;
+    stored = 0;
     ingress = ingress_ == INGRESS_BBOX5 ? INGRESS_BBOX : ingress_;  // (the record form only differs in where the kernel loads it from)
     fw = fw_;
     resident = resident_;
@@ -314,6 +317,7 @@ struct Wave {
   }
   ARCLE_DEV U4 load(int pl) const { return resident ? cache[pl] : load_hbm(pl); }
   ARCLE_DEV void store(int pl, const U4& v) const {
+    stored |= 1u << pl;
     if (resident) {
       cache[pl] = v;
       dirty |= 1u << pl;
@@ -1183,6 +1187,13 @@ ARCLE_DEV void dense_none(const Wave& w) {
     w.p.dense[2 * (size_t)w.env + 1] = 0;
   }
 }
+// The library keeps the dense pair of every env's CURRENT grid in a cache of its own (StepParams::dense_cache; (0, 0) = unknown):
+// a step that leaves grid and grid_dim alone — failed flood fills, Copy, Submit, no-op moves: about a third of the O2ARC mix —
+// re-uses it instead of reading the grid and the answer plane again.  Everything that changes a grid OUTSIDE an op invalidates the
+// entry: the reset kernels, arcle_set_state_rows, auto-reset steps; host code that edits planes directly calls arcle_invalidate.
+ARCLE_DEV void dense_forget(const Wave& w) {
+  if (w.p.dense_cache && w.lane == 0) *reinterpret_cast<I2*>(w.p.dense_cache + 2 * (size_t)w.env) = I2{0, 0};
+}
 
 // Everything of step() between "record/op/payload are in registers" and "record/counters/outputs go back to
 // memory": autoreset, op decode, the operation itself, reward.  Planes are read/written through w.load/w.store, so
@@ -1212,11 +1223,23 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
       if (resample) ok = load_sampled_task(w, r, w.env, in);
       if (ok) init_state(w, r, cnt0, resample, in);
       else raise_status(p, out, ARCLE_ST_AUG_DOMAIN);
-      if (FEAT && (flags & ARCLE_STEP_DENSE)) dense_none(w);
+      if (FEAT && (flags & ARCLE_STEP_DENSE)) {
+        dense_none(w);
+        dense_forget(w);
+      }
       out.term = 0;
       out.bytes = (uint32_t)((resample ? 9 : 7) * P + 2 * ARCLE_REC_BYTES);
       return out;
     }
+  }
+  // ARCLE_STEP_DENSE: this env's cached pair, requested now so that the scalar load runs under the op
+  I2 dense_prev = I2{0, 0};
+  bool dense_known = false;
+  if (FEAT && (flags & ARCLE_STEP_DENSE) && p.dense_cache && !w.resident) {
+    const U2 c = xl::uload2(p.dense_cache + 2 * (size_t)w.env);
+    dense_prev.x = (int32_t)c[0];
+    dense_prev.y = (int32_t)c[1];
+    dense_known = c[1] != 0u;
   }
   // an index past the table reads slot n_ops, which is always empty (the table copy has one more slot than ARCLE_MAX_OPS)
   const uint32_t slot = (uint32_t)op < (uint32_t)p.n_ops ? (uint32_t)op : (uint32_t)p.n_ops;
@@ -1550,22 +1573,25 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   if (FEAT && (flags & ARCLE_STEP_DENSE)) {
     // the research env's dense reward (agents/env.py:44-58) as an exact integer pair (correct cells, total cells);
     // the host forms  sparse*100 - 1 + correct/total
-    need_grid<ACCT>(w, s);
-    const U4 a = w.load(ARCLE_PL_ANSWER);
-    ARCLE_ACCT(P + 8);
-    const int gh = r.gh(), gw = r.gw(), ah = r.ah(), aw = r.aw();
-    const int mh = imin(gh, ah), mw = imin(gw, aw);
-    // cells of this lane's window that match inside the common rectangle
-    const uint32_t same = (flags16(nzflags(s.grid[0] ^ a[0]), nzflags(s.grid[1] ^ a[1]), nzflags(s.grid[2] ^ a[2]), nzflags(s.grid[3] ^ a[3])) ^ 0xffffu) &
-                          w.rect16(0, mh - 1, 0, mw - 1);
-    const int correct = (int)xl::wave_add((uint32_t)__builtin_popcount(same));
-    int total = mh * mw;
-    if ((gh <= ah) == (gw <= aw)) total += ah * aw > gh * gw ? ah * aw - gh * gw : gh * gw - ah * aw;
-    else total += (gh > ah ? gh - ah : ah - gh) * mw + (gw > aw ? gw - aw : aw - gw) * mh;
-    if (lane == 0) {
-      p.dense[2 * (size_t)w.env] = correct;
-      p.dense[2 * (size_t)w.env + 1] = total;
+    I2 pair = dense_prev;
+    ARCLE_ACCT(16);  // cache entry in, pair out
+    if (!dense_known || (w.stored & (1u << ARCLE_PL_GRID))) {  // the grid (or grid_dim: every op that changes it stores the plane) moved
+      need_grid<ACCT>(w, s);
+      const U4 a = w.load(ARCLE_PL_ANSWER);
+      ARCLE_ACCT(P);
+      const int gh = r.gh(), gw = r.gw(), ah = r.ah(), aw = r.aw();
+      const int mh = imin(gh, ah), mw = imin(gw, aw);
+      // cells of this lane's window that match inside the common rectangle
+      const uint32_t same = (flags16(nzflags(s.grid[0] ^ a[0]), nzflags(s.grid[1] ^ a[1]), nzflags(s.grid[2] ^ a[2]), nzflags(s.grid[3] ^ a[3])) ^ 0xffffu) &
+                            w.rect16(0, mh - 1, 0, mw - 1);
+      pair.x = (int)xl::wave_add((uint32_t)__builtin_popcount(same));
+      int total = mh * mw;
+      if ((gh <= ah) == (gw <= aw)) total += ah * aw > gh * gw ? ah * aw - gh * gw : gh * gw - ah * aw;
+      else total += (gh > ah ? gh - ah : ah - gh) * mw + (gw > aw ? gw - aw : aw - gw) * mh;
+      pair.y = total;
+      if (p.dense_cache && !w.resident && lane == 0) *reinterpret_cast<I2*>(p.dense_cache + 2 * (size_t)w.env) = pair;
     }
+    if (lane == 0) *reinterpret_cast<I2*>(p.dense + 2 * (size_t)w.env) = pair;
   }
   cnt0.x += 1;  // o2arcenv.py:142
   cnt0.y += submit_inc;
@@ -1575,7 +1601,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   return out;
 }
 
-ARCLE_DEV void flat_row(const Wave& w, const Rec& r);  // (the observation writers, below)
+ARCLE_DEV void flat_row(const Wave& w, const Rec& r, bool only_stored = false);  // (the observation writers, below)
 struct StepOut;
 ARCLE_DEV void flat_tail(const Wave& w, const StepOut& out, const I2& cnt, bool truncated);
 ARCLE_HD int flat_obs_len(const StepParams& p, int filtered);
@@ -1680,11 +1706,13 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
     // FilterO2ARC), written by the same wave — no second launch, no re-read of
     // the record.  The planes are read back through the wave's own L1 path (program order, see xl::own_stores_visible).
     xl::own_stores_visible();
-    flat_row(w, r);
+    const uint32_t issued_before = w.issued;
+    flat_row(w, r, (flags & ARCLE_STEP_ROWS_INCREMENTAL) != 0);
     if (p.flat_tail) flat_tail(w, out, cnt0, truncated);
     if (ACCT) {
       out.bytes += 2u * (uint32_t)flat_obs_len(p, p.flat_filter) + ARCLE_REC_BYTES;  // planes + record read once, row written once
-      w.issued += (uint32_t)p.flat_stride;
+      // issued: the plane re-reads were counted by load_hbm; the row bytes written = what was read (+ scalars and padding)
+      w.issued += (flags & ARCLE_STEP_ROWS_INCREMENTAL) ? (w.issued - issued_before) / (uint32_t)p.PS * (uint32_t)p.P + 16u : (uint32_t)p.flat_stride;
     }
   }
   // fused packed row for the multi-GPU gather (grid | grid_dim | reward | terminated): in the feature instantiations, and in
@@ -1774,6 +1802,7 @@ ARCLE_DEV void wave_reset(const StepParams& p, WaveLDS* lds, const U2* lut, int 
   Rec r = load_rec(p, env);
   I2 cnt;
   init_state(w, r, cnt);
+  dense_forget(w);
   xl::lanes_converged();  // (emulator) every lane has read the record before lane 0 rewrites it
   store_rec(p, env, lane, r);
   store_cnt(p, env, lane, cnt);
@@ -1813,6 +1842,7 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
   }
   I2 cnt;
   init_state(w, r, cnt, true, in);
+  dense_forget(w);
   store_rec(p, env, lane, r);
   store_cnt(p, env, lane, cnt);
 }
@@ -1830,11 +1860,16 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
 // and 15 tail bytes stored singly; scalars are byte stores.  No per-row LDS buffer: the writer runs at the step kernel's occupancy.
 // ------------------------------------------------------------------------------------------------
 struct FlatRow {
-  int8_t* row;  // global memory, this env's row
-  int off;      // bytes written so far
+  int8_t* row;       // global memory, this env's row
+  int off;           // bytes written so far
+  bool only_stored;  // ARCLE_STEP_ROWS_INCREMENTAL: rewrite only the segments of planes this step stored
 };
 ARCLE_DEV void flat_plane(const Wave& w, FlatRow& fr, int pl) {
   if (!w.p.plane[pl]) return;
+  if (fr.only_stored && !(w.stored & (1u << pl))) {  // incremental rows: the segment already holds this plane (unchanged this step)
+    fr.off += w.p.P;
+    return;
+  }
   const int P = w.p.P, off = fr.off, lane = w.lane;
   w.stage(w.lds->a, w.load(pl));  // (the state-row kernels keep the planes in registers: `load` serves them from there)
   const int c0 = (off + 15) >> 4, S = 16 * c0 - off;  // first whole chunk of the row inside the segment; its plane byte offset
@@ -1861,13 +1896,14 @@ ARCLE_HD int flat_obs_len(const StepParams& p, int filtered) {
   return 2 * p.P + 6 + (clip ? p.P + 2 : 0) + (o2 ? 4 * p.P + 6 : 0);
 }
 // the row of w's env from the planes in memory and the record `r` (the step kernel calls it with the record it just produced)
-ARCLE_DEV void flat_row(const Wave& w, const Rec& r) {
+ARCLE_DEV void flat_row(const Wave& w, const Rec& r, bool only_stored) {
   const StepParams& p = w.p;
   const int lane = w.lane, env = w.env;
   const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
   FlatRow fr;
   fr.row = p.flat_out + (size_t)env * p.flat_stride;
   fr.off = 0;
+  fr.only_stored = only_stored;
   if (p.flat_filter) {
     flat_scalar(w, fr, r, ARCLE_REC_ACTIVE, 1);
     flat_plane(w, fr, ARCLE_PL_CLIP);
@@ -1984,6 +2020,7 @@ ARCLE_DEV void wave_set_state_row(const StepParams& p, WaveLDS* lds, const U2* l
   w.set_env(env);
   Rec r = load_rec(p, env);
   read_state_row(w, p.rows_in + (size_t)env * p.rows_in_stride, r, [&](int pl, const U4& v) { w.store_hbm(pl, v); });
+  dense_forget(w);
   xl::lanes_converged();
   store_rec(p, env, lane, r);
 }

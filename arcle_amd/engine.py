@@ -34,6 +34,7 @@ STEP_CONTINUE_RULE = 32
 STEP_RESET_ON_SUBMIT = 64
 STEP_FLAT_OBS = 128
 STEP_PACK_OBS = 256
+STEP_ROWS_INCREMENTAL = 512
 AUG_PERMUTE, AUG_ROT90 = 1, 2
 ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION, ST_AUG_DOMAIN = 1, 2, 4, 8, 16
 ROW_TAIL = 16  # bytes of the optional step-output tail of a flat row (arcle_set_flat_output_ex)
@@ -403,7 +404,13 @@ class EnvBatch:
             st["episode"], st["cur_task"] = self.episode.clone(), self.cur_task.clone()
         return st
 
+    def invalidate(self):
+        """After editing state planes behind the library's back (plain tensor writes into `planes`): drop what the library derived
+        from the old state (the dense-pair cache).  Rows kept by ARCLE_STEP_ROWS_INCREMENTAL must be rewritten by the caller."""
+        self._check(self.L.arcle_invalidate(self._h, self._stream()), "arcle_invalidate")
+
     def set_state(self, st):
+        self.invalidate()
         for k, v in st["planes"].items():
             self.planes[k].copy_(v)
         self.rec.copy_(st["rec"])

@@ -166,6 +166,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
                 lo, hi = _span(k)
                 rec[lo:hi] = np.asarray(flat[k], np.int8)
         b.rec[n].copy_(torch.as_tensor(rec, device=dev))
+        b.invalidate()  # (the planes were written behind the library's back)
 
     # ---- Gymnasium API -------------------------------------------------------------------------
     def reset(self, seed=None, options=None):

@@ -18,7 +18,7 @@ import torch
 
 from .. import actions, sampling
 from ..engine import (AUG_PERMUTE, AUG_ROT90, EnvBatch, STEP_AUTORESET, STEP_DENSE, STEP_FLAT_OBS, STEP_PACK_OBS, STEP_RESAMPLE,
-                      STEP_RESET_ON_SUBMIT, STEP_TRUNCATE, ST_AUG_DOMAIN, ST_BAD_OP, ST_BAD_SELECTION, ST_BAD_TASK, ST_ROTATE_DOMAIN)
+                      STEP_RESET_ON_SUBMIT, STEP_ROWS_INCREMENTAL, STEP_TRUNCATE, ST_AUG_DOMAIN, ST_BAD_OP, ST_BAD_SELECTION, ST_BAD_TASK, ST_ROTATE_DOMAIN)
 
 
 def _table_of(env_cls, **ctor_kw):
@@ -272,6 +272,7 @@ class ARCVecEnv:
         pidx, sidx = options.get("prob_index"), options.get("subprob_index")
         if pidx is None and sidx is None:
             self.batch.reset_sampled(mask)
+            self._refresh_rows()
             return self._obs, self._info()
         n_tasks = len(self.loader.data)
         p = self.rng.integers(0, n_tasks, self.N) if pidx is None else np.broadcast_to(np.asarray(pidx, np.int64), (self.N,))
@@ -295,6 +296,7 @@ class ARCVecEnv:
         else:
             self.batch.reset_from_table(idx, mask)
         self.batch.cur_task[m] = idx[m]
+        self._refresh_rows()
         return self._obs, self._info()
 
     # ---- step ------------------------------------------------------------------------------------------
@@ -332,6 +334,7 @@ class ARCVecEnv:
         b = self.batch
         if self._host_slots and operation is not None:
             self._apply_host_ops(operation, action_of, skip, reward, term)
+            self._refresh_rows()
             if self.flags & STEP_PACK_OBS:  # the step kernel packed its rows before the host callables ran: pack again
                 b.packed_obs(b.packed)
         if self.dense_reward:
@@ -353,6 +356,21 @@ class ARCVecEnv:
         if self._host_slots and self.flags & (STEP_AUTORESET | STEP_RESAMPLE):
             return self._ended().clone()
         return None
+
+    def enable_flat_rows(self, filtered=True):
+        """From now on every step also keeps `rows` — int8 [N, L], the FlattenObservation row of every env (filtered=True: the
+        FilterO2ARC subset the reference's policies consume, agents/env.py:109-126) — up to date from inside the step kernel.  The
+        buffer is a live mirror like `obs`: a step rewrites, per env, only the scalars and the segments of the planes that step
+        changed (ARCLE_STEP_ROWS_INCREMENTAL); resets and state ingests rewrite it in full.  Copy it to keep a step's rows."""
+        self.rows = self.batch.set_flat_output(filtered)
+        self._rows_filtered = bool(filtered)
+        self.flags |= STEP_FLAT_OBS | STEP_ROWS_INCREMENTAL
+        self._refresh_rows()
+        return self.rows
+
+    def _refresh_rows(self):
+        if self.flags & STEP_FLAT_OBS:
+            self.batch.flat_obs(out=self.batch._flat_buf, filtered=self._rows_filtered)
 
     def enable_packed_rows(self, out=None):
         """From now on every step also writes `batch.packed` ([N, R] uint8: grid | grid_dim | reward | terminated per env) from
@@ -494,11 +512,9 @@ class ARCVecEnv:
 
     def set_state_rows(self, rows, env_mask=None):
         """Overwrites the state of the (masked) envs from rows as `state_rows` returns them."""
-        if not (self.flags & STEP_RESET_ON_SUBMIT) and not self.batch.L.arcle_can_elide_selected(self.batch._h):
-            pass
         self.batch.set_state_rows(rows, env_mask)
-        self._ingested = True
         self.flags &= ~self.batch.elide_flag  # states from outside may break the invariant the zero-fill elision rests on
+        self._refresh_rows()
 
     def transition(self, rows, action, src_env=None, out=None):
         """The reference's `transition(state, action)` (o2arcenv.py:149-151; README: `env.transition(deepcopy(state), action)`) for
@@ -526,6 +542,7 @@ class ARCVecEnv:
 
     def set_state(self, st):
         self.batch.set_state(st)
+        self._refresh_rows()
 
 
     def rollout_bbox(self, bbox, operation):

@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29e12 measured copy)
 STEP_AUTORESET = 1
 STEP_PACK_OBS = 256
+STEP_ROWS_INCREMENTAL = 512
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -403,30 +404,37 @@ def research_env_leg(dev, n, bbox, op, K=200):
     v = ARCVecEnv(Crop, n, SyntheticLoader(n_tasks=400, seed=1, max_size=(30, 30)), device=dev, seed=7, autoreset="resample", augment=("permute", "rot90"),
                   dense_reward=True, max_episode_steps=100)
     v.reset()
-    rows = v.batch.set_flat_output(filtered=True)
-    FL = v.flags | STEP_FLAT_OBS
+    rows = v.enable_flat_rows(filtered=True)  # a live [N, 2710] mirror of the FilterO2ARC rows, kept by the step kernel
     K = min(K, bbox.shape[0])
     b = v.batch
-
-    def enqueue(sh):
-        for i in range(K):
-            b.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, sh)
     # desynchronise the episodes first (all envs start at step 0: left alone, every env would hit TimeLimit in the same launch —
     # a training run is never in that state after its first episode)
     b.cnt[:, 0] = torch.randint(0, 100, (n,), device=dev, dtype=torch.int32)
     for i in range(100):
-        b.step_bbox_ptr(bbox[i % K].data_ptr(), op[(i * 7 + 3) % K].data_ptr(), FL, torch.cuda.current_stream(dev).cuda_stream)
+        b.step_bbox_ptr(bbox[i % K].data_ptr(), op[(i * 7 + 3) % K].data_ptr(), v.flags, torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
-    alg, issued, _ = counted_bytes(b, enqueue, K, dev)
-    sec, _ = graph_time(dev, enqueue, K)
+    out = {}
+    for name, FL in (("rows_rewritten_in_full", v.flags & ~STEP_ROWS_INCREMENTAL), ("rows_incremental", v.flags)):
+        def enqueue(sh, FL=FL):
+            for i in range(K):
+                b.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, sh)
+        alg, issued, _ = counted_bytes(b, enqueue, K, dev)
+        v._refresh_rows()  # (the byte count replayed the steps and restored the state: bring the mirrored rows back in line)
+        sec, _ = graph_time(dev, enqueue, K)
+        out[name] = {"value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6,
+                     "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 1, research flags, 30>", sec, alg, issued, n,
+                                                note="algorithmic = the step's planes + 56 B, + the dense reward's answer read when the grid moved, "
+                                                     "+ per row: its three planes read once and 2710 B written (SURVEY.md 8d style, also for the "
+                                                     "incremental writer, which leaves unchanged segments alone: compare `traffic`); the kernel re-reads "
+                                                     "the planes it just stored through its own L1/L2, so issued > HBM traffic for the full rewrite")}
     assert b.status() == 0
-    return {"mode": "ARCVecEnv(autoreset='resample', augment, dense_reward, max_episode_steps=100) + fused FilterO2ARC rows",
-            "value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6, "row_bytes": int(rows.shape[1]),
-            "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 1, research flags, 30>", sec, alg, issued, n,
-                                       note="algorithmic = the step's planes + 56 B, + the dense reward's answer read, + per row: its "
-                                            "three planes read once and 2710 B written (SURVEY.md 8d style); the kernel re-reads the "
-                                            "planes it just stored through its own L1/L2, so issued > HBM traffic here"),
-            "note": "one launch per step; 2710-byte observation row per env and step written by the step kernel"}
+    assert torch.equal(rows, b.flat_obs(filtered=True)), "the incrementally kept rows drifted from the state"
+    best = out["rows_incremental"]
+    out.update({"mode": "ARCVecEnv(autoreset='resample', augment, dense_reward, max_episode_steps=100).enable_flat_rows(filtered=True): "
+                        "one launch per step keeps the FilterO2ARC rows of all envs current (incremental writer); the full-rewrite form beside it",
+                "value": best["value"], "unit": "env-steps/s", "us_per_step_batch": best["us_per_step_batch"], "row_bytes": int(rows.shape[1]),
+                "roofline": best["roofline"]})
+    return out
 
 
 def ingress_leg(dev, n, bbox, op, K=64):

@@ -143,9 +143,14 @@ enum arcle_op_kind {
 /* the step kernel also writes the env's packed per-step row  grid | grid_dim | reward | terminated  (arcle_set_packed_output; the
  * record a central learner gathers from every GPU) — fused into the same launch */
 #define ARCLE_STEP_PACK_OBS 256u
+/* with ARCLE_STEP_FLAT_OBS: the row buffer still holds every env's row of the PREVIOUS step (same buffer, installed once, every
+ * step of this handle run with ARCLE_STEP_FLAT_OBS since the rows were last written in full — by arcle_flatten_obs into that buffer or
+ * by a step without this flag).  The writer then rewrites only the scalars and the segments of the planes this step stored; an
+ * op touches one to five of the seven planes, so most of a row is left as it is.  The rows are byte-identical to full rewrites. */
+#define ARCLE_STEP_ROWS_INCREMENTAL 512u
 #define ARCLE_STEP_FEATURE_FLAGS                                                                                        \
   (ARCLE_STEP_RESAMPLE | ARCLE_STEP_DENSE | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT | ARCLE_STEP_FLAT_OBS | \
-   ARCLE_STEP_PACK_OBS)
+   ARCLE_STEP_PACK_OBS | ARCLE_STEP_ROWS_INCREMENTAL)
 
 /* ---- augmentation of a task at reset (arcle_set_sampler / ARCLE_STEP_RESAMPLE / arcle_reset_sampled) ---- */
 #define ARCLE_AUG_PERMUTE 1u /* random permutation of the colours 0..9 (applied to input and answer) */
@@ -289,8 +294,14 @@ int arcle_reset_sampled(arcle_env* env, const uint8_t* mask, void* stream);
  * aug_perm device uint8 [n_envs][16] (perm[c] for colour c < 10); NULL = none. */
 int arcle_reset_from_table_aug(arcle_env* env, const int32_t* task_idx, const uint8_t* mask, const uint8_t* aug_k,
                                const uint8_t* aug_perm, void* stream);
-/* Installs the output of ARCLE_STEP_DENSE: dense_out device int32 [n_envs][2]; NULL removes it. */
+/* Installs the output of ARCLE_STEP_DENSE: dense_out device int32 [n_envs][2]; NULL removes it.  (0, 0) is written for a step that
+ * executed no action (the auto-reset step of an env, a skipped step): "no dense term".  The library keeps the pair of every env's
+ * current grid in a cache of its own and recomputes it only when a step stored the grid plane. */
 int arcle_set_dense_output(arcle_env* env, int32_t* dense_out);
+/* For code that edits state planes BEHIND the library's back (plain copies into the buffers of arcle_get_buffers, host-applied
+ * op slots): forget everything derived from the state (the dense-pair cache).  The library's own writers (reset kernels,
+ * arcle_set_state_rows, auto-reset) do this themselves.  Asynchronous on `stream`. */
+int arcle_invalidate(arcle_env* env, void* stream);
 
 /* Installs the output of ARCLE_STEP_TRUNCATE: trunc_out device uint8[n_envs], step_limit = max_episode_steps.
  * trunc_out == NULL removes it. */

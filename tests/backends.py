@@ -139,7 +139,7 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p), ("aug_k", ctypes.c_void_p),
                 ("aug_perm", ctypes.c_void_p), ("n_problems", ctypes.c_int32),
                 ("wpw", ctypes.c_int32), ("flat_tail", ctypes.c_int32), ("rows_in", ctypes.c_void_p),
-                ("rows_in_stride", ctypes.c_int32), ("n_resident", ctypes.c_int32)]
+                ("rows_in_stride", ctypes.c_int32), ("n_resident", ctypes.c_int32), ("dense_cache", ctypes.c_void_p)]
 
 
 _emu = None
@@ -204,6 +204,7 @@ class EmuBackend:
 
     def reset(self, mask=None):
         p = self._params()
+        self._extras(p)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         p.rmask = None if m is None else m.ctypes.data
         rc = emu_lib().emu_run(1, ctypes.byref(p))
@@ -251,7 +252,7 @@ class EmuBackend:
     # ---- round-2 features (same kernels, the emulator runs them lock-step) ------------------------------
     def _extras(self, p):
         """Optional per-step outputs / sampler state shared by the step and reset kernels."""
-        for name in ("trunc", "dense", "episode", "cur_task"):
+        for name in ("trunc", "dense", "dense_cache", "episode", "cur_task"):
             arr = getattr(self, name, None)
             if arr is not None:
                 setattr(p, name, arr.ctypes.data)
@@ -306,6 +307,7 @@ class EmuBackend:
 
     def set_state_rows(self, rows, mask=None):
         p = self._params()
+        self._extras(p)
         rows = np.ascontiguousarray(rows, np.int8)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         p.rows_in, p.rows_in_stride = rows.ctypes.data, rows.shape[1]
@@ -340,6 +342,7 @@ class EmuBackend:
 
     def set_dense_output(self):
         self.dense = np.zeros((self.N, 2), np.int32)
+        self.dense_cache = np.zeros((self.N, 2), np.int32)  # (the library owns this one: arcle_set_dense_output allocates it)
 
     def set_sampler(self, pair_off, pair_cnt, seed, env_base=0, aug_flags=0):
         self._sampler = (np.ascontiguousarray(pair_off, np.int32), np.ascontiguousarray(pair_cnt, np.int32), int(seed), int(env_base), int(aug_flags))

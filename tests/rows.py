@@ -8,7 +8,7 @@ import numpy as np
 import backends as B
 from oracle import oracle as O
 
-STEP_AUTORESET, STEP_ELIDE, STEP_TRUNCATE, STEP_DENSE, STEP_ROS, STEP_FLAT_OBS = 1, 2, 4, 16, 64, 128
+STEP_AUTORESET, STEP_ELIDE, STEP_TRUNCATE, STEP_DENSE, STEP_ROS, STEP_FLAT_OBS, STEP_ROWS_INC = 1, 2, 4, 16, 64, 128, 512
 
 
 def _tasks(rng, N, H, W, same_answer=0.5):
@@ -279,5 +279,85 @@ def dense_on_autoreset(cls):
         ended = t2.astype(bool)
         be.status(), orc.status()
         if len(errs) > 10:
+            break
+    return errs
+
+
+def incremental_rows(cls):
+    """ARCLE_STEP_ROWS_INCREMENTAL: rows kept across steps (only the segments of stored planes rewritten) stay byte-identical to the
+    stand-alone writer's rows of the same state — full and FilterO2ARC layouts, with auto-reset and the zero-fill elision on."""
+    errs = []
+    for filtered in (False, True):
+        for H, W, flags in ((30, 30, STEP_AUTORESET | STEP_ELIDE), (12, 12, 0), (7, 12, STEP_AUTORESET)):
+            N = 8
+            rng = np.random.default_rng(H + W + filtered)
+            ops = O.o2arc_ops()
+            be = cls(N, H, W, 2, "o2arc", ops)
+            be.set_tasks(*_tasks(rng, N, H, W, same_answer=0.8))
+            be.reset()
+            be.set_flat_output(filtered)
+            be.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 32, np.int32), flags | STEP_FLAT_OBS)  # one full write
+            for s in range(40):
+                ing, pay, op = _random_actions(rng, N, H, W, len(ops))
+                op[rng.random(N) < 0.2] = 34
+                be.step(ing, pay, op, flags | STEP_FLAT_OBS | STEP_ROWS_INC)
+                if not np.array_equal(be.fused_flat(), be.flat_obs(filtered)):
+                    bad = np.nonzero((be.fused_flat() != be.flat_obs(filtered)).any(1))[0]
+                    errs.append(f"{H}x{W} filtered={filtered} step {s}: incremental rows differ for envs {bad.tolist()} (ops {op[bad].tolist()})")
+                    break
+            be.status()
+    return errs
+
+
+def dense_cache(cls):
+    """The dense pair is recomputed only when a step stored the grid; the cached pairs equal a recomputation from the state after
+    EVERY step — incl. steps that leave the grid alone, resets through every path, and state ingest."""
+    errs = []
+    N, H, W = 12, 10, 10
+    rng = np.random.default_rng(11)
+    ops = O.o2arc_ops()
+    be, orc = cls(N, H, W, 2, "o2arc", ops), B.OracleBackend(N, H, W, 2, "o2arc", ops)
+    tasks = _tasks(rng, N, H, W, same_answer=0.6)
+    for b in (be, orc):
+        b.set_tasks(*tasks)
+        b.reset()
+    be.set_dense_output()
+
+    def expect(n):
+        gh, ah = orc.get("grid_dim").astype(int)[n], orc.get("answer_dim").astype(int)[n]
+        g, a = orc.get("grid")[n], orc.get("answer")[n]
+        mh, mw = min(gh[0], ah[0]), min(gh[1], ah[1])
+        correct = int((g[:mh, :mw] == a[:mh, :mw]).sum())
+        G, A = gh[0] * gh[1], ah[0] * ah[1]
+        total = mh * mw + (abs(A - G) if (gh[0] <= ah[0]) == (gh[1] <= ah[1]) else abs(gh[0] - ah[0]) * mw + abs(gh[1] - ah[1]) * mh)
+        return (correct, total)
+    for s in range(60):
+        ing, pay, op = _random_actions(rng, N, H, W, len(ops))
+        quiet = rng.random(N) < 0.5
+        op[quiet] = rng.choice([10, 28, 29, 20], quiet.sum())  # mostly grid-preserving: failed fills, copies, no-op moves
+        if s % 13 == 5:  # a reset from outside, masked
+            m = (rng.random(N) < 0.4).astype(np.uint8)
+            be.reset(m)
+            orc.reset(m)
+        if s % 17 == 9:  # state ingest: all envs back to an earlier state
+            rows = B.state_rows(orc)
+            orc.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 3, np.int32))
+            be.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 3, np.int32), STEP_DENSE)
+            be.set_state_rows(rows)
+            lay, off = B.row_layout("o2arc", H * W), 0
+            for f, n in lay:
+                dst = orc.env.planes[f] if f in orc.env.planes else orc.env.field(f)
+                dst[:] = rows[:, off:off + n].reshape(dst.shape)
+                off += n
+        r1, t1 = be.step(ing, pay, op, STEP_DENSE)
+        r2, t2 = orc.step(ing, pay, op)
+        if not (np.array_equal(r1, r2) and np.array_equal(t1, t2)):
+            errs.append(f"step {s}: reward / terminated differ")
+        d = be.dense
+        for n in range(N):
+            if tuple(d[n]) != expect(n):
+                errs.append(f"step {s} env {n} op {op[n]}: dense {tuple(d[n])} != {expect(n)}")
+        be.status(), orc.status()
+        if len(errs) > 8:
             break
     return errs
