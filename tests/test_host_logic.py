@@ -150,3 +150,60 @@ def test_lazy_info_dict_semantics():
         raise AssertionError("KeyError expected")
     except KeyError:
         pass
+
+
+def test_table_probe_falls_back_to_constructing_the_class():
+    """ARCVecEnv asks the env CLASS for its op table: create_operations() on a bare instance first (agents/env.py:23-28 style overrides
+    need nothing else), the real constructor when the override reads instance state set up in __init__."""
+    from arcle_amd.envs.vec import _table_of
+    from arcle_amd.loaders import SyntheticLoader
+
+    class NeedsInit(O2ARCv2Env):
+        def __init__(self, *a, **k):
+            self.extra_colour = 7          # (set BEFORE the base constructor builds the table)
+            super().__init__(*a, **k)
+
+        def create_operations(self):
+            ops = super().create_operations()
+            ops[0] = A.reset_sel(A.gen_color(self.extra_colour))
+            return ops
+    kw = dict(data_loader=SyntheticLoader(n_tasks=2, seed=0, max_size=(5, 5)), max_grid_size=(5, 5), colors=10, max_trial=-1, device=None)
+    table = _table_of(NeedsInit, **kw)
+    assert len(table) == 35 and table[0].arg == 7 and table[0].__name__ == "Color7"
+    assert [op.desc for op in _table_of(O2ARCv2Env, **kw)] == [op.desc for op in O2ARCv2Env.default_operations()]
+
+
+def test_lazy_info_dict_semantics():
+    from arcle_amd.envs.vec import _LazyInfo
+    calls = []
+    d = _LazyInfo({"a": 1})
+    d.lazy("b", lambda: calls.append("b") or 2)
+    d.lazy("c", lambda: calls.append("c") or 3)
+    assert "b" in d and len(d) == 3 and calls == []
+    c = d.copy()
+    assert c == {"a": 1, "b": 2, "c": 3} and type(c) is dict and sorted(calls) == ["b", "c"]
+    d2 = _LazyInfo({})
+    d2.lazy("x", lambda: 5)
+    assert d2.pop("x") == 5 and "x" not in d2 and d2.pop("x", None) is None
+    d3 = _LazyInfo({})
+    d3.lazy("y", lambda: 9)
+    assert d3.setdefault("y", 0) == 9 and d3.setdefault("z", 4) == 4
+
+
+def test_dense_reward_formula_and_no_action_marker():
+    """ARCVecEnv._dense: sparse * 100 - 1 + correct / total (agents/env.py:44-58); the pair (0, 0) — a step that executed no action —
+    is reward 0."""
+    import torch
+    from arcle_amd.envs import ARCVecEnv
+    r = ARCVecEnv._dense(torch.tensor([0, 1, 0, 0]), torch.tensor([[3, 4], [9, 9], [0, 0], [0, 5]]))
+    assert r.dtype == torch.float32 and r.tolist() == [-0.25, 100.0, 0.0, -1.0]
+
+
+def test_augmentation_draw_mirror_matches_the_scalar_mirror():
+    from arcle_amd import sampling as S
+    gids, eps = [0, 5, 123456789, 2**40 + 3], [0, 1, 7, 300]
+    for flags in (0, 1, 2, 3):
+        k, perm = S.draw_aug_batch(99, gids, eps, flags)
+        for i, (g, e) in enumerate(zip(gids, eps)):
+            _, _, kk, pp = S.draw_task(99, g, e, [2, 3, 4], flags)
+            assert kk == int(k[i]) and pp == perm[i].tolist()

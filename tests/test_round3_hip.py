@@ -436,3 +436,36 @@ def test_kernel_counted_bytes():
     b.step_bbox(bb, op, b.elide_flag)  # the same with the redundant zero-fill elided: one plane store less is issued
     alg2, issued2, _ = b.accounting_ex(clear=True)
     assert alg2 == alg and issued2 == issued - N * 1024
+
+
+def test_host_slot_is_not_applied_to_envs_the_kernel_auto_reset():
+    """with autoreset, the action of an env whose episode had ended is not executed (the launch re-initialises it) — a
+    host-applied table slot must not touch that env either; for the others the callable's effect on `terminated` is reported."""
+    import torch
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+
+    def paint(state, action):
+        state["grid"][0, 0] = 7
+        state["terminated"][0] = 1
+
+    class Custom(O2ARCv2Env):
+        def create_operations(self):
+            ops = super().create_operations()
+            ops[5] = paint
+            return ops
+    N = 8
+    ld = SyntheticLoader(n_tasks=4, seed=2, max_size=(12, 12), min_size=(3, 3), p_same=1.0)
+    v = ARCVecEnv(Custom, N, ld, max_grid_size=(12, 12), seed=1, autoreset=True)
+    obs, info = v.reset()
+    zeros = torch.zeros((N, 4), dtype=torch.int32, device="cuda")
+    submit = torch.tensor([34, 34, 34, 34, 0, 0, 0, 0], dtype=torch.int32, device="cuda")
+    obs, r, t, tr, info = v.step_bbox(zeros, submit)          # answer == input: envs 0-3 terminate with reward 1
+    assert t.tolist() == [True] * 4 + [False] * 4 and r.tolist() == [1] * 4 + [0] * 4
+    first = obs["input"][:, 0, 0].clone()
+    obs, r, t, tr, info = v.step_bbox(zeros, torch.full((N,), 5, dtype=torch.int32, device="cuda"))
+    g00 = obs["grid"][:, 0, 0]
+    assert torch.equal(g00[:4], first[:4]), "the callable ran on envs that were auto-reset in this step"
+    assert g00[4:].tolist() == [7] * 4 and t.tolist() == [False] * 4 + [True] * 4
+    assert info["steps"].tolist() == [0] * 4 + [2] * 4
+    v.check_errors()
