@@ -21,12 +21,20 @@ Timing: after an untimed clock ramp and W warm-up steps, the region "barrier + s
 + barrier" is run R times (R reported as `timing.regions`); `value`/`ms_per_step` are the MEDIAN region (max over
 ranks per region).  A region that is one hipGraph replay is clocked by HIP events recorded on the launch stream between the two
 synchronisations (device time of exactly the K steps; the host-clock figure of the same regions is `timing.host_region_ms`);
-eagerly launched regions (multi-rank c4) are clocked by the host.  Besides the contract fields the line carries
-  roofline      achieved ALGORITHMIC HBM bytes/s of the step kernel: bytes from the kernel's own per-env accounting
-                (planes semantically read+written by the executed op/mode + 56 B) divided by the kernel's
-                average launch duration, measured with a HIP-event pair recorded on the launch stream around the K
-                back-to-back launches of a timed region; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
-                of this same command (profiles/pmc_latest.json — a recorded figure, labelled as such);
+eagerly launched regions are clocked by the host.  (The K launches are captured once: every region replays the same K action
+batches on an evolving state.)  Besides the contract fields the line carries
+  roofline      of the step kernel, all bytes counted BY THE KERNEL in this run (accounting instantiation, region 0 replayed once,
+                untimed): `achieved` / `frac` = algorithmic HBM bytes (planes semantically read + written by the
+                executed op / mode + 56 B) / the average launch duration (HIP-event pair on the launch stream around the K
+                back-to-back launches) / 8 TB/s; `traffic` / `frac_by_traffic` = the bytes of every global-memory access the kernel
+                actually issued (elided writes excluded, row padding and re-reads included); `note_cache` = state bytes vs the 256 MiB
+                Infinity Cache; `pmc_crosscheck` = the FETCH_SIZE / WRITE_SIZE figure recorded under profiles/ (calibrated there);
+  extras        (N = 1, c3) the paths users call, each with `us_per_step_batch` and its own kernel-counted roofline block: vec_api
+                (ARCVecEnv: Python loop / step_many / capture + replay), research_env (the paper's training step, rows rewritten in
+                full / incrementally), mask_ingress (int8 / bit-packed masks), host_actions (records of a host-resident policy:
+                zero-copy / one copy node / two), single_env (Gym class: step and transition latency), transition_rows (stateless
+                batched transition), rollout, batch_sweep (32 768 and 131 072 envs: the out-of-cache fraction), other_configs
+                (c2 / c4 on one rank / c5 with their real bounds);
   cpu_baseline  (N=1) on this box's host, bounded samples of the same workload: the oracle's C restatement (1 thread /
                 all cores) and `numpy_step` = a plain-NumPy one-env-at-a-time step() loop with the reference's call
                 structure (oracle/numpy_env.py), 1 process / all cores.
@@ -743,26 +751,50 @@ def main():
     optr = [op[i].data_ptr() for i in range(S)]
 
     gather = None
+    side = None
     if a.config == "c4":  # the learner-side gather: ONE all-gather of the packed 912-byte record per env and step
-        # the step kernel writes the packed rows itself (STEP_PACK_OBS, fused epilogue): no packing launch
-        packed = batch.set_packed_output()
+        # The step kernel writes the packed rows itself (STEP_PACK_OBS, fused epilogue): no packing launch.  The rows are double-
+        # buffered and the collective runs on a SIDE stream behind an event: step i+1 (writing the other buffer) overlaps the
+        # all-gather of step i; a buffer is only rewritten once the gather that read it two steps ago has finished.  The sustained
+        # rate is then max(step, collective) per step instead of their sum.
+        R_ = batch.packed_obs_size()
+        packed2 = [torch.zeros((n, R_), dtype=torch.uint8, device=dev) for _ in range(2)]
+        batch.set_packed_output(packed2[0])
         FL |= STEP_PACK_OBS
-        full = torch.empty((world * n, packed.shape[1]), dtype=torch.uint8, device=dev)
-        host_full = torch.empty(full.shape, dtype=torch.uint8) if shared_gpu else None
+        full2 = [torch.empty((world * n, R_), dtype=torch.uint8, device=dev) for _ in range(2)] if dist is not None else None
+        host_full = torch.empty((world * n, R_), dtype=torch.uint8) if shared_gpu else None
+        side = torch.cuda.Stream(dev) if dist is not None and not shared_gpu else None
+        done = [None, None]
 
-        def gather():
+        def gather(slot, cur):
             if dist is None:
-                return  # one rank: the packed rows ARE the gathered tensor
+                return  # one rank, no process group: the packed rows ARE the gathered tensor
             if shared_gpu:
-                dist.all_gather_into_tensor(host_full, packed.cpu())
-            else:
-                dist.all_gather_into_tensor(full, packed)
+                dist.all_gather_into_tensor(host_full, packed2[slot].cpu())
+                return
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                dist.all_gather_into_tensor(full2[slot], packed2[slot])
+                done[slot] = torch.cuda.Event()
+                done[slot].record(side)
 
-    def step(i):
+    def step(i, sh_=None, cur=None):
         j = i % S
-        batch.step_bbox_ptr(bptr[j], optr[j], FL, sh)
+        cur = cur if cur is not None else stream
         if gather is not None:
-            gather()
+            slot = i & 1
+            if done[slot] is not None:  # the gather that last read this buffer
+                cur.wait_event(done[slot])
+            batch.set_packed_output(packed2[slot])  # (launch parameters are taken by value: earlier launches keep their buffer)
+        batch.step_bbox_ptr(bptr[j], optr[j], FL, sh if sh_ is None else sh_)
+        if gather is not None:
+            gather(i & 1, cur)
+
+    def join_side(cur=None):
+        if side is not None:
+            (cur if cur is not None else stream).wait_stream(side)
 
     def barrier():
         if dist is not None:
@@ -776,6 +808,7 @@ def main():
     # ---- untimed: W warm-up steps ---------------------------------------------------------------------------------
     for i in range(Wm):
         step(i)
+    join_side()
     torch.cuda.synchronize(dev)
     # snapshot of the state region 0 starts from (replayed below for the byte accounting)
     snap = {k: v.clone() for k, v in batch.planes.items()}
@@ -785,16 +818,25 @@ def main():
     # action batch) and replayed per region: a launch-bound inner loop belongs in a graph, and the host then issues one
     # call per region instead of K.  (With more than one rank c4 keeps eager launches: its collective is not captured.)
     graph = None
-    if not a.no_graph and (gather is None or dist is None):
+    if not a.no_graph and not (gather is not None and shared_gpu):
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev)):
-                csh = torch.cuda.current_stream(dev).cuda_stream
-                for i in range(Wm, Wm + K):
-                    batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, csh)
+            cap = torch.cuda.Stream(dev)
+            cap.wait_stream(stream)
+            if gather is not None:
+                done[0] = done[1] = None
+            with torch.cuda.graph(graph, stream=cap):
+                cs = torch.cuda.current_stream(dev)
+                for i in range(Wm, Wm + K):  # (c4 with a process group: the RCCL collectives are captured as well, on the forked side stream)
+                    step(i, cs.cuda_stream, cs)
+                join_side(cs)
+            if gather is not None:
+                done[0] = done[1] = None
         except Exception as exc:  # capture unsupported: eager launches
             print(f"bench: hipGraph capture failed ({exc}); eager launches", file=sys.stderr)
             graph = None
+            if gather is not None:
+                done[0] = done[1] = None
 
     def region(r):
         if graph is not None:
@@ -802,6 +844,7 @@ def main():
         else:
             for i in range(Wm + r * K, Wm + (r + 1) * K):
                 step(i)
+            join_side()
 
     # untimed clock ramp (the chip idles at low clocks before the first launch): the region's own launches, ~80 ms of them
     t_ramp, r = time.perf_counter(), 0
@@ -857,6 +900,9 @@ def main():
         batch.rec.copy_(snap_rec)
         batch.cnt.copy_(snap_cnt)
 
+        if gather is not None:
+            batch.set_packed_output(packed2[0])
+
         def replay_region0(sh_):
             for i in range(Wm, Wm + K):
                 batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, sh_)
@@ -886,7 +932,7 @@ def main():
             "config": {"workload": cfg["name"], "id": a.config, "envs_per_gpu": n, "global_envs": n * world,
                        "grid": [H, W], "ingress": "bbox",
                        "parallelism": f"env-shard x{world} (no data-path collective)" if gather is None
-                       else (f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL'})"
+                       else (f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL on a side stream, double-buffered rows, overlapping the next step'})"
                              if dist is not None else "one rank: step with the fused packed-row epilogue, nothing to gather")},
             "timing": {"regions": R, "stat": "median region, max over ranks per region",
                        "clock": "HIP events on the launch stream, recorded between the region's two synchronisations" if device_clock else "host perf_counter between the region's two synchronisations",
