@@ -40,6 +40,9 @@ ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION, ST_AUG_DOMAIN = 1, 2
 ROW_TAIL = 16  # bytes of the optional step-output tail of a flat row (arcle_set_flat_output_ex)
 
 
+_hip = None
+
+
 def _ptr(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -100,6 +103,17 @@ class EnvBatch:
             return torch._C._cuda_getCurrentRawStream(self.device.index)
         except AttributeError:  # pragma: no cover - older / newer torch without the private accessor
             return torch.cuda.current_stream(self.device).cuda_stream
+
+    def sync(self, stream=None):
+        """Blocks until `stream` (default: torch's current stream on this device) has drained — hipStreamSynchronize called directly
+        (the latency path of the single-env class; saves the Python-side bookkeeping of torch's Stream objects)."""
+        global _hip
+        if _hip is None:
+            _hip = ctypes.CDLL("libamdhip64.so")
+            _hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        rc = _hip.hipStreamSynchronize(self._stream() if stream is None else stream)
+        if rc != 0:
+            raise ArcleHipError(f"hipStreamSynchronize failed ({rc})")
 
     def plane(self, name):
         """Zero-copy [N,H,W] int8 view of a state plane (row stride PS)."""

@@ -93,18 +93,29 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         lay += [(("terminated",), 1), (("trials_remain",), 1)]
         return lay
 
+    def _row_plan(self):
+        if getattr(self, "_plan", None) is None:
+            P, off, plan = self.H * self.W, 0, []
+            for path, n in self._flat_layout():
+                plan.append((path, off, off + n, (self.H, self.W) if n == P else None))
+                off += n
+            self._plan, self._row_len = plan, off
+        return self._plan
+
     def _state_from_row(self, row):
-        """The reference's obs dict (fresh numpy int8 arrays) from one flattened row (numpy int8 [L])."""
-        P, st, off = self.H * self.W, {}, 0
-        for path, n in self._flat_layout():
-            v = row[off:off + n].copy()
-            off += n
-            if n == P:
-                v = v.reshape(self.H, self.W)
-            d = st
-            for k in path[:-1]:
-                d = d.setdefault(k, {})
-            d[path[-1]] = v
+        """The reference's obs dict (fresh numpy int8 arrays, independent of the staging buffer) from one flattened row: ONE copy of
+        the row, every key a view into that copy."""
+        plan = self._row_plan()
+        buf = row[:self._row_len].copy()
+        st = {}
+        for path, lo, hi, shape in plan:
+            v = buf[lo:hi]
+            if shape is not None:
+                v.shape = shape
+            if len(path) == 1:
+                st[path[0]] = v
+            else:
+                st.setdefault(path[0], {})[path[1]] = v
         return st
 
     def _fetch_state(self, b):
@@ -112,7 +123,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         io = self._io()
         buf = b._flat_buf
         b._check(b.L.arcle_flatten_obs(b._h, buf.data_ptr(), buf.shape[1], 0, b._stream()), "arcle_flatten_obs")
-        torch.cuda.current_stream(b.device).synchronize()
+        b.sync()
         return self._state_from_row(io["row"])
 
     def _row_from_state(self, state, out):
@@ -247,7 +258,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         st = b._stream()
         b._check(b.L.arcle_step_mask(b._h, io["sel_ptr"], io["op_ptr"], b._reward_ptr, b._term_ptr,
                                      self._step_flags() | STEP_FLAT_OBS, st), "arcle_step_mask")
-        torch.cuda.current_stream(b.device).synchronize()  # the one synchronisation of the step: row + tail are on the host now
+        b.sync(st)  # the one synchronisation of the step: row + tail are on the host now
         tail = io["tail"]
         status = (int(tail[3]) >> 16) & 0xFF
         if status:
@@ -323,7 +334,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         b._check(b.L.arcle_transition_rows(b._h, 1, t["rin"].data_ptr(), t["stride"], 0, ap, ap + t["op_off"], None,
                                            t["rout"].data_ptr(), t["stride"], 1, b._reward_ptr, b._term_ptr, self._step_flags(),
                                            b._stream()), "arcle_transition_rows")
-        torch.cuda.current_stream(b.device).synchronize()
+        b.sync()
         status = (int(t["tail"][3]) >> 16) & 0xFF
         if status:
             b.status()

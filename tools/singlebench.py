@@ -22,3 +22,11 @@ for a in acts:
     obs, r, term, trunc, info = env.step(a)
 dt = time.perf_counter() - t0
 print(f"O2ARCv2Env.step (one env, state dict on the host): {dt / len(acts) * 1e6:.1f} us per step = {len(acts) / dt:.0f} steps/s")
+import copy
+st = copy.deepcopy(obs)
+for a in acts[:20]:
+    env.transition(st, a)
+t0 = time.perf_counter()
+for a in acts[:200]:
+    env.transition(st, a)
+print(f"O2ARCv2Env.transition(state, action): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call")
