@@ -241,8 +241,10 @@ class EnvBatch:
     def _step(self, fn, payload, op, flags):
         if op.dtype != torch.int32 or not op.is_contiguous() or op.device != self.device:
             op = op.to(device=self.device, dtype=torch.int32).contiguous()
-        self._check(fn(self._h, _ptr(payload), _ptr(op), _ptr(self.reward), _ptr(self.term), int(flags), self._stream()),
-                    "arcle_step")
+        # (plain ints for the pointer arguments: ctypes converts them without a c_void_p object per argument)
+        rc = fn(self._h, payload.data_ptr(), op.data_ptr(), self._reward_ptr, self._term_ptr, flags, self._stream())
+        if rc != 0:
+            self._check(rc, "arcle_step")
         return self.reward, self.term
 
     def step_bbox(self, bbox, op, flags=0):

@@ -84,6 +84,12 @@ class _LazyInfo(dict):
     def __len__(self):
         return dict.__len__(self) + len(self._thunks)
 
+    def rearm(self, thunks):
+        """Makes the given entries pending again (their cached values are dropped): the same `info` object serves every step."""
+        for k in thunks:
+            dict.pop(self, k, None)
+        self._thunks.update(thunks)
+
     def copy(self):
         self._force()
         return dict(self)
@@ -199,18 +205,21 @@ class ARCVecEnv:
         return obs
 
     def _info(self):
-        """`info` of reset / step: zero-copy device views; the two entries that need a gather through the task table
-        (`task_index`, `subprob_index`) are produced when first read — a step that nobody asks for them launches nothing extra."""
+        """`info` of reset / step: zero-copy device views of live buffers (like `obs`, the next step updates them in place — ONE dict
+        object serves every step); the two entries that need a gather through the task table (`task_index`, `subprob_index`) are
+        produced when first read after a step — a step that nobody asks for them launches nothing extra."""
         b = self.batch
-        if getattr(self, "_info_views", None) is None:  # the views themselves never change: built once
-            self._info_views = {"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
-                                "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1]}
-        info = _LazyInfo(self._info_views)
-        if hasattr(b, "cur_task"):  # device tensors: which task-table entry / problem / pair every env runs right now
+        info = getattr(self, "_info_obj", None)
+        if info is None:  # the views themselves never change: built once
+            info = self._info_obj = _LazyInfo({"input": b.plane("input"), "input_dim": b.field("input_dim"), "answer": b.plane("answer"),
+                                               "answer_dim": b.field("answer_dim"), "steps": b.cnt[:, 0], "submit_count": b.cnt[:, 1]})
+            self._info_thunks = None
+        if self._info_thunks is None and hasattr(b, "cur_task"):  # which task-table entry / problem / pair every env runs right now
             info["table_index"] = b.cur_task
             entry = lambda: b.cur_task.long().clamp_min(0)  # noqa: E731
-            info.lazy("task_index", lambda: self._entry_problem[entry()])
-            info.lazy("subprob_index", lambda: self._entry_sub[entry()])
+            self._info_thunks = {"task_index": lambda: self._entry_problem[entry()], "subprob_index": lambda: self._entry_sub[entry()]}
+        if self._info_thunks is not None:
+            info.rearm(self._info_thunks)
         return info
 
     # ---- task table: Loader.parse's output, uploaded once -----------------------------------------------
