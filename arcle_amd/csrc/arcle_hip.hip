@@ -165,8 +165,8 @@ typedef arcle::BlockLDS<WAVES_PER_WG> BlockLDS;
 // vb = (b&7)*(nb/8) + (b>>3) gives each XCD one contiguous range of waves (affinity only)
 // (waves_per_wg comes from the caller, not from blockDim: the workgroup size sits in the hidden kernel arguments as a 16-bit
 // field, which costs a VECTOR load and its latency before the wave can even compute which env it owns)
-__device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, uint32_t nb8 = gridDim.x >> 3) {
-  const uint32_t b = blockIdx.x;  // the grid is a multiple of 8 workgroups; nb8 = gridDim.x / 8
+__device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, uint32_t nb8 = gridDim.x >> 3, uint32_t boff = 0) {
+  const uint32_t b = blockIdx.x - boff;  // the grid is a multiple of 8 workgroups; nb8 = (gridDim.x - boff) / 8
   const uint32_t vb = (b & 7u) * nb8 + (b >> 3);
   return __builtin_amdgcn_readfirstlane((int)(vb * (uint32_t)waves_per_wg + (threadIdx.x >> 6)));
 }
@@ -196,11 +196,32 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   }
   // (leading scalar arguments = what a wave needs to find and request its env's inputs; built with -amdgpu-kernarg-preload-count they
   // are in SGPRs at wave start.  They repeat p.rec / p.cnt / p.op / p.sel / p.n_envs / p.wpw.)
+  // (at the FRONT of the grid: the copy waves start first and their PCIe round trips run under the whole launch — 6.9 us per step at
+  // 8192 envs; placed at the end of the grid they start last and the launch waits for them: 8.1 us, profiles/round3_experiments.txt)
+  const bool pf_role = ING == arcle::INGRESS_BBOX5_PF && blockIdx.x < ARCLE_PF_BLOCKS;
+  const uint32_t pf_first = 0, pf_off = ING == arcle::INGRESS_BBOX5_PF ? ARCLE_PF_BLOCKS : 0u;
+  if (pf_role) {
+    // The first workgroups of the launch are a copy engine: they move the NEXT step's action records from pinned host memory into the
+    // device staging buffer that step will read (arcle_step_many over host-resident records).  The PCIe round trips of these few
+    // waves run under the whole launch; the env waves of the next launch then find their records in device memory.
+    const uint32_t n16 = ((uint32_t)n_envs * 20u) >> 4;  // whole 16-byte chunks (n_envs % 4 == 0, checked by the launcher)
+    const uint32_t tid = (blockIdx.x - pf_first) * blockDim.x + threadIdx.x, nthr = ARCLE_PF_BLOCKS * blockDim.x;
+    for (uint32_t i = tid; i < n16; i += 4u * nthr) {
+      xl::U4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (i + (uint32_t)k * nthr < n16) v[k] = xl::load16(reinterpret_cast<const int8_t*>(pa.next_sel), 16u * (i + (uint32_t)k * nthr));
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (i + (uint32_t)k * nthr < n16) *reinterpret_cast<ARCLE_AS_GLOBAL xl::U4*>((uintptr_t)pa.stage_out + 16u * (i + (uint32_t)k * nthr)) = v[k];
+    }
+    return;
+  }
   __shared__ BlockLDS lds;
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_entry = xl::clock();
 #endif
-  const int wv = wave_of_launch(wpw, nb8);
+  const int wv = wave_of_launch(wpw, nb8, pf_off);
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = valid ? wv : 0;
   arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0);
@@ -324,6 +345,9 @@ struct arcle_env {
   int flat_tail;
   uint32_t* retired_ops[64];  // op tables replaced by arcle_set_op_table: launches in flight (and captured graphs) may still read them
   int n_retired;
+  int32_t* d_stage;           // int32 [2][n_envs][5]: staging of host-resident action records (arcle_step_many), allocated on first use
+  const int32_t* pf_next;     // set by arcle_step_many around a launch: the next step's host records / the staging buffer to fill
+  int32_t* pf_stage;
   int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
   uint32_t* d_acct;
   uint64_t acct_steps;
@@ -452,6 +476,7 @@ extern "C" int arcle_destroy(arcle_env* e) {
   if (e->d_ops) (void)hipFree(e->d_ops);
   for (int i = 0; i < e->n_retired; i++) (void)hipFree(e->retired_ops[i]);
   if (e->d_dense_cache) (void)hipFree(e->d_dense_cache);
+  if (e->d_stage) (void)hipFree(e->d_stage);
   if (e->d_acct) (void)hipFree(e->d_acct);
   delete e;
   return ARCLE_OK;
@@ -610,6 +635,14 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
   if constexpr (FW == arcle::FW_FULL) {  // the standard 30 x 30 grid: lean instantiations with the dimensions as compile-time constants
     if (p.H == 30 && p.W == 30 && !acct) {
       if (p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_PACK_FLAGS, 30); return; }
+      if constexpr (ING == arcle::INGRESS_BBOX5) {
+        if (p.flags == (uint32_t)HOT_FLAGS && p.next_sel && p.wpw == WAVES_PER_WG) {  // records prefetched by the launch's front workgroups
+          const dim3 gp(g.x + ARCLE_PF_BLOCKS);
+          hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX5_PF, FW, 0, 0, HOT_FLAGS, 30>), gp, b, 0, st, (const int8_t*)p.rec,
+                             (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
+          return;
+        }
+      }
       if (p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_FLAGS, 30); return; }
       if (research_shape(p)) { LAUNCH_STEP(ING, FW, 0, 1, RESEARCH_FL, 30); return; }
       if (research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) { LAUNCH_STEP(ING, FW, 0, 1, RESEARCH_INC_FL, 30); return; }
@@ -651,6 +684,8 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.flags = flags;
   p.acct = e->d_acct;
   p.rmask = nullptr;
+  p.next_sel = e->pf_next;
+  p.stage_out = e->pf_stage;
   // workgroups of 8 waves while the batch is one occupancy round or two (7.3 vs 7.7 us per launch at 8192 envs), 4 waves in
   // the streaming regime (76-79 vs 85-88 us at 131072 envs): in-box A/B, profiles/round2_experiments.txt
   const int wpw = p.n_envs >= 65536 ? 4 : WAVES_PER_WG;
@@ -724,12 +759,46 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
   if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
   const size_t n = (size_t)e->cfg.n_envs, pb = payload_bytes(e, ingress);
-  for (int32_t t = 0; t < n_steps; t++) {
-    const int rc = launch_step(e, ingress, (const char*)sel + (size_t)t * pb, op ? op + (size_t)t * n : nullptr,
-                               reward ? reward + (size_t)t * n : nullptr, term ? term + (size_t)t * n : nullptr, flags, stream);
-    if (rc != ARCLE_OK) return rc;
+  // Host-resident 5-tuple records (a policy on the CPU): step t reads its records from a device staging buffer that the FRONT
+  // workgroups of launch t-1 filled from pinned host memory while that launch ran; only step 0 reads across PCIe itself.
+  bool prefetch = false;
+  // (only where the lean instantiation that carries the copy workgroups applies: the standard 30 x 30 batch with ARCVecEnv's flags)
+  const bool pf_kernel = width_class(e->base) == arcle::FW_FULL && e->base.H == 30 && e->base.W == 30 && flags == (uint32_t)HOT_FLAGS &&
+                         !e->d_acct && e->cfg.n_envs < 65536;
+  if (pf_kernel && ingress == arcle::INGRESS_BBOX5 && n_steps > 1 && (n & 3) == 0 && sel) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, sel) == hipSuccess && attr.type == hipMemoryTypeHost) prefetch = true;
+    else (void)hipGetLastError();
   }
-  return ARCLE_OK;
+  if (prefetch && !e->d_stage) {
+    // (the staging buffer is allocated by the first such call OUTSIDE a stream capture: allocating would invalidate a capture in
+    // progress — a captured call without it falls back to every wave reading its own record across PCIe)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      prefetch = false;
+    } else {
+      DeviceGuard guard(e->device);
+      if (hipMalloc((void**)&e->d_stage, 2 * n * 20) != hipSuccess) {
+        (void)hipGetLastError();
+        prefetch = false;
+      }
+    }
+  }
+  int rc = ARCLE_OK;
+  for (int32_t t = 0; t < n_steps && rc == ARCLE_OK; t++) {
+    const void* src = (const char*)sel + (size_t)t * pb;
+    if (prefetch) {
+      if (t > 0) src = e->d_stage + (size_t)(t & 1) * n * 5;
+      e->pf_next = t + 1 < n_steps ? (const int32_t*)((const char*)sel + (size_t)(t + 1) * pb) : nullptr;
+      e->pf_stage = e->d_stage + (size_t)((t + 1) & 1) * n * 5;
+    }
+    rc = launch_step(e, ingress, src, op ? op + (size_t)t * n : nullptr, reward ? reward + (size_t)t * n : nullptr,
+                     term ? term + (size_t)t * n : nullptr, flags, stream);
+  }
+  e->pf_next = nullptr;
+  e->pf_stage = nullptr;
+  return rc;
 }
 
 extern "C" int arcle_pack_mask_bits(arcle_env* e, const int8_t* sel, uint8_t* bits, void* stream) {

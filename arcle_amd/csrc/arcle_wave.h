@@ -38,14 +38,17 @@ enum { INGRESS_MASK = 0,    // int8 [N][P] selection masks as given (action['sel
        INGRESS_BBOX = 1,    // int32 [N][4] BBoxWrapper corners (bbox.py:22-30)
        INGRESS_POINT = 2,   // int32 [N][2] PointWrapper cell (bbox.py:43-49)
        INGRESS_BBOX5 = 3,   // int32 [N][5] the BBoxWrapper action as ONE record (x1, y1, x2, y2, operation): selection form = BBOX
-       INGRESS_BITS = 4 };  // uint8 [N][128] bit-packed boolean masks (bit f of the row = cell f truthy; base.py:136 accepts bool)
+       INGRESS_BITS = 4,    // uint8 [N][128] bit-packed boolean masks (bit f of the row = cell f truthy; base.py:136 accepts bool)
+       INGRESS_BBOX5_PF = 5 };  // launcher-internal: BBOX5 read from a device staging buffer, while ARCLE_PF_BLOCKS extra workgroups at the
+                                // front of the grid copy the NEXT step's records (pinned host memory) into the other staging buffer
+#define ARCLE_PF_BLOCKS 8
 #define ARCLE_BITS_STRIDE (ARCLE_MAX_CELLS / 8)
 // launcher-internal bit of a compile-time flag set (FL template parameter): the fused flat rows are the FilterO2ARC subset
 #define ARCLE_STEPX_FLAT_FILTERED 0x10000
 // row strides of the 30 x 30 lean instantiations: 3*900 + 10 and 7*900 + 14, rounded up to 16
 #define ARCLE_ROW30_FILTERED_STRIDE 2720
 #define ARCLE_ROW30_FULL_STRIDE 6320
-ARCLE_HD constexpr bool is_tuple(int ing) { return ing == INGRESS_BBOX || ing == INGRESS_POINT || ing == INGRESS_BBOX5; }
+ARCLE_HD constexpr bool is_tuple(int ing) { return ing == INGRESS_BBOX || ing == INGRESS_POINT || ing == INGRESS_BBOX5 || ing == INGRESS_BBOX5_PF; }
 ARCLE_HD constexpr bool is_cells(int ing) { return ing == INGRESS_MASK || ing == INGRESS_BITS; }
 // FW (instantiation parameter): grid-width class of the launch
 enum { FW_GENERIC = 0,  // any W
@@ -100,6 +103,8 @@ struct StepParams {
   int32_t rows_in_stride;
   int32_t n_resident;      // state-row kernels: envs of the handle (src_env range check); n_envs = rows of the launch
   int32_t* dense_cache;    // library-owned int32 [N][2]: the dense pair of the env's CURRENT grid, (0, 0) = unknown (see step_core)
+  const int32_t* next_sel; // INGRESS_BBOX5_PF: the NEXT step's records (pinned host memory, int32 [N][5]) ...
+  int32_t* stage_out;      // ... and the device staging buffer the front workgroups copy them into while this step runs
 };
 
 // 16 bytes of a plane = 4 VGPRs; a first-class vector value so that it always lives in registers
@@ -284,7 +289,7 @@ struct Wave {
     count = count_;
     issued = 0;
     stored = 0;
-    ingress = ingress_ == INGRESS_BBOX5 ? INGRESS_BBOX : ingress_;  // (the record form only differs in where the kernel loads it from)
+    ingress = (ingress_ == INGRESS_BBOX5 || ingress_ == INGRESS_BBOX5_PF) ? INGRESS_BBOX : ingress_;  // (the record forms only differ in where the kernel loads from)
     fw = fw_;
     resident = resident_;
     dirty = 0;
@@ -1624,9 +1629,9 @@ ARCLE_DEV StepInputs load_inputs(const Wave& w, int env, const int8_t* rec, cons
   // 32-bit unsigned byte offsets: the scalar loads take them as an SGPR offset (no 64-bit address arithmetic per array)
   const uint32_t e = (uint32_t)env;
   in.rec = xl::uload4(at(rec, e * (uint32_t)ARCLE_REC_BYTES));
-  if (ING != INGRESS_BBOX5) in.op = xl::uload1(at(op, e * 4u));
+  if (ING != INGRESS_BBOX5 && ING != INGRESS_BBOX5_PF) in.op = xl::uload1(at(op, e * 4u));
   in.cnt = xl::uload2(at(cnt, e * 8u));
-  if (ING == INGRESS_BBOX5) {  // one 20-byte record per env: the four corners, then the operation (rows are only dword aligned)
+  if (ING == INGRESS_BBOX5 || ING == INGRESS_BBOX5_PF) {  // one 20-byte record per env: the four corners, then the operation (rows are only dword aligned)
     in.payload = xl::uload4(at(sel, e * 20u));
     in.op = xl::uload1(at(sel, e * 20u + 16u));
   } else if (ING == INGRESS_BBOX) {
@@ -1696,7 +1701,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
     if (flags & ARCLE_STEP_TRUNCATE) *at(p.trunc, e) = (uint8_t)truncated;
   }
   if (ACCT) {  // what the wave moved besides planes: record + counters in and out, action in, outputs out
-    const uint32_t act = ING == INGRESS_MASK ? (uint32_t)p.P : ING == INGRESS_BITS ? 2u * 64u : ING == INGRESS_POINT ? 12u : 20u;
+    const uint32_t act = ING == INGRESS_MASK ? (uint32_t)p.P : ING == INGRESS_BITS ? 2u * 64u : ING == INGRESS_POINT ? 12u : 20u;  // (records: 20)
     w.issued += 2u * ARCLE_REC_BYTES + 16u + act + 5u;
     if (flags & ARCLE_STEP_TRUNCATE) { w.issued += 1u; out.bytes += 1u; }
     if (FEAT && (flags & ARCLE_STEP_DENSE)) w.issued += 8u;

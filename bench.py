@@ -484,8 +484,10 @@ def ingress_leg(dev, n, bbox, op, K=64):
 
 def host_actions_leg(dev, n, bbox, op, K=200):
     """PCIe-inclusive rates of a HOST-resident policy (never part of `value`): the action of every env is the BBoxWrapper 5-tuple
-    record (20 B per env, arcle_step_bbox5).  (a) zero-copy: the kernel reads the records straight from pinned host memory; (b) one
-    copy node (pinned host -> device) in front of every step; (c) round 2's form: two arrays, two copy nodes."""
+    record (20 B per env, arcle_step_bbox5).  (a) arcle_step_many over the host array: eight extra workgroups at the front of launch
+    t copy step t+1's records into a device staging buffer while launch t runs; (b) zero-copy: every wave reads its own record
+    straight from pinned host memory; (c) one copy node (pinned host -> device) in front of every step; (d) round 2's form: two
+    arrays, two copy nodes."""
     K = min(K, bbox.shape[0])
     act5 = torch.cat([bbox[:K], op[:K, :, None]], -1).contiguous()
     h5 = act5.cpu().pin_memory()
@@ -511,11 +513,18 @@ def host_actions_leg(dev, n, bbox, op, K=200):
             db.copy_(hb[i], non_blocking=True)
             do.copy_(ho[i], non_blocking=True)
             batch.step_bbox_ptr(db.data_ptr(), do.data_ptr(), FL, sh)
-    for name, fn in (("zero_copy_pinned_records", zero_copy), ("one_copy_node_records", one_copy), ("two_copy_nodes_round2", two_copies)):
+    rw, tm = torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)
+
+    def prefetched(sh):  # ONE library call for the K steps over the host array: the front workgroups of launch t fetch step t+1's records
+        assert L.arcle_step_many(h, 3, K, h5.data_ptr(), None, rw.data_ptr(), tm.data_ptr(), FL, sh) == 0
+    prefetched(torch.cuda.current_stream(dev).cuda_stream)  # (eagerly once: the library allocates its staging buffer outside a capture)
+    torch.cuda.synchronize(dev)
+    for name, fn in (("prefetched_by_the_previous_launch", prefetched), ("zero_copy_pinned_records", zero_copy),
+                     ("one_copy_node_records", one_copy), ("two_copy_nodes_round2", two_copies)):
         sec, _ = graph_time(dev, fn, K)
         out[name] = {"us_per_step_batch": sec * 1e6, "value": n / sec}
     alg, issued, _ = counted_bytes(batch, zero_copy, K, dev)
-    best = min(("zero_copy_pinned_records", "one_copy_node_records"), key=lambda k: out[k]["us_per_step_batch"])
+    best = min(("prefetched_by_the_previous_launch", "zero_copy_pinned_records", "one_copy_node_records"), key=lambda k: out[k]["us_per_step_batch"])
     sec = out[best]["us_per_step_batch"] * 1e-6
     out.update({"mode": f"BBoxWrapper 5-tuple records from pinned host memory ({best})", "value": n / sec, "unit": "env-steps/s",
                 "us_per_step_batch": sec * 1e6, "host_bytes_per_step": int(n * 20),

@@ -261,7 +261,12 @@ int arcle_pack_mask_bits(arcle_env* env, const int8_t* sel, uint8_t* bits, void*
  * holds the actions of the next n steps; every step is a full step(): state observable in between on the stream, all step flags
  * valid).  `ingress`: arcle_ingress; sel: the form's payload [n_steps][n_envs][...]; op int32 [n_steps][n_envs] (NULL for BBOX5);
  * reward int32 [n_steps][n_envs], term uint8 [n_steps][n_envs] out.  Per-handle outputs (truncated, dense, flat / packed rows) hold
- * the LAST step's values afterwards.  Capturable into a hipGraph like the single-step calls (no synchronisation, no allocation). */
+ * the LAST step's values afterwards.  Capturable into a hipGraph like the single-step calls (no synchronisation).
+ * Host-resident actions: with ARCLE_INGRESS_BBOX5 `sel` may be PINNED HOST memory (the records of a policy that runs on the CPU).
+ * For the standard 30 x 30 batch stepped with ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED the library then pipelines the PCIe
+ * traffic: eight extra workgroups at the front of launch t copy step t+1's records into a device staging buffer while launch t
+ * runs, and step t+1 reads them from HBM (only step 0 reads across PCIe itself).  The staging buffer (2 x 20 B per env) is allocated
+ * by the first such call made outside a stream capture. */
 int arcle_step_many(arcle_env* env, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
                     uint8_t* term, uint32_t flags, void* stream);
 

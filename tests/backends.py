@@ -139,7 +139,8 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p), ("aug_k", ctypes.c_void_p),
                 ("aug_perm", ctypes.c_void_p), ("n_problems", ctypes.c_int32),
                 ("wpw", ctypes.c_int32), ("flat_tail", ctypes.c_int32), ("rows_in", ctypes.c_void_p),
-                ("rows_in_stride", ctypes.c_int32), ("n_resident", ctypes.c_int32), ("dense_cache", ctypes.c_void_p)]
+                ("rows_in_stride", ctypes.c_int32), ("n_resident", ctypes.c_int32), ("dense_cache", ctypes.c_void_p),
+                ("next_sel", ctypes.c_void_p), ("stage_out", ctypes.c_void_p)]
 
 
 _emu = None

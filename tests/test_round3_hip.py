@@ -469,3 +469,39 @@ def test_host_slot_is_not_applied_to_envs_the_kernel_auto_reset():
     assert g00[4:].tolist() == [7] * 4 and t.tolist() == [False] * 4 + [True] * 4
     assert info["steps"].tolist() == [0] * 4 + [2] * 4
     v.check_errors()
+
+
+def test_step_many_over_host_resident_records_with_in_launch_prefetch():
+    """arcle_step_many on PINNED HOST 5-tuple records (30 x 30, ARCVecEnv's flags): step t reads what the front workgroups of launch
+    t-1 copied into the device staging buffer — results equal the same steps fed from device memory, also when replayed in a graph."""
+    import torch
+    import bench
+    n, K = 2048, 40
+    bb, op = bench.make_actions(K, n, 77)
+    act5 = torch.from_numpy(np.concatenate([bb, op[..., None]], -1).astype(np.int32))
+    h5, d5 = act5.pin_memory(), act5.cuda()
+    a, b = bench.make_batch(torch.device("cuda:0"), n, seed=5), bench.make_batch(torch.device("cuda:0"), n, seed=5)
+    FL = a.elide_flag | 1
+    ra, ta = a.step_many("bbox5", d5, None, FL)
+    rb, tb = torch.empty_like(ra), torch.empty_like(ta)
+    assert b.L.arcle_step_many(b._h, 3, K, h5.data_ptr(), None, rb.data_ptr(), tb.data_ptr(), FL, b._stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ra, rb) and torch.equal(ta, tb)
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), k
+    assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt) and a.status() == 0 and b.status() == 0
+    # the same inside a hipGraph, replayed twice with the host array rewritten in between
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=st):
+        assert b.L.arcle_step_many(b._h, 3, K, h5.data_ptr(), None, rb.data_ptr(), tb.data_ptr(), FL, torch.cuda.current_stream().cuda_stream) == 0
+    for seed in (78, 79):
+        bb, op = bench.make_actions(K, n, seed)
+        act5 = torch.from_numpy(np.concatenate([bb, op[..., None]], -1).astype(np.int32))
+        torch.cuda.synchronize()
+        h5.copy_(act5)
+        g.replay()
+        ra, ta = a.step_many("bbox5", act5.cuda(), None, FL)
+        torch.cuda.synchronize()
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(a.planes["grid"], b.planes["grid"]) and torch.equal(a.rec, b.rec)
