@@ -361,3 +361,22 @@ def dense_cache(cls):
         if len(errs) > 8:
             break
     return errs
+
+
+def partial_store_invariants(cls):
+    """The invariant ARCLE_STEP_ELIDE_SELECTED rests on (an inactive env holds an all-zero `selected` plane) under stress: tables with
+    Rotate 180 and the Flip D0 / D1 quirk (tile transposed, object_dim not), object ops dominating, objects walked off the grid (int8
+    wrap of object_pos), every ingress form, auto-reset — every plane compared with the oracle after every step.  (Written for an
+    experiment that also limited the stores of `selected` / `object` / `object_sel` to the rows that can differ — 22 % fewer bytes
+    issued, but slower: profiles/round3_experiments.txt — and kept: it catches a wrong row bound within a few steps.)"""
+    errs = []
+    ops = O.o2arc_ops()
+    ops[24] = O.desc(O.OP_ROTATE, 2)
+    ops[26] = O.desc(O.OP_FLIP, 2)   # D0
+    ops[27] = O.desc(O.OP_FLIP, 3)   # D1
+    heavy = [1] * 20 + [6] * 8 + [2] * 7
+    for (H, W), seed in (((30, 30), 1), ((16, 16), 2), ((20, 30), 3), ((32, 32), 4)):
+        for flags in (STEP_ELIDE, STEP_ELIDE | STEP_AUTORESET):
+            errs += B.random_trace_compare(cls, "o2arc", ops, H, W, N=6, S=70, seed=seed + 10 * flags, max_trial=2, flags=flags, op_weights=heavy)
+    errs += B.random_trace_compare(cls, "o2arc", O.o2arc_ops(), 30, 30, N=6, S=120, seed=99, flags=STEP_ELIDE, op_weights=[1] * 20 + [12] * 4 + [2] * 4 + [1] * 7)
+    return errs

@@ -15,7 +15,7 @@ def test_emulated_kernel_feature(check):
 
 
 @pytest.mark.parametrize("check", [R.new_ingress_forms, R.mask_bits_packer, R.state_rows_roundtrip, R.transition_rows, R.flat_tail,
-                                   R.dense_on_autoreset, R.incremental_rows, R.dense_cache], ids=lambda f: f.__name__)
+                                   R.dense_on_autoreset, R.incremental_rows, R.dense_cache, R.partial_store_invariants], ids=lambda f: f.__name__)
 def test_emulated_round3_boundary(check):
     """bbox5 / bit-packed ingress, state rows in, stateless batched transition, row tail, dense on auto-reset steps — the kernel
     bodies run lock-step on the CPU against the oracle."""

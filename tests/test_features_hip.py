@@ -33,7 +33,7 @@ def test_hip_feature(check):
 
 
 @pytest.mark.parametrize("check", [R.new_ingress_forms, R.mask_bits_packer, R.state_rows_roundtrip, R.transition_rows, R.flat_tail,
-                                   R.dense_on_autoreset, R.incremental_rows, R.dense_cache], ids=lambda f: f.__name__)
+                                   R.dense_on_autoreset, R.incremental_rows, R.dense_cache, R.partial_store_invariants], ids=lambda f: f.__name__)
 def test_hip_round3_boundary(check):
     errs = check(B.HipBackend)
     assert not errs, "\n".join(errs[:10])
