@@ -611,7 +611,7 @@ def batch_sweep_leg(dev, bbox, op, sizes=(32768, 131072), K=24):
             for i in range(K):
                 batch.step_bbox_ptr(bb[i].data_ptr(), oo[i].data_ptr(), FL, sh)
         alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
-        sec, _ = graph_time(dev, enqueue, K, reps=3, warm=2)
+        sec, _ = graph_time(dev, enqueue, K, reps=7, warm=8)  # (1 GB of freshly allocated state: let TLBs and clocks settle)
         out.append({"envs": N, "us_per_step_batch": sec * 1e6, "value": N / sec, "unit": "env-steps/s",
                     "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, N)})
         del batch, bb, oo
