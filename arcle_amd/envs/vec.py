@@ -167,8 +167,9 @@ class ARCVecEnv:
         if set(augment) - {"permute", "rot90"}:
             raise ValueError('augment: a subset of ("permute", "rot90"), or True for both')
         self.aug_flags = (AUG_PERMUTE if "permute" in augment else 0) | (AUG_ROT90 if "rot90" in augment else 0)
-        # the vector env's state only evolves through the kernels, so redundant zero-fills of `selected` can be elided
-        self.flags = self.batch.elide_flag
+        # the vector env's state only evolves through the kernels, so redundant zero-fills of `selected` can be elided — unless the
+        # table holds host callables, which may write anything into the state they are handed
+        self.flags = 0 if self._host_slots else self.batch.elide_flag
         if autoreset is True:
             self.flags |= STEP_AUTORESET
         elif autoreset == "resample":
@@ -552,7 +553,6 @@ class ARCVecEnv:
     def set_state(self, st):
         self.batch.set_state(st)
         self._refresh_rows()
-
 
     def rollout_bbox(self, bbox, operation):
         """T steps in ONE launch: bbox int32 [T,N,4], operation int32 [T,N] -> (obs, reward [T,N], terminated [T,N]).
