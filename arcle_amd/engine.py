@@ -411,6 +411,22 @@ class EnvBatch:
                                                  self._stream()), "arcle_transition_rows")
         return out, reward, term
 
+    def get_plane(self, name, out=None):
+        """One key of the state dict as a dense [N, H, W] int8 array (device tensor, or a pinned host tensor passed as `out`):
+        arcle_get_plane, a strided copy on the current stream."""
+        if out is None:
+            out = torch.empty((self.N, self.H, self.W), dtype=torch.int8, device=self.device)
+        assert out.dtype == torch.int8 and out.is_contiguous() and out.numel() == self.N * self.P
+        self._check(self.L.arcle_get_plane(self._h, PLANE_ID[name], _ptr(out), self._stream()), "arcle_get_plane")
+        return out
+
+    def set_plane(self, name, src):
+        """The inverse: dense [N, H, W] int8 (device or pinned host) -> the plane (padding untouched); the caches derived from the
+        state are dropped (arcle_invalidate)."""
+        assert src.dtype == torch.int8 and src.is_contiguous() and src.numel() == self.N * self.P
+        self._check(self.L.arcle_set_plane(self._h, PLANE_ID[name], _ptr(src), self._stream()), "arcle_set_plane")
+        self.invalidate()
+
     def get_state(self):
         """Checkpoint of everything that defines the batch's future: a dict of CLONED device tensors (state planes incl. the task's
         input / answer, the per-env record, the counters, and — when a sampler is installed — the per-env episode numbers and

@@ -505,3 +505,50 @@ def test_step_many_over_host_resident_records_with_in_launch_prefetch():
         ra, ta = a.step_many("bbox5", act5.cuda(), None, FL)
         torch.cuda.synchronize()
         assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(a.planes["grid"], b.planes["grid"]) and torch.equal(a.rec, b.rec)
+
+
+def test_plane_copies_and_step_many_in_every_action_form():
+    """arcle_get_plane / arcle_set_plane (dense [N, H, W] <-> the strided plane, device and pinned host) and arcle_step_many for the
+    mask / bit-packed / point forms: K steps per call == K single steps."""
+    import torch
+    from arcle_amd.engine import EnvBatch
+    N, H, W, K = 64, 12, 12, 10
+    rng = np.random.default_rng(4)
+    mk = lambda: B.HipBackend(N, H, W, 2, "o2arc", O.o2arc_ops())  # noqa: E731
+    a, b = mk(), mk()
+    tasks = R._tasks(rng, N, H, W)
+    for be in (a, b):
+        be.set_tasks(*tasks)
+        be.reset()
+    g = a.b.get_plane("grid")
+    assert g.shape == (N, H, W) and torch.equal(g, a.b.plane("grid"))
+    host = torch.empty((N, H, W), dtype=torch.int8).pin_memory()
+    a.b.get_plane("input", host)
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), tasks[0])
+    new = torch.from_numpy(rng.integers(0, 10, (N, H, W)).astype(np.int8))
+    for be in (a, b):
+        be.b.set_plane("grid", new.cuda())
+    assert torch.equal(a.b.plane("grid"), new.cuda()) and a.padding_is_zero()
+    for form in ("mask", "bits", "point"):
+        if form == "point":
+            pay = torch.from_numpy(np.stack([rng.integers(0, H, (K, N)), rng.integers(0, W, (K, N))], -1).astype(np.int32)).cuda()
+        else:
+            pay = torch.from_numpy((rng.random((K, N, H, W)) < 0.1).astype(np.int8)).cuda()
+        op = torch.from_numpy(rng.integers(0, 35, (K, N)).astype(np.int32)).cuda()
+        rs, ts = [], []
+        for i in range(K):
+            if form == "mask":
+                r, t = a.b.step_mask(pay[i], op[i], 1)
+            elif form == "bits":
+                r, t = a.b.step_bits(a.b.pack_mask_bits(pay[i]), op[i], 1)
+            else:
+                r, t = a.b.step_point(pay[i], op[i], 1)
+            rs.append(r.clone()), ts.append(t.clone())
+        many = torch.stack([b.b.pack_mask_bits(pay[i]) for i in range(K)]) if form == "bits" else pay
+        r2, t2 = b.b.step_many(form, many.contiguous(), op, 1)
+        assert torch.equal(torch.stack(rs), r2) and torch.equal(torch.stack(ts), t2), form
+        for k in a.b.planes:
+            assert torch.equal(a.b.planes[k], b.b.planes[k]), (form, k)
+        assert torch.equal(a.b.rec, b.b.rec) and torch.equal(a.b.cnt, b.b.cnt)
+    assert a.status() == b.status()
