@@ -1072,6 +1072,8 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
   p.flat_stride = out_stride;
   p.flat_filter = 0;
   p.flat_tail = tail ? 1 : 0;
+  // in place: a plane the op did not touch stays where it is (the writer's incremental mode); otherwise it is passed through
+  if (rows_out == rows_in && out_stride == in_stride) p.flags |= ARCLE_STEP_ROWS_INCREMENTAL;
   const dim3 g = grid_for(n_rows), b(64 * WAVES_PER_WG);
   hipStream_t st = (hipStream_t)stream;
   const int fw = width_class(e->base);

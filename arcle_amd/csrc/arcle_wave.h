@@ -278,6 +278,11 @@ struct Wave {
   bool resident;
   mutable U4 cache[ARCLE_N_PLANES];
   mutable uint32_t dirty;  // planes of `cache` that differ from HBM
+  // state-row kernels: the planes come out of a flattened state row ON DEMAND (a plane the op never reads is never held in
+  // registers: the row writer passes it through at the end, or — in place — leaves it alone); `have` = planes already in `cache`
+  const int8_t* row_src;
+  int answer_env;
+  mutable uint32_t have;
   // accounting instantiations: bytes of global-memory accesses this wave ISSUED (every plane / table / row access, whole 16-byte
   // lanes incl. row padding) — next to the algorithmic figure of SURVEY.md 8d it shows what the implementation really moves
   bool count;
@@ -293,6 +298,9 @@ struct Wave {
     fw = fw_;
     resident = resident_;
     dirty = 0;
+    row_src = nullptr;
+    answer_env = 0;
+    have = ~0u;
     const uint32_t f0 = 16u * (uint32_t)lane;
     r0 = (int)(xl::mul24(f0, p.div_magic) >> 16);  // f0 < 1024, div_magic < 2^17
     c0 = (int)f0 - (int)xl::mul24((uint32_t)r0, (uint32_t)p.W);
@@ -320,11 +328,20 @@ struct Wave {
     if (live) xl::store16(p.plane[pl], poff, v);
     if (count) issued += (uint32_t)p.PS;
   }
-  ARCLE_DEV U4 load(int pl) const { return resident ? cache[pl] : load_hbm(pl); }
+  ARCLE_DEV U4 load_from_row(int pl) const;  // (defined with the row layout, below)
+  ARCLE_DEV U4 load(int pl) const {
+    if (!resident) return load_hbm(pl);
+    if (!(have & (1u << pl))) {
+      cache[pl] = load_from_row(pl);
+      have |= 1u << pl;
+    }
+    return cache[pl];
+  }
   ARCLE_DEV void store(int pl, const U4& v) const {
     stored |= 1u << pl;
     if (resident) {
       cache[pl] = v;
+      have |= 1u << pl;
       dirty |= 1u << pl;
     } else {
       store_hbm(pl, v);
@@ -1869,6 +1886,12 @@ struct FlatRow {
   int off;           // bytes written so far
   bool only_stored;  // ARCLE_STEP_ROWS_INCREMENTAL: rewrite only the segments of planes this step stored
 };
+// whole 16-byte chunk `chunk` of the row.  A plain (write-back) store: the write-through form the plane stores use is slower here
+// (transition rows 35.5 -> 39.7 us, fused FilterO2ARC rows 10.8 -> 13.9 us: the boundary bytes of a row go to lines its chunk stores
+// also touch, and a write-through store drops the line from the L2 — profiles/round3_experiments.txt)
+ARCLE_DEV void row_store16(const Wave&, const FlatRow& fr, int chunk, const U4& v) {
+  *reinterpret_cast<U4*>(fr.row + 16 * (size_t)chunk) = v;
+}
 ARCLE_DEV void flat_plane(const Wave& w, FlatRow& fr, int pl) {
   if (!w.p.plane[pl]) return;
   if (fr.only_stored && !(w.stored & (1u << pl))) {  // incremental rows: the segment already holds this plane (unchanged this step)
@@ -1876,11 +1899,27 @@ ARCLE_DEV void flat_plane(const Wave& w, FlatRow& fr, int pl) {
     return;
   }
   const int P = w.p.P, off = fr.off, lane = w.lane;
+  if (w.resident && w.row_src && !(w.stored & (1u << pl)) && (reinterpret_cast<uintptr_t>(w.row_src) & 15) == 0) {
+    // state-row kernels, a plane the op did not change, input row 16-byte aligned: input and output rows share one layout, so the
+    // segment is passed through chunk for chunk (aligned 16-byte loads and stores, no staging, no shift) plus its edge bytes
+    const int8_t* in = w.row_src;
+    const int c0 = (off + 15) >> 4, n_full = ((off + P) >> 4) - c0;
+    if (lane < n_full) {
+      const U4 c = *reinterpret_cast<const U4*>(in + 16 * (size_t)(c0 + lane));
+      row_store16(w, fr, c0 + lane, c);
+    }
+    const int head = imin(16 * c0 - off, P);
+    if (lane < head) fr.row[off + lane] = in[off + lane];
+    const int tail = n_full >= 0 ? ((off + P) & 15) : 0;
+    if (lane < tail) fr.row[16 * (c0 + n_full) + lane] = in[16 * (c0 + n_full) + lane];
+    fr.off += P;
+    return;
+  }
   w.stage(w.lds->a, w.load(pl));  // (the state-row kernels keep the planes in registers: `load` serves them from there)
   const int c0 = (off + 15) >> 4, S = 16 * c0 - off;  // first whole chunk of the row inside the segment; its plane byte offset
   const int n_full = ((off + P) >> 4) - c0;           // whole chunks (<= 64); negative: the segment ends inside its first chunk
   const U4 o = w.shifted(w.lds->a, S);
-  if (lane < n_full) *reinterpret_cast<U4*>(fr.row + 16 * (size_t)(c0 + lane)) = o;
+  if (lane < n_full) row_store16(w, fr, c0 + lane, o);
   const uint8_t* t8 = reinterpret_cast<const uint8_t*>(w.lds->a);
   const int head = imin(S, P);                        // row bytes [off, 16 c0) = plane bytes [0, S)
   if (lane < head) fr.row[off + lane] = (int8_t)t8[xl::lds_idx(lane, 1024)];
@@ -1979,15 +2018,35 @@ ARCLE_DEV U4 row_plane(const Wave& w, const int8_t* row, int off) {
   return v;
 }
 ARCLE_DEV uint32_t row_byte(const int8_t* row, int off) { return xl::uniform((uint32_t)(uint8_t)row[off]); }
-// `sink(plane id, bytes)` receives every plane of the row; the record's state fields are filled in (answer_dim untouched)
+// byte offset of plane `pl`'s segment in a full state row (the layout flat_row writes); pl is a constant at every call site
+ARCLE_DEV int row_offset(const StepParams& p, int pl) {
+  const int P = p.P;
+  const int c = p.plane[ARCLE_PL_CLIP] ? P + 2 : 0;  // clip, clip_dim in front of grid
+  switch (pl) {
+    case ARCLE_PL_CLIP: return 0;
+    case ARCLE_PL_GRID: return c;
+    case ARCLE_PL_INPUT: return c + P + 2;
+    case ARCLE_PL_BACKGROUND: return c + 2 * P + 4 + 1;
+    case ARCLE_PL_OBJECT: return c + 3 * P + 5;
+    case ARCLE_PL_OBJECT_SEL: return c + 4 * P + 9;
+    default: return c + 5 * P + 10;  // ARCLE_PL_SELECTED
+  }
+}
+ARCLE_DEV U4 Wave::load_from_row(int pl) const {
+  if (pl == ARCLE_PL_ANSWER) return xl::load16(p.plane[ARCLE_PL_ANSWER], (uint32_t)answer_env * (uint32_t)p.PS + 16u * (uint32_t)lane);
+  if (!p.plane[pl]) return u4_zero();
+  return row_plane(*this, row_src, row_offset(p, pl));
+}
+// `sink(plane id, bytes)` receives every plane of the row (planes = false: the scalars only); the record's state fields are filled
+// in (answer_dim untouched)
 template <typename Sink>
-ARCLE_DEV void read_state_row(const Wave& w, const int8_t* row, Rec& r, Sink&& sink) {
+ARCLE_DEV void read_state_row(const Wave& w, const int8_t* row, Rec& r, Sink&& sink, bool planes = true) {
   const StepParams& p = w.p;
   const int P = p.P;
   const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
   int off = 0;
   auto plane = [&](int pl) __attribute__((always_inline)) {
-    sink(pl, row_plane(w, row, off));
+    if (planes) sink(pl, row_plane(w, row, off));
     off += P;
   };
   auto scalar = [&](int field, int n) __attribute__((always_inline)) {
@@ -2053,12 +2112,12 @@ ARCLE_DEV void wave_transition_row(const StepParams& p, WaveLDS* lds, const U2* 
     src = 0;
   }
   w.set_env(src);
-#pragma unroll
-  for (int pl = 0; pl < ARCLE_N_PLANES; pl++) w.cache[pl] = u4_zero();
-  w.cache[ARCLE_PL_ANSWER] = w.load_hbm(ARCLE_PL_ANSWER);
   Rec r = load_rec(p, src);  // (answer_dim; every state field is overwritten from the row)
-  read_state_row(w, rin, r, [&](int pl, const U4& v) { w.cache[pl] = v; });
+  read_state_row(w, rin, r, [&](int, const U4&) {}, false);  // the scalars now; planes on demand (Wave::load)
   w.resident = true;
+  w.row_src = rin;
+  w.answer_env = src;
+  w.have = 0;
   w.env = row;  // outputs (dense pair, flat row) are indexed by the row
   const U4 pay = load_payload(w, row, 0, p.sel);
   const int op = (int)xl::uniform((uint32_t)p.op[row]);
@@ -2068,7 +2127,9 @@ ARCLE_DEV void wave_transition_row(const StepParams& p, WaveLDS* lds, const U2* 
     p.reward[row] = out.reward;
     p.term[row] = (uint8_t)out.term;
   }
-  flat_row(w, r);
+  // planes the op did not touch are passed through from the input row — or, in place (the launcher sets the incremental flag when
+  // rows_out is rows_in), left where they are
+  flat_row(w, r, (p.flags & ARCLE_STEP_ROWS_INCREMENTAL) != 0);
   if (p.flat_tail) flat_tail(w, out, cnt, false);
 }
 

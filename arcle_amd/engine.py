@@ -400,7 +400,9 @@ class EnvBatch:
         stride = ((L + 15) & ~15) + (ROW_TAIL if tail else 0)
         if out is None:
             out = torch.empty((M, stride), dtype=torch.int8, device=self.device)
-        assert out.shape == (M, stride) and out.dtype == torch.int8 and out.is_contiguous()
+        # (`out` may be the buffer `rows` views: rows_out == rows_in with equal strides is the in-place form — untouched planes stay)
+        assert out.dim() == 2 and out.shape[0] == M and out.shape[1] >= stride and out.shape[1] % 16 == 0 and out.dtype == torch.int8 and out.is_contiguous()
+        stride = out.shape[1]
         assert rows.dtype == torch.int8 and rows.stride(1) == 1 and payload.is_contiguous() and op.dtype == torch.int32 and op.is_contiguous()
         if reward is None:
             reward = torch.empty(M, dtype=torch.int32, device=self.device)

@@ -526,13 +526,21 @@ class ARCVecEnv:
         self.flags &= ~self.batch.elide_flag  # states from outside may break the invariant the zero-fill elision rests on
         self._refresh_rows()
 
-    def transition(self, rows, action, src_env=None, out=None):
+    def transition(self, rows, action, src_env=None, out=None, in_place=False):
         """The reference's `transition(state, action)` (o2arcenv.py:149-151; README: `env.transition(deepcopy(state), action)`) for
         a batch: rows int8 [M, L] = M states (as `state_rows` / a previous `transition` returns them — M is NOT tied to num_envs),
         action = {"selection": [M,H,W] mask | "bbox": int32 [M,4] | "point": int32 [M,2], "operation": int32 [M]}; src_env int32
         [M] = the env whose task (answer) row m belongs to (default: env m).  Returns (rows_out [M, L], reward int32 [M], terminated
-        bool [M]).  Nothing of this env's own state is touched: expanding thousands of hypothetical states per launch is the point."""
+        bool [M]).  Nothing of this env's own state is touched: expanding thousands of hypothetical states per launch is the point.
+        in_place=True: `rows` (a tensor an earlier `transition` returned, or any view of a [M, 16-byte-multiple] buffer) is overwritten
+        with the successor states — the kernel then rewrites only the planes the op changed, about half the time of the
+        out-of-place form (walking M trajectories forward rather than branching)."""
         b = self.batch
+        if in_place:
+            stride = rows.stride(0)
+            if rows.dim() != 2 or rows.stride(1) != 1 or stride % 16 or stride < ((b.state_row_size() + 15) & ~15) or rows.data_ptr() % 16:
+                raise ValueError("in_place: rows must be a view of a 16-byte aligned [M, stride] int8 buffer, stride a multiple of 16 >= the row length")
+            out = torch.as_strided(rows, (rows.shape[0], stride), (stride, 1))
         if "bbox" in action:
             form, pay = "bbox", action["bbox"].to(device=self.device, dtype=torch.int32).contiguous()
         elif "point" in action:

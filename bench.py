@@ -588,12 +588,24 @@ def transition_leg(dev, n, bbox, op, K=32):
     sec, _ = graph_time(dev, enqueue, K)
     L = batch.state_row_size()
     moved = n * (2 * L + 1024 + 16 + 24)
+    # in place: rows_out IS rows_in — the kernel rewrites only the planes the op changed (walking n trajectories forward)
+    buf = torch.zeros((n, out.shape[1]), dtype=torch.int8, device=dev)
+    buf[:, :L] = rows
+
+    def enqueue_in_place(sh):
+        for i in range(K):
+            rc = batch.L.arcle_transition_rows(batch._h, n, buf.data_ptr(), buf.shape[1], 1, bbox[i].data_ptr(), op[i].data_ptr(), None,
+                                               buf.data_ptr(), buf.shape[1], 0, rw.data_ptr(), tm.data_ptr(), 0, sh)
+            assert rc == 0
+    sec_ip, _ = graph_time(dev, enqueue_in_place, K)
     return {"mode": f"arcle_transition_rows, {n} (row, bbox action) pairs per launch, rows {L} B", "value": n / sec, "unit": "transitions/s",
             "us_per_step_batch": sec * 1e6,
+            "in_place": {"us_per_step_batch": sec_ip * 1e6, "value": n / sec_ip, "unit": "transitions/s",
+                         "note": "rows_out is rows_in: only the planes the op changed are rewritten"},
             "roofline": {"bound": "hbm", "achieved": moved / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": moved / sec / HBM_PEAK,
                          "traffic": None, "algorithmic_bytes_per_launch": moved,
-                         "note": "algorithmic = row in + row out + answer plane + action/outputs per pair (every transition reads and writes "
-                                 "the WHOLE 6314-byte state: it has no resident copy to leave untouched planes in)"}}
+                         "note": "algorithmic = row in + row out + answer plane + action/outputs per pair (every out-of-place transition reads and "
+                                 "writes the WHOLE 6314-byte state: it has no resident copy to leave untouched planes in)"}}
 
 
 def batch_sweep_leg(dev, bbox, op, sizes=(32768, 131072), K=24):

@@ -349,7 +349,8 @@ int arcle_set_flat_output_ex(arcle_env* env, int8_t* out, int32_t out_stride, in
  *                          _BBOX / _POINT with the matching `sel` array [n_rows][...]; op int32[n_rows]; reward int32[n_rows],
  *                          term uint8[n_rows] out; tail as arcle_set_flat_output_ex (action_steps = 1, submit_count = 1 iff the
  *                          Submit counted, base.py:174-175).  flags: ARCLE_STEP_RESET_ON_SUBMIT | _DENSE | _CONTINUE_RULE.
- *                          rows_out may equal rows_in when the strides agree (in place). */
+ *                          rows_out may equal rows_in when the strides agree: IN PLACE, only the planes the op changed (and the scalars)
+ *                          are rewritten — about half the time of the out-of-place form. */
 int arcle_get_state_rows(arcle_env* env, int8_t* rows, int32_t stride, void* stream);
 int arcle_set_state_rows(arcle_env* env, const int8_t* rows, int32_t stride, const uint8_t* mask, void* stream);
 int arcle_transition_rows(arcle_env* env, int32_t n_rows, const int8_t* rows_in, int32_t in_stride, int ingress, const void* sel,

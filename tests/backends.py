@@ -316,13 +316,18 @@ class EmuBackend:
         rc = emu_lib().emu_run(6, ctypes.byref(p))
         assert rc == 0
 
-    def transition_rows(self, rows, ingress, payload, op, src_env=None, tail=False, flags=0):
+    def transition_rows(self, rows, ingress, payload, op, src_env=None, tail=False, flags=0, in_place=False):
         p = self._params()
         self._extras(p)
         rows = np.ascontiguousarray(rows, np.int8)
         M = rows.shape[0]
         L = self._flat_len(False)
         out = np.full((M, ((L + 15) & ~15) + (16 if tail else 0)), 0x55, np.int8)
+        if in_place:  # rows_out IS rows_in: untouched planes stay where they are (the library sets the writer's incremental mode)
+            out[:, :L] = rows[:, :L]
+            out[:, L:(L + 15) & ~15] = 0
+            rows = out
+            flags |= 512
         pay = (np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(M, self.P) if ingress == "mask"
                else np.ascontiguousarray(payload, np.int32))
         opa = np.ascontiguousarray(op, np.int32)
@@ -513,9 +518,19 @@ class HipBackend:
         self.b.set_state_rows(t.as_tensor(np.ascontiguousarray(rows, np.int8), device=self.b.device),
                               None if mask is None else t.as_tensor(np.ascontiguousarray(mask, np.uint8), device=self.b.device))
 
-    def transition_rows(self, rows, ingress, payload, op, src_env=None, tail=False, flags=0):
+    def transition_rows(self, rows, ingress, payload, op, src_env=None, tail=False, flags=0, in_place=False):
         t, dev = self.torch, self.b.device
         M = len(rows)
+        if in_place:
+            L = self.b.state_row_size()
+            buf = t.zeros((M, ((L + 15) & ~15) + (16 if tail else 0)), dtype=t.int8, device=dev)
+            buf[:, :L] = t.as_tensor(np.ascontiguousarray(rows, np.int8), device=dev)[:, :L]
+            pay = (t.as_tensor(np.ascontiguousarray(np.asarray(payload).astype(np.int8)), device=dev).reshape(M, self.H, self.W) if ingress == "mask"
+                   else t.as_tensor(np.ascontiguousarray(payload, np.int32), device=dev))
+            out, r, tm = self.b.transition_rows(buf, ingress, pay, t.as_tensor(np.ascontiguousarray(op, np.int32), device=dev),
+                                                None if src_env is None else t.as_tensor(np.ascontiguousarray(src_env, np.int32), device=dev),
+                                                out=buf, tail=tail, flags=flags)
+            return out.cpu().numpy(), r.cpu().numpy(), tm.cpu().numpy()
         pay = (t.as_tensor(np.ascontiguousarray(np.asarray(payload).astype(np.int8)), device=dev).reshape(M, self.H, self.W) if ingress == "mask"
                else t.as_tensor(np.ascontiguousarray(payload, np.int32), device=dev))
         out, r, tm = self.b.transition_rows(t.as_tensor(np.ascontiguousarray(rows, np.int8), device=dev), ingress, pay,

@@ -160,7 +160,7 @@ def transition_rows(cls):
             if rep == 3:
                 op[0] = len(ops) + 2  # an out-of-range op: the row passes through, status bit in the tail
             trials_before = orc.get("trials_remain")[:, 0].copy()
-            out, r1, t1 = be.transition_rows(rows, ing, pay, op, tail=True)
+            out, r1, t1 = be.transition_rows(rows, ing, pay, op, tail=True, in_place=(rep % 2 == 1))  # (odd rounds: rows_out IS rows_in)
             r2, t2 = orc.step(ing, pay, op)
             want = B.state_rows(orc)
             tag = f"{kind} {H}x{W} rep {rep} {ing}"

@@ -552,3 +552,27 @@ def test_plane_copies_and_step_many_in_every_action_form():
             assert torch.equal(a.b.planes[k], b.b.planes[k]), (form, k)
         assert torch.equal(a.b.rec, b.b.rec) and torch.equal(a.b.cnt, b.b.cnt)
     assert a.status() == b.status()
+
+
+def test_vec_transition_in_place_walks_trajectories():
+    """ARCVecEnv.transition(in_place=True): the rows buffer is advanced by one action per call, only changed planes rewritten — after
+    T calls it equals T out-of-place transitions and T resident steps of the same envs."""
+    import torch
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    N, T = 256, 12
+    v = ARCVecEnv(O2ARCv2Env, N, _loader(), max_grid_size=(12, 12), max_trial=3, seed=2)
+    v.reset()
+    rows0 = v.state_rows().clone()
+    bb, op = _actions(T, N, 12, 12, 8)
+    walk, _, _ = v.transition(rows0, {"bbox": bb[0], "operation": op[0]})   # the first hop allocates the [N, stride] buffer
+    branch = walk.clone()
+    for i in range(1, T):
+        walk2, r_ip, t_ip = v.transition(walk, {"bbox": bb[i], "operation": op[i]}, in_place=True)
+        assert walk2.data_ptr() == walk.data_ptr()
+        branch, r_op, t_op = v.transition(branch.contiguous(), {"bbox": bb[i], "operation": op[i]})
+        assert torch.equal(r_ip, r_op) and torch.equal(t_ip, t_op), i
+        assert torch.equal(walk2[:, :branch.shape[1]], branch), i
+    for i in range(T):
+        v.step_bbox(bb[i], op[i])
+    assert torch.equal(v.state_rows(), walk[:, :rows0.shape[1]])
+    v.check_errors()
