@@ -307,7 +307,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             L, P = b.state_row_size(), self.H * self.W
             stride = ((L + 15) & ~15) + 16
             rin = torch.zeros((1, stride), dtype=torch.int8).pin_memory()
-            rout = torch.zeros((1, stride), dtype=torch.int8).pin_memory()
+            rout = rin  # IN PLACE: the kernel fetches only the planes the op reads and rewrites only the ones it changed
             act = torch.zeros(((P + 3) & ~3) + 4, dtype=torch.int8).pin_memory()
             self._tio_bufs = dict(rin=rin, rout=rout, act=act, rin_np=rin[0].numpy(), rout_np=rout[0].numpy(), sel=act[:P].numpy(),
                                   op=act[(P + 3) & ~3:].view(torch.int32).numpy(), tail=rout[0, stride - 16:].view(torch.int32).numpy(),
