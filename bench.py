@@ -746,6 +746,8 @@ def main():
     n = a.envs_per_gpu or cfg["envs"]
     K, Wm = a.steps, a.warmup
     R = a.regions or max(5, min(50, math.ceil(2000 / max(K, 1))))
+    if shared_gpu and a.config == "c4" and not a.regions:
+        R = 3  # (ranks sharing one GPU gather through a CPU bounce, ~0.2 s per step: a functional leg, not a measurement)
     S = min(K * R + Wm, max(K + Wm, 2048))  # distinct action batches staged in HBM (regions cycle through them)
 
     # shard = contiguous global env ids [rank*n, (rank+1)*n); per-shard seeds keyed by rank
