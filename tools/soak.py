@@ -9,14 +9,62 @@ import backends as B
 from oracle import oracle as O
 ops = O.o2arc_ops()
 S = int(os.environ.get("SOAK_STEPS", 600))
+BE = getattr(B, os.environ.get("SOAK_BACKEND", "HipBackend"))  # (EmuBackend: a dry run of this script on the CPU)
+SCALE = int(os.environ.get("SOAK_SHRINK", 1))
 t0 = time.time()
 for name, H, W, N, flags, mt in (("30x30 flags=0", 30, 30, 1024, 0, 3), ("30x30 autoreset|elide", 30, 30, 1024, 1 | 2, 3),
                                  ("30x30 autoreset|elide, max_trial=-1", 30, 30, 1024, 1 | 2, -1),
                                  ("24x32 autoreset", 24, 32, 512, 1, 2), ("17x21 autoreset|elide", 17, 21, 512, 1 | 2, 5),
                                  ("9x13 generic", 9, 13, 512, 1, 3)):
-    errs = B.random_trace_compare(B.HipBackend, "o2arc", ops, H, W, N=N, S=S, seed=H * 131 + W + flags, max_trial=mt, flags=flags,
+    errs = B.random_trace_compare(BE, "o2arc", ops, H, W, N=N // SCALE, S=S, seed=H * 131 + W + flags, max_trial=mt, flags=flags,
                                   bad_ops=True)
     print(f"{name:40s} N={N} S={S}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
 arc = O.arc_ops()
-errs = B.random_trace_compare(B.HipBackend, "arc", arc, 30, 30, N=1024, S=S, seed=77, max_trial=3, flags=1, op_weights=[1] * 10 + [7] * 10 + [1] * 7)
+errs = B.random_trace_compare(BE, "arc", arc, 30, 30, N=1024 // SCALE, S=S, seed=77, max_trial=3, flags=1, op_weights=[1] * 10 + [7] * 10 + [1] * 7)
 print(f"{'ARCEnv 30x30 FloodFill-heavy':40s} N=1024 S={S}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
+
+# round-3 forms: 5-tuple records + bit-packed masks through the lean instantiations, and the research flag set (dense pair cache,
+# fused FilterO2ARC rows kept incrementally, auto-reset, elision) checked against the oracle's state and the stand-alone row writer
+import numpy as np
+import rows as R
+for name, flags in (("30x30 bbox5/bits flags=0", 0), ("30x30 bbox5/bits autoreset|elide", 3)):
+    errs = B.random_trace_compare(BE, "o2arc", ops, 30, 30, N=1024 // SCALE, S=S, seed=911 + flags, max_trial=3, flags=flags, new_forms=True)
+    print(f"{name:40s} N=1024 S={S}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
+N, H, W = 512 // SCALE, 30, 30
+FL = R.STEP_AUTORESET | R.STEP_ELIDE | R.STEP_DENSE | R.STEP_FLAT_OBS
+for filtered in (True, False):
+    rng = np.random.default_rng(5 + filtered)
+    be, orc = BE(N, H, W, 3, "o2arc", ops), B.OracleBackend(N, H, W, 3, "o2arc", ops)
+    tasks = R._tasks(rng, N, H, W, same_answer=0.7)
+    for b in (be, orc):
+        b.set_tasks(*tasks)
+        b.reset()
+    be.set_dense_output()
+    be.set_flat_output(filtered)
+    be.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 32, np.int32), FL)
+    orc.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 32, np.int32), R.STEP_AUTORESET)
+    errs = []
+    fields = R._state_fields("o2arc")
+    for s in range(S):
+        ing, pay, op = R._random_actions(rng, N, H, W, len(ops))
+        r1, t1 = be.step(ing, pay, op, FL | R.STEP_ROWS_INC)
+        r2, t2 = orc.step(ing, pay, op, R.STEP_AUTORESET)
+        if not (np.array_equal(r1, r2) and np.array_equal(t1, t2)):
+            errs.append(f"step {s}: reward / terminated differ")
+        for f in fields:
+            if not np.array_equal(be.get(f), orc.get(f)):
+                errs.append(f"step {s}: field {f} differs")
+        if not np.array_equal(be.fused_flat(), be.flat_obs(filtered)):
+            errs.append(f"step {s}: incremental rows differ from the stand-alone writer's")
+        if s % 8 == 0:
+            gd, ad = orc.get("grid_dim").astype(int), orc.get("answer_dim").astype(int)
+            g, a, d = orc.get("grid"), orc.get("answer"), be.dense
+            for n in range(0, N, 7):
+                mh, mw = min(gd[n, 0], ad[n, 0]), min(gd[n, 1], ad[n, 1])
+                correct = int((g[n, :mh, :mw] == a[n, :mh, :mw]).sum())
+                if int(d[n, 0]) != correct and tuple(d[n]) != (0, 0):
+                    errs.append(f"step {s} env {n}: dense correct {d[n, 0]} != {correct}")
+        be.status(), orc.status()
+        if errs:
+            break
+    print(f"{'research flags, filtered=' + str(filtered):40s} N={N} S={S}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
