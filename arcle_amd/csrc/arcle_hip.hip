@@ -12,6 +12,7 @@
 // That is an affinity choice only — correctness never depends on placement (envs share no
 // data and no workgroup communicates with another).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +87,16 @@ ARCLE_DEV U4 load16(const int8_t* base, uint32_t off) {
 ARCLE_DEV void store16(int8_t* base, uint32_t off, const U4& v) {
   asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 " ARCLE_STORE_POLICY "\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
+// lane-0 stores of the step outputs: uniform base + byte offset held in a VGPR -> `global_store v_off, data, s[base]` (the saddr
+// form).  With the offset in an SGPR the compiler forms the 64-bit address with s_add_u32 / s_addc_u32 per store — scalar
+// instructions, the one kind this kernel is short of (profiles/round3_experiments.txt: 8-11 ns per launch each)
+template <typename T>
+ARCLE_DEV void store_at(void* base, uint32_t off, const T& v) {
+  asm volatile("" : "+v"(off));  // (the offset lives in a VGPR from here on)
+  typedef std::conditional_t<sizeof(T) == 16, U4, std::conditional_t<sizeof(T) == 8, U2, std::conditional_t<sizeof(T) == 4, uint32_t, uint8_t>>> R;
+  static_assert(sizeof(R) == sizeof(T), "16 / 8 / 4 / 1 byte values");
+  *reinterpret_cast<ARCLE_AS_GLOBAL R*>((uintptr_t)base + off) = __builtin_bit_cast(R, v);
+}
 ARCLE_DEV uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz constant clock
 // neighbouring lane's value through DPP wave shifts (no LDS): lane j-1 / lane j+1, 0 at the wave boundary
 ARCLE_DEV uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
@@ -143,6 +154,22 @@ ARCLE_DEV void arrived3(U4& a, U2& b, uint32_t& c) { asm volatile("" : "+s"(a), 
 // every `a[i] = x; y = a[i];` relies on).  An agent-scope invalidate (`buffer_inv sc1`) here cost 50 us per launch: it empties the
 // CU's L1 under the 31 other resident waves.  The asm is a compiler-level fence only (the plane stores are inline asm).
 ARCLE_DEV void own_stores_visible() { asm volatile("" ::: "memory"); }
+// "uniform value, vector register": v_perm_b32 with the identity selector has no scalar form, so the (still wave-uniform) result
+// lives in a VGPR and everything computed from it is vector ALU work; a branch on such a value is v_cmp + s_cbranch_vccnz — no
+// scalar instruction at all.  The CU's one scalar unit is what the step kernel saturates (profiles/round3_experiments.txt: a
+// scalar instruction costs a launch 8-11 ns, the first ~40 extra vector instructions per wave nothing), so the per-env
+// arithmetic that only feeds cell masks and LDS addresses is moved over with this.
+ARCLE_DEV uint32_t tov(uint32_t x) { return __builtin_amdgcn_perm(x, x, 0x03020100u); }
+// a volatile no-op on a scalar: the optimiser can neither speculate it nor fold the branch it sits in into a select — keeps a rare
+// case a BRANCH, so that its arithmetic stays off the common path
+ARCLE_DEV int rare_s(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+ARCLE_DEV int rare_v(int v) {  // (the same for a value held in a vector register)
+  asm volatile("" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ void sink_s(uint32_t v) { asm volatile("" ::"s"(v)); }
 __device__ __forceinline__ void sink_v(uint32_t v) { asm volatile("" ::"v"(v)); }
 }  // namespace xl
@@ -223,10 +250,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #endif
   const int wv = wave_of_launch(wpw, nb8, pf_off);
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
-  const int env = valid ? wv : 0;
+  const int env = (int)__builtin_elementwise_min((uint32_t)wv, (uint32_t)n_envs - 1u);  // (surplus waves load env N-1's inputs and leave)
   arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0);
   arcle::StepInputs in = arcle::load_inputs<ING>(w, env, rec, cnt, op, sel);  // in flight while the expansion table is built
-  arcle::lut_init(lds.lut, (int)threadIdx.x);
+  // (the always-true scalar test keeps a block boundary between the loads and the barrier: with straight-line code here the
+  // optimiser sinks the four loads below the barrier — into the only block that uses them — and their latency is exposed)
+  if (wpw > 0) arcle::lut_init(lds.lut, (int)threadIdx.x);
   xl::wg_barrier();
   if (!valid) return;
 #if ARCLE_STOP_AT == 1

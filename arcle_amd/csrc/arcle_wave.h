@@ -136,6 +136,7 @@ struct BlockLDS {
 // ------------------------------------------------------------------------------------------------
 ARCLE_DEV int imin(int a, int b) { return a < b ? a : b; }
 ARCLE_DEV int imax(int a, int b) { return a > b ? a : b; }
+ARCLE_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 ARCLE_DEV int i8w(int x) { return (int)(int8_t)(uint8_t)(x & 0xff); }  // wrap to int8
 ARCLE_DEV int floordiv2(int a) { return a >> 1; }                       // arithmetic shift == floor(a/2)
 ARCLE_DEV uint32_t bits_range(int a, int b) { return (2u << b) - (1u << a); }  // bits a..b, 0<=a<=b<=30
@@ -437,8 +438,10 @@ struct Wave {
 
 // fills the workgroup's mask-expansion table; every thread of the workgroup calls it, followed by xl::wg_barrier()
 // (workgroups that use the table have >= 256 threads; the emulator's single wave passes `nthreads` = 64)
+// (every thread writes entry tid & 255: in a 512-thread workgroup both halves store the same values — no exec masking, whose
+// s_and_saveexec / s_or are scalar instructions on every wave's path)
 ARCLE_DEV void lut_init(U2* lut, int tid, int nthreads = 256) {
-  for (int b = tid; b < 256; b += nthreads) {
+  for (int b = tid & 255; b < 256; b += nthreads) {
     const uint32_t lo = (uint32_t)b & 0xfu, hi = ((uint32_t)b >> 4) & 0xfu;
     const uint32_t x = (lo * 0x00204081u) & 0x01010101u, y = (hi * 0x00204081u) & 0x01010101u;
     U2 e;
@@ -543,32 +546,43 @@ ARCLE_DEV U4 load_payload_v(const Wave& w, int env, size_t step) {
 // Ingest: `ingest_scalar` is the wave-uniform part of a bbox / point tuple (returns false for a tuple outside the wrappers'
 // action space; the caller raises ARCLE_ST_BAD_SELECTION), `ingest_cells` produces the per-lane cell masks (and everything
 // for a mask payload).
-ARCLE_DEV bool ingest_scalar(const Wave& w, Sel& s, const U4& payload) {
+struct StepOut;
+ARCLE_DEV void raise_status(const StepParams& p, StepOut& out, uint32_t bits);
+// (scalar instructions are what the step kernel is short of — profiles/round3_experiments.txt — so the common case is ONE unsigned
+// test: a sorted, clipped tuple is non-empty iff both lower corners lie inside the plane; a negative coordinate fails it as a huge
+// unsigned value and is told apart, normalised to an empty rectangle and reported inside the rare branch)
+ARCLE_DEV void ingest_scalar(const Wave& w, Sel& s, const U4& payload, StepOut& out) {
   const StepParams& p = w.p;
-  bool ok = true;
   if (w.ingress == INGRESS_BBOX) {
     // BBoxWrapper.action (bbox.py:22-30): sort the corners, sel[x1:x2+1, y1:y2+1] = 1 (slices clip at H, W;
     // negative coordinates are outside the wrapper's Discrete action space and select nothing here)
     const int bx1 = (int)payload[0], by1 = (int)payload[1], bx2 = (int)payload[2], by2 = (int)payload[3];
     int xa = imin(bx1, bx2), xb = imin(imax(bx1, bx2), p.H - 1);
     int ya = imin(by1, by2), yb = imin(imax(by1, by2), p.W - 1);
-    if ((xa | ya) < 0) {
-      xa = xb + 1;
-      ok = false;
+    const bool any = p.H == p.W ? umax((uint32_t)xa, (uint32_t)ya) < (uint32_t)p.H : ((uint32_t)xa < (uint32_t)p.H && (uint32_t)ya < (uint32_t)p.W);
+    if (!any) {
+      if (xl::rare_v(xa | ya) < 0) {
+        xa = xb + 1;
+        raise_status(p, out, ARCLE_ST_BAD_SELECTION);
+      }
     }
     s.x0 = xa; s.x1 = xb; s.y0 = ya; s.y1 = yb;
+    s.any_nz = s.any_pos = any;
   } else if (w.ingress == INGRESS_POINT) {
     // PointWrapper.action (bbox.py:43-49)
     const int x = (int)payload[0], y = (int)payload[1];
-    ok = x >= 0 && x < p.H && y >= 0 && y < p.W;
-    s.x0 = x; s.x1 = ok ? x : x - 1; s.y0 = s.y1 = y;
+    const bool ok = (uint32_t)x < (uint32_t)p.H && (uint32_t)y < (uint32_t)p.W;
+    s.x0 = x; s.x1 = x; s.y0 = s.y1 = y;
+    if (!ok) {
+      s.x1 = x - 1;
+      raise_status(p, out, ARCLE_ST_BAD_SELECTION);
+    }
+    s.any_nz = s.any_pos = ok;
   } else {
-    return true;
+    return;
   }
   s.is_rect = true;
   s.one_cell = -1;
-  s.any_nz = s.any_pos = (s.x0 <= s.x1 && s.y0 <= s.y1);
-  return ok;
 }
 // `want_rect`: the op can take its rectangle shortcuts (object ops, Copy, Crop) — worth testing whether a mask IS its bounding box
 // `want_bbox`: the op reads the selection's bounding box at all (Color and FloodFill do not)
@@ -649,7 +663,8 @@ struct Scratch {
   U4 grid;
   bool have_grid;    // `grid` holds the current grid plane (loaded, requested early, or just produced by the op)
   bool grid_counted; // ACCT: the byte count already includes the grid read (or the op replaced the plane)
-  bool sel_written;  // the op itself wrote `selected` (place): the reset_sel / keep_sel value is superseded
+  uint32_t sel_pending;  // what reset_sel / keep_sel still owe the `selected` plane after the op: 0 nothing (or the op wrote the plane
+                         // itself: place), bit 1 = keep_sel's copy of the selection, 1 = reset_sel's zero-fill
   uint32_t bytes;  // algorithmic HBM bytes of this step (SURVEY.md §8d accounting; ACCT instantiations only)
 };
 #define ARCLE_ACCT(expr)      \
@@ -712,7 +727,7 @@ ARCLE_DEV void place(const Wave& w, Scratch& s, const Rec& r, const U4& backgrou
   w.store(ARCLE_PL_GRID, s.grid);
   w.store(ARCLE_PL_SELECTED, selected);
   s.have_grid = s.grid_counted = true;
-  s.sel_written = true;
+  s.sel_pending = 0;
   ARCLE_ACCT(2 * w.p.P);
 }
 
@@ -1290,7 +1305,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   int eq = -1;  // grid == answer, evaluated at most once (Submit and reward see the same state)
 
   Sel sel;
-  if (!ingest_scalar(w, sel, payload)) raise_status(p, out, ARCLE_ST_BAD_SELECTION);
+  ingest_scalar(w, sel, payload, out);
   ingest_cells(w, sel, payload, kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP || kind == ARCLE_OP_COPY || kind == ARCLE_OP_CROP_GRID,
                kind != ARCLE_OP_COLOR && kind != ARCLE_OP_FLOODFILL);
   if (ING == INGRESS_MASK) ARCLE_ACCT(P);
@@ -1321,16 +1336,18 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   // reset_sel / keep_sel (object.py:10-41) set `selected` BEFORE the wrapped op runs; an object op that places its
   // object overwrites it afterwards.  The plane is written once, after the op, with whichever value is final — and not at
   // all when the op turns out to be out of its domain (the step is skipped).
-  bool zero_selected = false;
-  if (oflags & ARCLE_OPF_RESET_SEL) {  // object.py:20-25
-    // with ARCLE_STEP_ELIDE_SELECTED an env that enters the step inactive is known to hold an all-zero `selected`
-    // plane already (see include/arcle_hip.h): the zero-fill would rewrite zeros with zeros
-    zero_selected = !((flags & ARCLE_STEP_ELIDE_SELECTED) && r.active() == 0);
-    ARCLE_ACCT(P);  // semantic accounting is unchanged
-    r.put(ARCLE_REC_ACTIVE, 0);
-  }
+  // (mask arithmetic instead of a branch: a uniform bool lives in an SGPR pair and costs the scalar unit a compare, a select and
+  // an and per use)
+  static_assert(ARCLE_OPF_RESET_SEL == 1u && (ARCLE_REC_ACTIVE & 3) == 0, "bit 0 of the flags byte; `active` is byte 0 of its dword");
+  const uint32_t rs_mask = (uint32_t)((int32_t)(desc << 15) >> 31) & 0xffu;  // 0xff for an op wrapped by reset_sel (object.py:20-25)
+  // with ARCLE_STEP_ELIDE_SELECTED an env that enters the step inactive is known to hold an all-zero `selected`
+  // plane already (see include/arcle_hip.h): the zero-fill would rewrite zeros with zeros
+  const uint32_t zero_selected = (flags & ARCLE_STEP_ELIDE_SELECTED) ? (r.w[ARCLE_REC_ACTIVE >> 2] & rs_mask) : rs_mask;
+  if (ACCT && rs_mask) ARCLE_ACCT(P);  // semantic accounting is unchanged
+  r.w[ARCLE_REC_ACTIVE >> 2] &= ~rs_mask;
   if ((oflags & (ARCLE_OPF_KEEP_SEL | ARCLE_OPF_RESET_SEL)) == ARCLE_OPF_KEEP_SEL) ARCLE_ACCT(P);  // object.py:36-40
-  s.sel_written = false;
+  static_assert(ARCLE_OPF_KEEP_SEL == 2u, "bit 1");
+  s.sel_pending = (oflags & ARCLE_OPF_KEEP_SEL) | (zero_selected ? 1u : 0u);
 
   switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
     case ARCLE_OP_COLOR: {  // color.py:70-74 — whole HxW plane, grid_dim ignored
@@ -1581,9 +1598,9 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
     out.term = r.term() != 0;
     return out;
   }
-  if (!s.sel_written) {
-    if (oflags & ARCLE_OPF_KEEP_SEL) w.store(ARCLE_PL_SELECTED, sel_values(w, sel));
-    else if (zero_selected) w.store(ARCLE_PL_SELECTED, u4_zero());
+  if (s.sel_pending) {
+    if (s.sel_pending & ARCLE_OPF_KEEP_SEL) w.store(ARCLE_PL_SELECTED, sel_values(w, sel));
+    else w.store(ARCLE_PL_SELECTED, u4_zero());
   }
 
   // reward(): only the LAST op of the table can be rewarded (o2arcenv.py:121-128)
@@ -1682,6 +1699,12 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
 #ifdef ARCLE_TRACE_WAVES  // diagnostic build: per-wave shader clocks into the acct buffer (as uint64[N][8])
   const uint64_t t_in = xl::clock();
 #endif
+#ifndef ARCLE_NO_TOV
+  if (is_tuple(ING)) {  // the tuple's arithmetic (sort, clip, rectangle masks, shift distances) runs on the vector ALUs: xl::tov
+#pragma unroll
+    for (int i = 0; i < 4; i++) in.payload[i] = xl::tov(in.payload[i]);
+  }
+#endif
   Rec r;
   r.w[0] = in.rec[0];
   r.w[1] = in.rec[1];
@@ -1691,6 +1714,15 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   cnt0.x = (int32_t)in.cnt[0];
   cnt0.y = (int32_t)in.cnt[1];
   w.set_env(env);
+#ifdef ARCLE_EXP_S
+  { uint32_t d = in.op; asm volatile(".rept %c1\n s_add_u32 %0, %0, 1\n .endr" : "+s"(d) : "n"(ARCLE_EXP_S) : "scc"); xl::sink_s(d); }
+#endif
+#ifdef ARCLE_EXP_N
+  asm volatile(".rept %c0\n s_nop 0\n .endr" :: "n"(ARCLE_EXP_N));
+#endif
+#ifdef ARCLE_EXP_V
+  { uint32_t d = (uint32_t)lane; asm volatile(".rept %c1\n v_add_u32 %0, %0, 1\n .endr" : "+v"(d) : "n"(ARCLE_EXP_V)); asm volatile("" :: "v"(d)); }
+#endif
 #if ARCLE_STOP_AT == 2
   xl::sink_s(r.w[0] + r.w[1] + r.w[2] + r.w[3] + (uint32_t)cnt0.x + (uint32_t)cnt0.y + in.op + in.payload[0] + in.payload[3]);
   return;
@@ -1711,11 +1743,11 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
     rv[2] = r.w[2];
     rv[3] = r.w[3];
     const uint32_t e = (uint32_t)env;
-    *reinterpret_cast<U4*>(at(p.rec, e * (uint32_t)ARCLE_REC_BYTES)) = rv;
-    *reinterpret_cast<I2*>(at(p.cnt, e * 8u)) = cnt0;
-    *at(p.reward, e * 4u) = out.reward;
-    *at(p.term, e) = (uint8_t)out.term;
-    if (flags & ARCLE_STEP_TRUNCATE) *at(p.trunc, e) = (uint8_t)truncated;
+    xl::store_at(p.rec, e * (uint32_t)ARCLE_REC_BYTES, rv);
+    xl::store_at(p.cnt, e * 8u, cnt0);
+    xl::store_at(p.reward, e * 4u, (int32_t)out.reward);
+    xl::store_at(p.term, e, (uint8_t)out.term);
+    if (flags & ARCLE_STEP_TRUNCATE) xl::store_at(p.trunc, e, (uint8_t)truncated);
   }
   if (ACCT) {  // what the wave moved besides planes: record + counters in and out, action in, outputs out
     const uint32_t act = ING == INGRESS_MASK ? (uint32_t)p.P : ING == INGRESS_BITS ? 2u * 64u : ING == INGRESS_POINT ? 12u : 20u;  // (records: 20)

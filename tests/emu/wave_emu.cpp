@@ -117,6 +117,11 @@ ARCLE_DEV void wg_barrier() { yield(8); }
 ARCLE_DEV void lanes_converged() { yield(9); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 ARCLE_DEV uint32_t opaque(uint32_t v) { return v; }
+ARCLE_DEV int rare_s(int v) { return v; }
+ARCLE_DEV int rare_v(int v) { return v; }
+ARCLE_DEV uint32_t tov(uint32_t x) { return x; }
+template <typename T>
+ARCLE_DEV void store_at(void* base, uint32_t off, const T& v) { memcpy((char*)base + off, &v, sizeof(T)); }
 ARCLE_DEV uint32_t bfrev(uint32_t v) {
   uint32_t r = 0;
   for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
