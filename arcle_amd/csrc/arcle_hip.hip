@@ -198,13 +198,85 @@ __device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, u
   return __builtin_amdgcn_readfirstlane((int)(vb * (uint32_t)waves_per_wg + (threadIdx.x >> 6)));
 }
 
+// ---- dispatch order of the NEXT step (ARCLE_STEPX_ORDERED launches of arcle_step_many) -------------------------------------
+// A launch of one wave per env ends with its last object operation: the hardware starts the 8192 waves over ~2 us (every XCD works
+// through its workgroups in index order) and a Move / Rotate / Flip wave lives ~1.2 us longer than the others, so a launch whose late
+// slots hold object ops ends ~0.6 us after one whose EARLY slots hold them (tools/lptbench.py: 5.33 vs 4.71 us).  arcle_step_many
+// knows the next step's op array while a step runs (the caller handed over K steps of actions), so the first workgroup on every
+// XCD of launch t partitions that XCD's slot range for launch t+1: with L object ops among the rs slots, the object ops that sit
+// in slots >= L trade places with the other ops sitting in slots < L (k-th with k-th) — afterwards slots [0, L) hold the object ops.
+// The table maps slot -> env and is a permutation of the XCD's own env range (L2 affinity is kept).  It is scheduling only: whatever
+// the table holds, every env is stepped exactly once, and a caller that rewrites the next actions after this ran loses nothing
+// but the ordering.
+#define ARCLE_ORD_BLOCKS 8u    // one per XCD: workgroup b < 8 runs on XCD b
+#define ARCLE_ORD_MAX_SLOTS 1024u  // slots per XCD this pass handles (2 per thread of a 512-thread workgroup): N <= 8192
+__device__ __forceinline__ void order_next_step(const StepParams& p, uint32_t xcd, uint32_t rs) {
+  __shared__ uint32_t cnt[16];
+  __shared__ uint32_t long_before_L;
+  __shared__ uint16_t early_other[ARCLE_ORD_MAX_SLOTS], late_long[ARCLE_ORD_MAX_SLOTS], slot_of[ARCLE_ORD_MAX_SLOTS];
+  const uint32_t t = threadIdx.x, wave = t >> 6, base = xcd * rs;
+  const uint32_t s0 = t, s1 = t + 512u;
+  bool lg0 = false, lg1 = false;
+  if (s0 < rs) {
+    const uint32_t o = (uint32_t)p.next_op[(size_t)(base + s0) * (size_t)p.next_op_stride];
+    lg0 = (p.long_mask >> (o < 63u ? o : 63u)) & 1ull;
+  }
+  if (s1 < rs) {
+    const uint32_t o = (uint32_t)p.next_op[(size_t)(base + s1) * (size_t)p.next_op_stride];
+    lg1 = (p.long_mask >> (o < 63u ? o : 63u)) & 1ull;
+  }
+  const unsigned long long b0 = __ballot(lg0), b1 = __ballot(lg1);
+  if ((t & 63u) == 0) {
+    cnt[wave] = (uint32_t)__popcll(b0);
+    cnt[8 + wave] = (uint32_t)__popcll(b1);
+  }
+  slot_of[s0] = (uint16_t)s0;
+  slot_of[s1] = (uint16_t)s1;
+  __syncthreads();
+  uint32_t before0 = 0, before1 = 0, L = 0;  // object ops in the slots before s0 / s1, and among all rs slots
+#pragma unroll
+  for (uint32_t c = 0; c < 16; c++) {
+    const uint32_t v = cnt[c];
+    if (c < wave) before0 += v;
+    if (c < 8 + wave) before1 += v;
+    L += v;
+  }
+  before0 += __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
+  before1 += __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+  if (s0 == L) long_before_L = before0;
+  if (s1 == L) long_before_L = before1;
+  __syncthreads();
+  const uint32_t pl = L < rs ? long_before_L : L;  // object ops already inside [0, L)
+  const uint32_t n_swap = L - pl;                  // = object ops in [L, rs) = other ops in [0, L)
+  if (s0 < rs) {
+    if (s0 < L && !lg0) early_other[s0 - before0] = (uint16_t)s0;
+    if (s0 >= L && lg0) late_long[before0 - pl] = (uint16_t)s0;
+  }
+  if (s1 < rs) {
+    if (s1 < L && !lg1) early_other[s1 - before1] = (uint16_t)s1;
+    if (s1 >= L && lg1) late_long[before1 - pl] = (uint16_t)s1;
+  }
+  __syncthreads();
+  for (uint32_t k = t; k < n_swap; k += 512u) {
+    const uint16_t a = early_other[k], b = late_long[k];
+    slot_of[a] = b;
+    slot_of[b] = a;
+  }
+  __syncthreads();
+  if (s0 < rs) p.order_next[base + s0] = base + slot_of[s0];
+  if (s1 < rs) p.order_next[base + s1] = base + slot_of[s1];
+}
+
 // ING: selection ingress form; FW: arcle::FW_* grid-width class;
 // ACCT: 1 = add the step's algorithmic bytes to p.acct[env]; FEAT: 1 = carries the ARCLE_STEP_FEATURE_FLAGS code
 // WC: 30 = the launch's grid is the standard 30 x 30 (H, W, P, plane stride and the division constant are compile-time
 // constants: every clamp, row/column split and rectangle mask folds), 0 = read from the arguments
 template <int ING, int FW, int ACCT, int FEAT, int FL = -1, int WC = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(
-    const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel, int n_envs, int wpw, uint32_t nb8, const StepParams pa) {
+    const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel, const uint32_t* order, int n_envs, int wpw_front, uint32_t nb8,
+    const StepParams pa) {
+  // (wpw_front: waves per workgroup | front workgroups that do not step envs << 8 — ordered-dispatch launches only)
+  const int wpw = (FL >= 0 && (FL & ARCLE_STEPX_ORDERED)) ? (wpw_front & 0xff) : wpw_front;
   StepParams p = pa;  // (a register-promoted copy: only the fields a path reads are ever fetched)
   if (WC == 30) {
     p.H = p.W = 30;
@@ -226,7 +298,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   // (at the FRONT of the grid: the copy waves start first and their PCIe round trips run under the whole launch — 6.9 us per step at
   // 8192 envs; placed at the end of the grid they start last and the launch waits for them: 8.1 us, profiles/round3_experiments.txt)
   const bool pf_role = ING == arcle::INGRESS_BBOX5_PF && blockIdx.x < ARCLE_PF_BLOCKS;
-  const uint32_t pf_first = 0, pf_off = ING == arcle::INGRESS_BBOX5_PF ? ARCLE_PF_BLOCKS : 0u;
+  uint32_t pf_first = 0, pf_off = ING == arcle::INGRESS_BBOX5_PF ? ARCLE_PF_BLOCKS : 0u;
+  constexpr bool ORD = FL >= 0 && (FL & ARCLE_STEPX_ORDERED) != 0;
+  if (ORD) {  // (as above: at the front of the grid, one workgroup on every XCD; their number travels in a preloaded argument)
+    pf_off = (uint32_t)wpw_front >> 8;
+    if (blockIdx.x < pf_off) {
+      order_next_step(pa, blockIdx.x, nb8 * (uint32_t)wpw);
+      return;
+    }
+  }
   if (pf_role) {
     // The first workgroups of the launch are a copy engine: they move the NEXT step's action records from pinned host memory into the
     // device staging buffer that step will read (arcle_step_many over host-resident records).  The PCIe round trips of these few
@@ -252,6 +332,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = (int)__builtin_elementwise_min((uint32_t)wv, (uint32_t)n_envs - 1u);  // (surplus waves load env N-1's inputs and leave)
   arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0);
+  // ordered dispatch: the slot's table entry is requested beside the inputs of the env in the same position — most slots keep it
+  uint32_t slot_env = (uint32_t)env;
+  if (ORD) slot_env = xl::uload1(arcle::at(order, 4u * (uint32_t)env));
   arcle::StepInputs in = arcle::load_inputs<ING>(w, env, rec, cnt, op, sel);  // in flight while the expansion table is built
   // (the always-true scalar test keeps a block boundary between the loads and the barrier: with straight-line code here the
   // optimiser sinks the four loads below the barrier — into the only block that uses them — and their latency is exposed)
@@ -261,10 +344,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #if ARCLE_STOP_AT == 1
   return;
 #endif
+  int my_env = env;
+  if (ORD && slot_env != (uint32_t)env) {  // a traded slot: one more round trip for the other env's inputs
+    my_env = (int)slot_env;
+    in = arcle::load_inputs<ING>(w, my_env, rec, cnt, op, sel);
+  }
 #ifdef ARCLE_TRACE_WAVES
-  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in, t_entry, xl::clock());
+  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, t_entry, xl::clock());
 #else
-  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in);
+  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in);
 #endif
 }
 
@@ -377,6 +465,12 @@ struct arcle_env {
   int32_t* d_stage;           // int32 [2][n_envs][5]: staging of host-resident action records (arcle_step_many), allocated on first use
   const int32_t* pf_next;     // set by arcle_step_many around a launch: the next step's host records / the staging buffer to fill
   int32_t* pf_stage;
+  uint32_t* d_order;          // uint32 [3][n_envs]: dispatch-order tables of arcle_step_many (two alternating + the identity), first use
+  int order_enabled;          // arcle_set_dispatch_order (default 1)
+  const uint32_t* ord_cur;    // set by arcle_step_many around a launch: this step's table, the one to fill, the next step's ops
+  uint32_t* ord_next;
+  const int32_t* ord_next_op;
+  int32_t ord_next_stride;
   int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
   uint32_t* d_acct;
   uint64_t acct_steps;
@@ -414,6 +508,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   arcle_env* e = new (std::nothrow) arcle_env();
   if (!e) return ARCLE_ERR_ARG;
   memset(e, 0, sizeof(*e));
+  e->order_enabled = 1;
   e->cfg = *cfg;
   int caller_dev = 0;
   (void)hipGetDevice(&caller_dev);
@@ -506,6 +601,7 @@ extern "C" int arcle_destroy(arcle_env* e) {
   for (int i = 0; i < e->n_retired; i++) (void)hipFree(e->retired_ops[i]);
   if (e->d_dense_cache) (void)hipFree(e->d_dense_cache);
   if (e->d_stage) (void)hipFree(e->d_stage);
+  if (e->d_order) (void)hipFree(e->d_order);
   if (e->d_acct) (void)hipFree(e->d_acct);
   delete e;
   return ARCLE_OK;
@@ -562,6 +658,11 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
     e->base.d_ops = fresh;
   }
   e->base.n_ops = n_ops;
+  e->base.long_mask = 0;  // the operations whose waves run longest (ordered dispatch of arcle_step_many)
+  for (int i = 0; i < n_ops && i < 63; i++) {
+    const uint32_t k = ARCLE_OP_KIND(descs[i]);
+    if (k == ARCLE_OP_MOVE || k == ARCLE_OP_ROTATE || k == ARCLE_OP_FLIP) e->base.long_mask |= 1ull << i;
+  }
   return ARCLE_OK;
 }
 
@@ -631,7 +732,7 @@ static int width_class(const StepParams& p) {
   if (p.W < 16 || p.W > 32) return arcle::FW_GENERIC;
   return p.PS == ARCLE_MAX_CELLS ? arcle::FW_FULL : arcle::FW_FAST;
 }
-#define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p
+#define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw, g.x >> 3, p
 #define LAUNCH_STEP(...) hipLaunchKernelGGL((arcle_step_kernel<__VA_ARGS__>), g, b, 0, st, STEP_ARGS)
 // the flag combination ARCVecEnv steps with (next-step autoreset, elided zero-fill of `selected`) has its own instantiation
 // with the flags as a compile-time constant
@@ -654,6 +755,10 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
     if (!acct && research_shape(p)) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 1, RESEARCH_FL, 30);
     else if (!acct && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 1, RESEARCH_INC_FL, 30);
     else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 1);
+  } else if (p.flags == (uint32_t)HOT_FLAGS && p.order && p.wpw == WAVES_PER_WG) {
+    const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));
+    hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, 0, st,
+                       (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);
   } else if (p.flags == (uint32_t)HOT_FLAGS) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS, 30);
   else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, -1, 30);
   return ARCLE_OK;
@@ -668,7 +773,15 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
         if (p.flags == (uint32_t)HOT_FLAGS && p.next_sel && p.wpw == WAVES_PER_WG) {  // records prefetched by the launch's front workgroups
           const dim3 gp(g.x + ARCLE_PF_BLOCKS);
           hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX5_PF, FW, 0, 0, HOT_FLAGS, 30>), gp, b, 0, st, (const int8_t*)p.rec,
-                             (const int32_t*)p.cnt, p.op, p.sel, p.n_envs, p.wpw, g.x >> 3, p);
+                             (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw, g.x >> 3, p);
+          return;
+        }
+      }
+      if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
+        if (p.flags == (uint32_t)HOT_FLAGS && p.order && p.wpw == WAVES_PER_WG) {  // arcle_step_many: waves take their env from the order table
+          const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));
+          hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, 0, st, (const int8_t*)p.rec,
+                             (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);
           return;
         }
       }
@@ -715,6 +828,10 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.rmask = nullptr;
   p.next_sel = e->pf_next;
   p.stage_out = e->pf_stage;
+  p.order = e->ord_cur;
+  p.order_next = e->ord_next;
+  p.next_op = e->ord_next_op;
+  p.next_op_stride = e->ord_next_stride;
   // workgroups of 8 waves while the batch is one occupancy round or two (7.3 vs 7.7 us per launch at 8192 envs), 4 waves in
   // the streaming regime (76-79 vs 85-88 us at 131072 envs): in-box A/B, profiles/round2_experiments.txt
   const int wpw = p.n_envs >= 65536 ? 4 : WAVES_PER_WG;
@@ -782,6 +899,26 @@ static size_t payload_bytes(const arcle_env* e, int ingress) {
   }
 }
 
+// the three dispatch-order tables of arcle_step_many (two alternating by step parity + the identity step 0 runs with)
+static bool ensure_order_tables(arcle_env* e) {
+  if (e->d_order) return true;
+  DeviceGuard guard(e->device);
+  const size_t n = (size_t)e->cfg.n_envs;
+  uint32_t* ident = new (std::nothrow) uint32_t[n];
+  bool ok = ident && hipMalloc((void**)&e->d_order, 3 * n * sizeof(uint32_t)) == hipSuccess;
+  if (ok) {
+    for (size_t i = 0; i < n; i++) ident[i] = (uint32_t)i;
+    ok = hipMemcpy(e->d_order + 2 * n, ident, n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) (void)hipFree(e->d_order);
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    e->d_order = nullptr;
+  }
+  delete[] ident;
+  return ok;
+}
+
 extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
                                uint8_t* term, uint32_t flags, void* stream) {
   if (!e) return ARCLE_ERR_ARG;
@@ -814,8 +951,38 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
       }
     }
   }
+  // Ordered dispatch (device-resident bbox + op arrays or 5-tuple records, the lean 30 x 30 instantiation): launch t's front workgroups
+  // sort step t+1's slots — object operations first — from that step's op array; see order_next_step.
+  const uint32_t slots = grid_for((int)n, WAVES_PER_WG).x * (uint32_t)WAVES_PER_WG;
+  bool ordered = e->order_enabled && pf_kernel && !prefetch && n_steps > 1 && sel && (size_t)slots == n && slots / 8u <= ARCLE_ORD_MAX_SLOTS &&
+                 ((ingress == arcle::INGRESS_BBOX && op) || ingress == arcle::INGRESS_BBOX5);
+  if (ordered && ingress == arcle::INGRESS_BBOX5) {  // (host-resident records take the prefetch path above, or none)
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, sel) != hipSuccess || attr.type != hipMemoryTypeDevice) ordered = false;
+    (void)hipGetLastError();
+  }
+  if (ordered && !e->d_order) {  // (allocated like the staging buffer: by the first call outside a stream capture, or by arcle_set_dispatch_order)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      ordered = false;
+    } else if (!ensure_order_tables(e)) {
+      ordered = false;
+    }
+  }
   int rc = ARCLE_OK;
   for (int32_t t = 0; t < n_steps && rc == ARCLE_OK; t++) {
+    if (ordered) {
+      e->ord_cur = t == 0 ? e->d_order + 2 * n : e->d_order + (size_t)(t & 1) * n;  // (step 0: the identity; nobody looked ahead for it)
+      e->ord_next = t + 1 < n_steps ? e->d_order + (size_t)((t + 1) & 1) * n : nullptr;
+      if (ingress == arcle::INGRESS_BBOX5) {
+        e->ord_next_op = (const int32_t*)((const char*)sel + (size_t)(t + 1) * pb) + 4;
+        e->ord_next_stride = 5;
+      } else {
+        e->ord_next_op = op + (size_t)(t + 1) * n;
+        e->ord_next_stride = 1;
+      }
+    }
     const void* src = (const char*)sel + (size_t)t * pb;
     if (prefetch) {
       if (t > 0) src = e->d_stage + (size_t)(t & 1) * n * 5;
@@ -827,7 +994,18 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
   }
   e->pf_next = nullptr;
   e->pf_stage = nullptr;
+  e->ord_cur = nullptr;
+  e->ord_next = nullptr;
+  e->ord_next_op = nullptr;
   return rc;
+}
+
+extern "C" int arcle_set_dispatch_order(arcle_env* e, int enable) {
+  if (!e) return ARCLE_ERR_ARG;
+  e->order_enabled = enable ? 1 : 0;
+  // (enabling allocates the tables now: a later arcle_step_many inside a stream capture cannot)
+  if (enable && !ensure_order_tables(e)) return fail(e, ARCLE_ERR_HIP, "could not allocate the dispatch-order tables");
+  return ARCLE_OK;
 }
 
 extern "C" int arcle_pack_mask_bits(arcle_env* e, const int8_t* sel, uint8_t* bits, void* stream) {
@@ -1186,6 +1364,17 @@ extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
     HIP_TRY(e, hipFree(e->d_acct));
     e->d_acct = nullptr;
   }
+  return ARCLE_OK;
+}
+
+// (test hook, not part of include/arcle_hip.h: the dispatch-order tables arcle_step_many last wrote — [0], [1] alternate by step
+// parity, [2] is the identity — so that tests can check them against the op arrays)
+extern "C" int arcle_debug_copy_order(arcle_env* e, uint32_t* host_out) {
+  if (!e || !host_out) return ARCLE_ERR_ARG;
+  if (!e->d_order) return fail(e, ARCLE_ERR_CONFIG, "no dispatch-order tables (no ordered arcle_step_many call yet)");
+  DeviceGuard guard(e->device);
+  HIP_TRY(e, hipDeviceSynchronize());
+  HIP_TRY(e, hipMemcpy(host_out, e->d_order, 3 * (size_t)e->cfg.n_envs * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return ARCLE_OK;
 }
 

@@ -45,6 +45,8 @@ enum { INGRESS_MASK = 0,    // int8 [N][P] selection masks as given (action['sel
 #define ARCLE_BITS_STRIDE (ARCLE_MAX_CELLS / 8)
 // launcher-internal bit of a compile-time flag set (FL template parameter): the fused flat rows are the FilterO2ARC subset
 #define ARCLE_STEPX_FLAT_FILTERED 0x10000
+// ... and that its waves take their env from a dispatch-order table (arcle_step_many: longest operations first, see the kernel)
+#define ARCLE_STEPX_ORDERED 0x20000
 // row strides of the 30 x 30 lean instantiations: 3*900 + 10 and 7*900 + 14, rounded up to 16
 #define ARCLE_ROW30_FILTERED_STRIDE 2720
 #define ARCLE_ROW30_FULL_STRIDE 6320
@@ -105,6 +107,12 @@ struct StepParams {
   int32_t* dense_cache;    // library-owned int32 [N][2]: the dense pair of the env's CURRENT grid, (0, 0) = unknown (see step_core)
   const int32_t* next_sel; // INGRESS_BBOX5_PF: the NEXT step's records (pinned host memory, int32 [N][5]) ...
   int32_t* stage_out;      // ... and the device staging buffer the front workgroups copy them into while this step runs
+  // ---- ordered dispatch (ARCLE_STEPX_ORDERED instantiations, arcle_step_many) ----
+  const uint32_t* order;   // uint32 [N]: the env the wave in dispatch slot s steps (a permutation inside every XCD's slot range)
+  uint32_t* order_next;    // table the launch's front workgroups fill for the NEXT step (NULL: last step)
+  const int32_t* next_op;  // the next step's op indices: element s at next_op[s * next_op_stride]
+  int32_t next_op_stride;  // 1 (op arrays) / 5 (the op field of BBoxWrapper records)
+  uint64_t long_mask;      // bit i: op table slot i is an object operation (Move / Rotate / Flip: the longest-running waves)
 };
 
 // 16 bytes of a plane = 4 VGPRs; a first-class vector value so that it always lives in registers
@@ -1349,6 +1357,9 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   static_assert(ARCLE_OPF_KEEP_SEL == 2u, "bit 1");
   s.sel_pending = (oflags & ARCLE_OPF_KEEP_SEL) | (zero_selected ? 1u : 0u);
 
+#ifdef ARCLE_EXP_PRIO
+  if (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP) __builtin_amdgcn_s_setprio(ARCLE_EXP_PRIO);
+#endif
   switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
     case ARCLE_OP_COLOR: {  // color.py:70-74 — whole HxW plane, grid_dim ignored
       if (sel.any_nz) {

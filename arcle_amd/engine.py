@@ -305,6 +305,10 @@ class EnvBatch:
                                            self._stream()), "arcle_step_many")
         return reward, term
 
+    def set_dispatch_order(self, enable=True):
+        """arcle_step_many's ordered dispatch (object operations handed to the waves that start first; scheduling only) on / off."""
+        self._check(self.L.arcle_set_dispatch_order(self._h, 1 if enable else 0), "arcle_set_dispatch_order")
+
     def step_bbox_ptr(self, bbox_ptr, op_ptr, flags=0, stream=0):
         """Lowest-overhead launch for rollout loops: raw device addresses (ints) of an int32 [N,4] bbox array
         and an int32 [N] op array, explicit stream handle.  Outputs land in self.reward / self.term."""

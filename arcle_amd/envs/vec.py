@@ -506,6 +506,7 @@ class ARCVecEnv:
         self._check_many(form, payload, operation)
         K = int(payload.shape[0])
         reward, term, trunc, dense = self._many_buffers(K)
+        self.batch.set_dispatch_order(True)  # (allocates the dispatch-order tables now: inside the capture the library cannot)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         g = torch.cuda.CUDAGraph()

@@ -266,7 +266,17 @@ int arcle_pack_mask_bits(arcle_env* env, const int8_t* sel, uint8_t* bits, void*
  * For the standard 30 x 30 batch stepped with ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED the library then pipelines the PCIe
  * traffic: eight extra workgroups at the front of launch t copy step t+1's records into a device staging buffer while launch t
  * runs, and step t+1 reads them from HBM (only step 0 reads across PCIe itself).  The staging buffer (2 x 20 B per env) is allocated
- * by the first such call made outside a stream capture. */
+ * by the first such call made outside a stream capture.
+ * Ordered dispatch: a launch of one wave per env ends with its last Move / Rotate / Flip wave (they run ~1.2 us longer than the other
+ * operations' waves, and the hardware starts the waves of a launch over ~2 us).  With device-resident BBOX + op arrays or BBOX5
+ * records, the same 30 x 30 batch and flags, n_envs a multiple of 64 and <= 8192, one extra workgroup per XCD at the front of
+ * launch t reads step t+1's op indices and writes the order in which launch t+1 hands envs to its waves: object operations to the
+ * waves that start first (a permutation inside every XCD's env range; 12 B per env of tables, allocated by the first such call
+ * outside a stream capture).  It is scheduling only — results, outputs and their order in memory are exactly those of n_steps
+ * arcle_step_* calls, and a caller that rewrites step t+1's actions while step t runs loses nothing but the ordering.
+ * arcle_set_dispatch_order(env, 0) turns it off (default on); (env, 1) also allocates the tables at once — call it before capturing
+ * arcle_step_many into a hipGraph on a handle that has not run an ordered arcle_step_many yet. */
+int arcle_set_dispatch_order(arcle_env* env, int enable);
 int arcle_step_many(arcle_env* env, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
                     uint8_t* term, uint32_t flags, void* stream);
 

@@ -576,3 +576,64 @@ def test_vec_transition_in_place_walks_trajectories():
         v.step_bbox(bb[i], op[i])
     assert torch.equal(v.state_rows(), walk[:, :rows0.shape[1]])
     v.check_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8192, 1024, 960])
+def test_step_many_ordered_dispatch_is_scheduling_only(n):
+    """arcle_step_many's ordered dispatch (launch t sorts step t+1's dispatch slots from that step's op array, object operations
+    first): rewards, terminated flags and every byte of state equal the unordered run — bbox + op arrays and 5-tuple records, eager
+    and replayed as a hipGraph with the action buffers rewritten in between, bad op indices included; the table itself is a
+    permutation of every XCD's env range with the object ops in the lowest slots.  (n = 960 is not a multiple of 64: the library
+    steps it unordered, silently.)"""
+    import ctypes
+    import torch
+    import bench
+    K = 30
+    dev = torch.device("cuda:0")
+    bb_np, op_np = bench.make_actions(K, n, 123)
+    op_np = op_np.copy()
+    op_np[3, ::97] = 35 + (np.arange(len(op_np[3, ::97])) % 40)  # indices past the table (raise ARCLE_ST_BAD_OP, step skipped)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    act5 = torch.cat([bb, op[:, :, None]], 2).contiguous()
+    for form, pay, o in (("bbox", bb, op), ("bbox5", act5, None)):
+        a, b = bench.make_batch(dev, n, seed=9), bench.make_batch(dev, n, seed=9)
+        a.set_dispatch_order(False)
+        b.set_dispatch_order(True)
+        FL = a.elide_flag | 1
+        ra, ta = a.step_many(form, pay, o, FL)
+        rb, tb = b.step_many(form, pay, o, FL)
+        torch.cuda.synchronize()
+        assert torch.equal(ra, rb) and torch.equal(ta, tb), form
+        for k in a.planes:
+            assert torch.equal(a.planes[k], b.planes[k]), (form, k)
+        assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt) and a.status() == b.status() == 1, form  # (1 = ARCLE_ST_BAD_OP)
+        if n % 64 == 0:  # the table launch K-2 wrote for step K-1
+            tab = np.zeros((3, n), np.uint32)
+            b.L.arcle_debug_copy_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            assert b.L.arcle_debug_copy_order(b._h, tab.ctypes.data) == 0
+            t, rs = tab[(K - 1) & 1].astype(np.int64), n // 8
+            lg = (op_np[K - 1] >= 20) & (op_np[K - 1] < 28)
+            assert (tab[2] == np.arange(n)).all()
+            for x in range(8):
+                seg = t[x * rs:(x + 1) * rs]
+                assert sorted(seg.tolist()) == list(range(x * rs, (x + 1) * rs)), f"XCD {x}: not a permutation of its env range"
+                L = int(lg[x * rs:(x + 1) * rs].sum())
+                assert lg[seg[:L]].all() and not lg[seg[L:]].any(), f"XCD {x}: object ops are not in the first {L} slots"
+            assert (t != np.arange(n)).any()
+        # replayed as a graph, with new actions written into the captured buffers between replays
+        g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=st):
+            b.step_many(form, pay, o, FL, rb, tb)
+        for seed in (124, 125):
+            bb2, op2 = bench.make_actions(K, n, seed)
+            bb.copy_(torch.from_numpy(bb2)), op.copy_(torch.from_numpy(op2))
+            if form == "bbox5":
+                act5.copy_(torch.cat([bb, op[:, :, None]], 2))
+            ra, ta = a.step_many(form, pay, o, FL)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(ra, rb) and torch.equal(ta, tb), (form, seed)
+            assert torch.equal(a.planes["grid"], b.planes["grid"]) and torch.equal(a.rec, b.rec), (form, seed)
+        bb.copy_(torch.from_numpy(bb_np)), op.copy_(torch.from_numpy(op_np))

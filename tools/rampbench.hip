@@ -55,6 +55,8 @@ int main() {
     run<10240, 40, 64>("WG64  lds10K vgpr~48", d, n);
     run<2560, 40, 64>("WG64  lds2.5K vgpr~48", d, n);
     run<10240, 40, 1024>("WG1024 lds10K vgpr~48", d, n);
+    run<18432, 40, 512>("WG512 lds18K vgpr~48", d, n);
+    run<0, 0, 512>("WG512 lds0 vgpr~8", d, n);
     run<0, 40, 64>("WG64  lds0 vgpr~48", d, n);
     run<0, 100, 256>("WG256 lds0 vgpr~104", d, n);
   }

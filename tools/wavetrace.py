@@ -36,6 +36,18 @@ for rep in range(3):
     ops = on[K - 1]
     print(f"rep {rep}: last start {st.max():.2f} us, last end {en.max():.2f} us; lifetime mean {life.mean():.2f} "
           f"p50 {np.median(life):.2f} p90 {np.percentile(life,90):.2f} max {life.max():.2f}")
+    nb = n // 8
+    vb = np.arange(n) // 8
+    blk = (vb % (nb // 8)) * 8 + vb // (nb // 8)  # inverse of vb = (b & 7) * (nb / 8) + (b >> 3): the workgroup index an env's wave ran in
+    order = np.argsort(blk, kind="stable")
+    chunks = np.array_split(st[order], 8)
+    print("   start by workgroup-index octile (us, mean): " + " ".join(f"{c.mean():.2f}" for c in chunks) + f"   corr(start, wg index) = {np.corrcoef(st, blk)[0, 1]:.3f}")
+    xcd, pos = blk % 8, blk // 8
+    print("   start mean by XCD (wg index % 8): " + " ".join(f"{st[xcd == x].mean():.2f}" for x in range(8)) +
+          "   corr(start, position in the XCD's sequence) per XCD: " + " ".join(f"{np.corrcoef(st[xcd == x], pos[xcd == x])[0, 1]:.2f}" for x in range(8)))
+    x0 = xcd == 0
+    ch = np.array_split(st[x0][np.argsort(pos[x0], kind="stable")], 16)
+    print("   XCD 0, start by position 1/16ths (mean / min / max): " + " ".join(f"{c.mean():.2f}/{c.min():.2f}/{c.max():.2f}" for c in ch))
     print("   start percentiles (us): " + " ".join(f"p{q}={np.percentile(st,q):.2f}" for q in (10, 50, 90, 99)))
     print("   end   percentiles (us): " + " ".join(f"p{q}={np.percentile(en,q):.2f}" for q in (10, 50, 90, 99)))
     print("   phases mean (us): table+barrier %.2f | inputs landed %.2f | op %.2f | epilogue %.2f" % tuple(ph.mean(0)))
