@@ -6,9 +6,13 @@
         bench.py --gpus N --steps K --warmup W
 (`python bench.py --gpus N` without a launcher spawns the N ranks itself.)
 
-A "step" is ONE pass of the hot path over one batch: a single `arcle_step_bbox` launch that applies one (selection,
+A "step" is ONE pass of the hot path over one batch: a single launch of the step kernel that applies one (selection,
 operation) action to every env of this GPU.  Tasks, state and the whole action stream are resident in HBM before the
-timed region starts.  Envs are independent, so N GPUs = N shards, no data-path collective (weak scaling); rank 0
+timed region starts.  c3 enqueues a region's K launches with ONE `arcle_step_many` call (what `ARCVecEnv.capture` records): the
+library then knows the next step's op array while a step runs, and every launch's eight front workgroups sort the next launch's
+dispatch slots — Move / Rotate / Flip to the waves that start first — which shortens the launch's tail (scheduling only: the same
+K launches with the same results; `--no-ordered` enqueues them call by call, and `timing.per_step_calls` times that form beside
+the headline in every run).  Envs are independent, so N GPUs = N shards, no data-path collective (weak scaling); rank 0
 prints ONE JSON line.  Workloads (`config.workload` names the one that ran):
   c3 (default, the headline: BASELINE configs[2])  O2ARCv2Env 30x30, 8192 envs/GPU, 35 ops uniform, BBox 5-tuples
       uniform, on-device auto-reset of terminated envs
@@ -710,6 +714,8 @@ def main():
     ap.add_argument("--regions", type=int, default=0, help="timed regions of K steps (default: 5, more for small K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-headline legs (kernel A/B runs)")
+    ap.add_argument("--no-ordered", action="store_true", help="enqueue the region's K launches one arcle_step_bbox call at a time instead of one "
+                    "arcle_step_many call (whose launches sort the next step's dispatch slots, object operations first)")
     ap.add_argument("--no-graph", action="store_true", help="launch the K steps of a region eagerly instead of as one hipGraph")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp launches (counter-collection runs)")
     a = ap.parse_args()
@@ -840,7 +846,14 @@ def main():
     # The K steps of a region are captured once into a hipGraph (K launches of arcle_step_kernel, each with its own
     # action batch) and replayed per region: a launch-bound inner loop belongs in a graph, and the host then issues one
     # call per region instead of K.  (With more than one rank c4 keeps eager launches: its collective is not captured.)
+    # c3: the region is ONE arcle_step_many call (what ARCVecEnv.capture records): the library holds the K steps' actions, and every
+    # launch's front workgroups sort the NEXT step's dispatch slots from its op array — object operations to the waves that start
+    # first (scheduling only: same launches, same results).  The same K launches enqueued one arcle_step_bbox call at
+    # a time (no look at the next step's actions) are captured into a second graph and timed beside it: timing.per_step_calls.
     graph = None
+    graph_calls = None
+    many = a.config == "c3" and gather is None and not a.no_ordered and K > 1
+    many_out = (torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)) if many else None
     if not a.no_graph and not (gather is not None and shared_gpu):
         try:
             graph = torch.cuda.CUDAGraph()
@@ -848,10 +861,20 @@ def main():
             cap.wait_stream(stream)
             if gather is not None:
                 done[0] = done[1] = None
+            if many:
+                batch.set_dispatch_order(True)  # (allocates the order tables: inside a capture the library cannot)
+                graph_calls = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_calls, stream=cap):
+                    cs = torch.cuda.current_stream(dev)
+                    for i in range(Wm, Wm + K):
+                        step(i, cs.cuda_stream, cs)
             with torch.cuda.graph(graph, stream=cap):
                 cs = torch.cuda.current_stream(dev)
-                for i in range(Wm, Wm + K):  # (c4 with a process group: the RCCL collectives are captured as well, on the forked side stream)
-                    step(i, cs.cuda_stream, cs)
+                if many:
+                    batch.step_many("bbox", bbox[Wm:Wm + K], op[Wm:Wm + K], FL, many_out[0], many_out[1])
+                else:
+                    for i in range(Wm, Wm + K):  # (c4 with a process group: the RCCL collectives are captured as well, on the forked side stream)
+                        step(i, cs.cuda_stream, cs)
                 join_side(cs)
             if gather is not None:
                 done[0] = done[1] = None
@@ -864,6 +887,8 @@ def main():
     def region(r):
         if graph is not None:
             graph.replay()
+        elif many:
+            batch.step_many("bbox", bbox[Wm:Wm + K], op[Wm:Wm + K], FL, many_out[0], many_out[1])
         else:
             for i in range(Wm + r * K, Wm + (r + 1) * K):
                 step(i)
@@ -903,6 +928,24 @@ def main():
         devt.append(ev0.elapsed_time(ev1) * 1e-3)
         kern.append(devt[-1] / K)
     host_ms = [round(x * 1e3, 4) for x in wall][:12]
+    per_step_calls = None
+    if graph_calls is not None:  # the same K launches, enqueued call by call (untimed for the headline; same event clock)
+        ts = []
+        for r in range(min(R, 7)):
+            for k, v in snap.items():
+                batch.planes[k].copy_(v)
+            batch.rec.copy_(snap_rec)
+            batch.cnt.copy_(snap_cnt)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            ev0.record(stream)
+            graph_calls.replay()
+            ev1.record(stream)
+            wait_gpu(ev1)
+            ts.append(ev0.elapsed_time(ev1) * 1e-3)
+        t_calls = float(np.median(ts))
+        per_step_calls = {"us_per_step_batch": t_calls / K * 1e6, "value": K * n / t_calls, "unit": "env-steps/s (this rank)",
+                          "launch": "hipGraph of K arcle_step_bbox calls: every launch hands envs to its waves in index order"}
     wall_t = torch.tensor(devt if device_clock else wall, dtype=torch.float64)
     if dist is not None:  # max over ranks, per region
         wt = wall_t if shared_gpu else wall_t.to(dev)
@@ -926,11 +969,11 @@ def main():
         if gather is not None:
             batch.set_packed_output(packed2[0])
 
-        def replay_region0(sh_):
+        def replay_region0(sh_):  # (the accounting instantiation hands out envs in index order: the bytes do not depend on the order)
             for i in range(Wm, Wm + K):
                 batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, sh_)
         per_launch_bytes, issued_bytes, _ = counted_bytes(batch, replay_region0, K, dev)
-        kname = {"c3": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>",
+        kname = {"c3": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|ordered, 30>" if many else "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>",
                  "c4": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|pack, 30> (fused packed-row epilogue; a multi-rank run has the all-gather inside the event pair)"}.get(a.config, "arcle_step_kernel")
         roofline = roofline_block(kname, kernel_avg_s, per_launch_bytes, issued_bytes, n, PS=batch.PS, planes=len(batch.planes),
                                   note="algorithmic bytes follow SURVEY.md 8d and include the reset_sel zero-fills of `selected` that "
@@ -960,7 +1003,9 @@ def main():
             "timing": {"regions": R, "stat": "median region, max over ranks per region",
                        "clock": "HIP events on the launch stream, recorded between the region's two synchronisations" if device_clock else "host perf_counter between the region's two synchronisations",
                        "host_region_ms": host_ms,
-                       "launch": "hipGraph of the K step launches, one replay per region" if graph is not None else "eager",
+                       "launch": ("hipGraph of ONE arcle_step_many call (K step launches; launch t orders step t+1's dispatch slots from its op array), one replay per region"
+                                  if many else "hipGraph of the K step launches, one replay per region") if graph is not None else "eager",
+                       "per_step_calls": per_step_calls,
                        "region_ms": [round(float(x) * 1e3, 4) for x in wall_t.tolist()][:12]},
             "roofline": roofline,
         }
