@@ -31,8 +31,26 @@ def swapped(tl, te):
             a, b = late[:k], early[:k]
             o[a], o[b] = o[b].copy(), o[a].copy()
     return out
+def xcd_weighted(weights):
+    # object ops first inside every XCD, and dealt to the XCDs in proportion to `weights` (the XCDs start up to 0.7 us apart)
+    out = np.empty_like(op_np)
+    w = np.asarray(weights, float); w = w / w.sum()
+    for s in range(K):
+        o = op_np[s]
+        lg = o[cost[o] > 0]; sh = o[cost[o] == 0]
+        lg = lg[np.argsort(-cost[lg], kind="stable")]
+        quota = np.floor(w * len(lg)).astype(int); quota[0] += len(lg) - quota.sum()
+        li = si = 0
+        for x in range(8):
+            m = np.nonzero(xcd == x)[0]
+            m = m[np.argsort(pos[m], kind="stable")]
+            q = quota[x]
+            out[s, m[:q]] = lg[li:li + q]; li += q
+            out[s, m[q:]] = sh[si:si + len(m) - q]; si += len(m) - q
+    return out
 def variant(v):
     if v == 0: return op_np
+    if v >= 8: return xcd_weighted([(1, 1, 1, 1, 0, 0, 1, 1), (1.2, 1.1, 1, 1, 0.6, 0.6, 0.9, 0.9), (1.5, 1.3, 1.1, 1, 0.3, 0.3, 0.8, 0.8)][v - 8])
     if v >= 3: return swapped(*[(64, 64), (48, 48), (32, 32), (64, 32), (96, 64)][v - 3])
     out = np.empty_like(op_np)
     slots = np.argsort(pos if v == 1 else -pos, kind="stable")     # v=1: long ops first; v=2: long ops LAST (the worst case)
@@ -41,7 +59,7 @@ def variant(v):
         out[s, slots] = o[np.argsort(-cost[o], kind="stable")]
     return out
 for rep in range(1):
-    for v, name in enumerate(["C3 mix as generated", "object ops dispatched first", "object ops dispatched last", "swap late>=64 early<64", "swap late>=48 early<48", "swap late>=32 early<32", "swap late>=64 early<32", "swap late>=96 early<64"]):
+    for v, name in [(i, nm) for i, nm in enumerate(["C3 mix as generated", "object ops dispatched first", "object ops dispatched last", "swap late>=64 early<64", "swap late>=48 early<48", "swap late>=32 early<32", "swap late>=64 early<32", "swap late>=96 early<64", "first + none on XCD 4,5", "first + XCD weights mild", "first + XCD weights strong"]) if i in (0, 1, 8, 9, 10)]:
         batch = EnvBatch(n, 30, 30, -1, "o2arc", dev)
         batch.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
         batch.set_tasks_padded(*bench.make_tasks(n, 1)); batch.reset()
