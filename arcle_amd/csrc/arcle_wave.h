@@ -1357,9 +1357,6 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   static_assert(ARCLE_OPF_KEEP_SEL == 2u, "bit 1");
   s.sel_pending = (oflags & ARCLE_OPF_KEEP_SEL) | (zero_selected ? 1u : 0u);
 
-#ifdef ARCLE_EXP_PRIO
-  if (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP) __builtin_amdgcn_s_setprio(ARCLE_EXP_PRIO);
-#endif
   switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
     case ARCLE_OP_COLOR: {  // color.py:70-74 — whole HxW plane, grid_dim ignored
       if (sel.any_nz) {
@@ -1725,6 +1722,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   cnt0.x = (int32_t)in.cnt[0];
   cnt0.y = (int32_t)in.cnt[1];
   w.set_env(env);
+  // (diagnostic builds, profiles/round3_experiments.txt: n dependent scalar adds / s_nop / vector adds in every wave — which pipe is short)
 #ifdef ARCLE_EXP_S
   { uint32_t d = in.op; asm volatile(".rept %c1\n s_add_u32 %0, %0, 1\n .endr" : "+s"(d) : "n"(ARCLE_EXP_S) : "scc"); xl::sink_s(d); }
 #endif

@@ -48,8 +48,17 @@ def xcd_weighted(weights):
             out[s, m[:q]] = lg[li:li + q]; li += q
             out[s, m[q:]] = sh[si:si + len(m) - q]; si += len(m) - q
     return out
+cost3 = cost.copy(); cost3[0:10] = 1   # Color waves live ~0.3 us longer than FloodFill / Copy / Paste / critical ones
+def sorted_by(c):
+    out = np.empty_like(op_np)
+    slots = np.argsort(pos, kind="stable")
+    for s in range(K):
+        o = op_np[s]
+        out[s, slots] = o[np.argsort(-c[o], kind="stable")]
+    return out
 def variant(v):
     if v == 0: return op_np
+    if v == 11: return sorted_by(cost3)
     if v >= 8: return xcd_weighted([(1, 1, 1, 1, 0, 0, 1, 1), (1.2, 1.1, 1, 1, 0.6, 0.6, 0.9, 0.9), (1.5, 1.3, 1.1, 1, 0.3, 0.3, 0.8, 0.8)][v - 8])
     if v >= 3: return swapped(*[(64, 64), (48, 48), (32, 32), (64, 32), (96, 64)][v - 3])
     out = np.empty_like(op_np)
@@ -59,7 +68,7 @@ def variant(v):
         out[s, slots] = o[np.argsort(-cost[o], kind="stable")]
     return out
 for rep in range(1):
-    for v, name in [(i, nm) for i, nm in enumerate(["C3 mix as generated", "object ops dispatched first", "object ops dispatched last", "swap late>=64 early<64", "swap late>=48 early<48", "swap late>=32 early<32", "swap late>=64 early<32", "swap late>=96 early<64", "first + none on XCD 4,5", "first + XCD weights mild", "first + XCD weights strong"]) if i in (0, 1, 8, 9, 10)]:
+    for v, name in [(i, nm) for i, nm in enumerate(["C3 mix as generated", "object ops dispatched first", "object ops dispatched last", "swap late>=64 early<64", "swap late>=48 early<48", "swap late>=32 early<32", "swap late>=64 early<32", "swap late>=96 early<64", "first + none on XCD 4,5", "first + XCD weights mild", "first + XCD weights strong", "object ops, then Color, then the rest"]) if i in (0, 1, 11)]:
         batch = EnvBatch(n, 30, 30, -1, "o2arc", dev)
         batch.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
         batch.set_tasks_padded(*bench.make_tasks(n, 1)); batch.reset()
