@@ -26,7 +26,7 @@ EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buff
            "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_invalidate", "arcle_flat_obs_size", "arcle_flatten_obs",
            "arcle_set_flat_output", "arcle_set_flat_output_ex", "arcle_get_state_rows", "arcle_set_state_rows",
            "arcle_transition_rows", "arcle_get_plane", "arcle_set_plane", "arcle_get_status",
-           "arcle_enable_accounting", "arcle_get_accounting", "arcle_get_accounting_ex", "arcle_last_error"]
+           "arcle_enable_accounting", "arcle_get_accounting", "arcle_get_accounting_ex", "arcle_last_error", "arcle_debug_copy_order"]
 
 
 class ArcleHipError(RuntimeError):
@@ -117,6 +117,7 @@ def lib():
     L.arcle_get_accounting.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                        ctypes.c_int, vp]
     L.arcle_last_error.argtypes = [vp]
+    L.arcle_debug_copy_order.argtypes = [vp, vp]
     L.arcle_last_error.restype = ctypes.c_char_p
     if L.arcle_abi_version() != ABI_VERSION:
         raise ArcleHipError("libarcle_hip.so ABI version mismatch — rebuild")

@@ -817,6 +817,9 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if (flags & ~0x3ffu) return fail(e, ARCLE_ERR_ARG, "unknown step flag");
   if ((flags & ARCLE_STEP_ROWS_INCREMENTAL) && !(flags & ARCLE_STEP_FLAT_OBS)) return fail(e, ARCLE_ERR_ARG, "ARCLE_STEP_ROWS_INCREMENTAL without ARCLE_STEP_FLAT_OBS");
   DeviceGuard guard(e->device);
+  // A step without ARCLE_STEP_DENSE on a handle that keeps dense pairs may move grids the cache still describes: drop the entries
+  // first (stream-ordered; handles that always step with the flag — ARCVecEnv(dense_reward) — never take this branch)
+  if (e->d_dense_cache && !(flags & ARCLE_STEP_DENSE)) HIP_TRY(e, hipMemsetAsync(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8, (hipStream_t)stream));
   StepParams p = e->base;
   p.ingress = ingress;
   p.sel = sel;
@@ -1047,6 +1050,7 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   if ((flags & ARCLE_STEP_FEATURE_FLAGS) && ingress != arcle::INGRESS_MASK)
     return fail(e, ARCLE_ERR_CONFIG, "the rollout kernels take ARCLE_STEP_CONTINUE_RULE / _RESET_ON_SUBMIT with mask ingress only");
   DeviceGuard guard(e->device);
+  if (e->d_dense_cache) HIP_TRY(e, hipMemsetAsync(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8, (hipStream_t)stream));  // (rollouts move grids, keep no pairs)
   StepParams p = e->base;
   p.ingress = ingress;
   p.sel = sel;
@@ -1367,8 +1371,8 @@ extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   return ARCLE_OK;
 }
 
-// (test hook, not part of include/arcle_hip.h: the dispatch-order tables arcle_step_many last wrote — [0], [1] alternate by step
-// parity, [2] is the identity — so that tests can check them against the op arrays)
+// (test hook, declared in include/arcle_hip.h's last section: the dispatch-order tables arcle_step_many last wrote — [0], [1] alternate
+// by step parity, [2] is the identity — so that tests can check them against the op arrays)
 extern "C" int arcle_debug_copy_order(arcle_env* e, uint32_t* host_out) {
   if (!e || !host_out) return ARCLE_ERR_ARG;
   if (!e->d_order) return fail(e, ARCLE_ERR_CONFIG, "no dispatch-order tables (no ordered arcle_step_many call yet)");
@@ -1378,7 +1382,7 @@ extern "C" int arcle_debug_copy_order(arcle_env* e, uint32_t* host_out) {
   return ARCLE_OK;
 }
 
-#ifdef ARCLE_TRACE_WAVES
+#ifdef ARCLE_TRACE_WAVES  // diagnostic builds only (tools/wavetrace.py); absent from the shipped library and from the header
 extern "C" int arcle_debug_copy_trace(arcle_env* e, uint64_t* host_out) {  // diagnostic builds only
   if (!e || !e->d_acct) return ARCLE_ERR_ARG;
   HIP_TRY(e, hipDeviceSynchronize());

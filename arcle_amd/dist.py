@@ -11,7 +11,9 @@ carries one shard).
 The collective is 8-10x longer than a step (7.5 MB per GPU over 7 links ~ 50 us against a 5.5 us kernel), so it must not sit on
 the step stream.  Three ways to keep it off the critical path, all provided here:
   * `gather_async()`  the all-gather runs on a SIDE stream behind an event; the step stream goes on.  Packed rows and gathered
-                      tensors are double-buffered, so step t+1 may overwrite nothing the collective of step t still reads.
+                      tensors are double-buffered, so step t+1 may overwrite nothing the collective of step t still reads; the step
+                      that re-enters a slot two windows later first waits for the collective that read it (whether or not the
+                      caller ever called wait()), so deferring wait() by any number of steps cannot corrupt rows in flight.
   * `groups=2`        the shard is split into ping-pong groups with their own state: while group A's rows travel (and the learner
                       computes A's next actions) group B steps — the strict loop  a(t+1) = policy(obs(t))  leaves nothing else to
                       overlap with.
@@ -63,6 +65,7 @@ class _Group:
         self.t = 0                      # steps taken since the last every-K gather
         self.last = None                # (slot, steps) of the rows the last step(s) produced
         self.consumed = [None, None]    # per slot: event after which the consumer is done with full[slot]
+        self.inflight = [None, None]    # per slot: (event | gloo work) of the gather that is still READING packed[slot]
 
 
 class ShardedVecEnv:
@@ -118,6 +121,16 @@ class ShardedVecEnv:
         return self.groups[group].env.reset(**kw)
 
     def _before_step(self, grp):
+        if grp.t == 0:
+            # a window starts in this slot: the gather that last read packed[slot] (issued two windows ago, maybe never waited for by
+            # the caller — the collective is 8-10x longer than a step) must have finished before a step kernel / arcle_pack_obs
+            # rewrites the rows it sends.  GPU: the step stream waits on the collective's completion event; CPU: the gloo work item.
+            pending, grp.inflight[grp.slot] = grp.inflight[grp.slot], None
+            if pending is not None:
+                if self._cuda:
+                    torch.cuda.current_stream(self.device).wait_event(pending)
+                else:
+                    pending.wait()
         if self.fused:  # this step's rows go into slot (pair grp.slot, step grp.t) — launches take their parameters by value
             grp.env.batch.set_packed_output(grp.packed[grp.slot][grp.t][:grp.n])
 
@@ -179,8 +192,10 @@ class ShardedVecEnv:
                 dist.all_gather_into_tensor(grp.full[slot], grp.packed[slot], group=self.group)
                 done = torch.cuda.Event()
                 done.record(self._side)
+            grp.inflight[slot] = done
             return GatherWork(self, group, slot, event=done)
         work = dist.all_gather_into_tensor(grp.full[slot], grp.packed[slot], group=self.group, async_op=True)
+        grp.inflight[slot] = work
         return GatherWork(self, group, slot, work=work)
 
     def release(self, work):

@@ -38,6 +38,20 @@ STEP_ROWS_INCREMENTAL = 512
 AUG_PERMUTE, AUG_ROT90 = 1, 2
 ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION, ST_AUG_DOMAIN = 1, 2, 4, 8, 16
 ROW_TAIL = 16  # bytes of the optional step-output tail of a flat row (arcle_set_flat_output_ex)
+MAX_CELLS = 1024  # ARCLE_MAX_CELLS: one 64-lane wavefront x 16 cells per lane holds a whole H x W plane
+MAX_SIDE = 127    # dims travel as int8 in the per-env record
+
+
+def check_grid_size(H, W):
+    """The one narrowing of the reference's constructor contract (base.py:37-49 takes any max_grid_size): the HIP path keeps a
+    whole plane in one wavefront, so H * W <= 1024 and H, W <= 127 (ARC grids are at most 30 x 30).  Raised here — before any device
+    is touched — with the limit in the message; arcle_create reports the same as ARCLE_ERR_CONFIG."""
+    H, W = int(H), int(W)
+    if H <= 0 or W <= 0:
+        raise ValueError(f"max_grid_size must be positive, got ({H}, {W})")
+    if H * W > MAX_CELLS or H > MAX_SIDE or W > MAX_SIDE:
+        raise ValueError(f"max_grid_size ({H}, {W}) is outside what the HIP path supports: H * W <= {MAX_CELLS} cells "
+                         f"(ARCLE_MAX_CELLS: one wavefront holds a plane) and H, W <= {MAX_SIDE}; ARC grids are at most 30 x 30")
 
 
 _hip = None
@@ -51,6 +65,7 @@ class EnvBatch:
     """n_envs envs of one kind on one GPU."""
 
     def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None, plane_stride=None):
+        check_grid_size(H, W)
         if not torch.cuda.is_available():
             raise ArcleHipError("no HIP device visible (torch.cuda.is_available() is False); "
                                 "arcle_amd has no CPU fallback")
@@ -296,7 +311,9 @@ class EnvBatch:
         `form` ("mask" | "bbox" | "point" | "bbox5" | "bits"), op int32 [K, N] (None for "bbox5") -> (reward int32 [K, N],
         terminated uint8 [K, N]).  Every step is a full step; self.reward / self.term are not written."""
         K = int(payload.shape[0])
-        assert payload.is_contiguous() and payload.device == self.device and (op is None or (op.is_contiguous() and op.dtype == torch.int32))
+        # ("bbox5" records may live in PINNED HOST memory: the library then prefetches step t+1's records under launch t)
+        assert payload.is_contiguous() and (payload.device == self.device or (form == "bbox5" and payload.is_pinned()))
+        assert op is None or (op.is_contiguous() and op.dtype == torch.int32)
         if reward is None:
             reward = torch.empty((K, self.N), dtype=torch.int32, device=self.device)
         if term is None:
@@ -308,6 +325,13 @@ class EnvBatch:
     def set_dispatch_order(self, enable=True):
         """arcle_step_many's ordered dispatch (object operations handed to the waves that start first; scheduling only) on / off."""
         self._check(self.L.arcle_set_dispatch_order(self._h, 1 if enable else 0), "arcle_set_dispatch_order")
+        self._order_enabled = bool(enable)
+
+    def prepare_dispatch_order(self):
+        """Before capturing step_many into a hipGraph: allocate the dispatch-order tables (a capture cannot) — but only if ordered
+        dispatch is on; a caller's set_dispatch_order(False) stays in force."""
+        if getattr(self, "_order_enabled", True):
+            self.set_dispatch_order(True)
 
     def step_bbox_ptr(self, bbox_ptr, op_ptr, flags=0, stream=0):
         """Lowest-overhead launch for rollout loops: raw device addresses (ints) of an int32 [N,4] bbox array

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import actions, spaces
-from ..engine import EnvBatch, ST_BAD_OP, ST_ROTATE_DOMAIN, STEP_FLAT_OBS, STEP_RESET_ON_SUBMIT
+from ..engine import EnvBatch, ST_BAD_OP, ST_ROTATE_DOMAIN, STEP_FLAT_OBS, STEP_RESET_ON_SUBMIT, check_grid_size
 from ..loaders import Loader
 
 
@@ -28,6 +28,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             raise NotImplementedError("rendering is outside the ported hot path (SURVEY.md §2 row 1)")
         self.loader = data_loader
         self.H, self.W = int(max_grid_size[0]), int(max_grid_size[1])
+        check_grid_size(self.H, self.W)  # (H * W <= 1024: the documented limit of the HIP path, raised before any device work)
         self.colors = colors
         self.max_trial = max_trial
         self.render_mode = render_mode

@@ -18,7 +18,8 @@ import torch
 
 from .. import actions, sampling
 from ..engine import (AUG_PERMUTE, AUG_ROT90, EnvBatch, STEP_AUTORESET, STEP_DENSE, STEP_FLAT_OBS, STEP_PACK_OBS, STEP_RESAMPLE,
-                      STEP_RESET_ON_SUBMIT, STEP_ROWS_INCREMENTAL, STEP_TRUNCATE, ST_AUG_DOMAIN, ST_BAD_OP, ST_BAD_SELECTION, ST_BAD_TASK, ST_ROTATE_DOMAIN)
+                      STEP_RESET_ON_SUBMIT, STEP_ROWS_INCREMENTAL, STEP_TRUNCATE, ST_AUG_DOMAIN, ST_BAD_OP, ST_BAD_SELECTION, ST_BAD_TASK, ST_ROTATE_DOMAIN,
+                      check_grid_size)
 
 
 def _table_of(env_cls, **ctor_kw):
@@ -142,6 +143,7 @@ class ARCVecEnv:
         terminated, truncated, info entries): the next step overwrites them in place — copy what must outlive it."""
         self.env_cls, self.N = env_cls, int(num_envs)
         self.H, self.W = int(max_grid_size[0]), int(max_grid_size[1])
+        check_grid_size(self.H, self.W)
         self.colors = colors
         if max_trial is None:
             max_trial = 3 if env_cls.KIND == "arc" else -1  # the classes' defaults (arcenv.py:79, o2arcenv.py:14)
@@ -240,6 +242,9 @@ class ARCVecEnv:
                 eprob.extend([t] * len(task[ii]))
                 esub.extend(range(len(task[ii])))
         self.batch.set_task_table(ins, outs)
+        # per table entry: does a quarter turn of the pair still fit the H x W plane? (non-square max_grid_size only)
+        self._entry_turns = np.asarray([np.shape(a)[1] <= self.H and np.shape(a)[0] <= self.W and np.shape(b)[1] <= self.H and np.shape(b)[0] <= self.W
+                                        for a, b in zip(ins, outs)], bool)
         self._entry_problem = torch.as_tensor(np.asarray(eprob, np.int64), device=self.device)
         self._entry_sub = torch.as_tensor(np.asarray(esub, np.int64), device=self.device)
         self._sampler_mode = None
@@ -301,6 +306,9 @@ class ARCVecEnv:
             # episode), so a run is reproducible and independent of the sharding — and the envs' episode counters advance
             ep = self.batch.episode.cpu().numpy()
             k, perm = sampling.draw_aug_batch(self.seed, self.env_base + np.arange(self.N), ep, self.aug_flags)
+            # the rule of the device-drawn path (arcle_wave.h load_task, soften): a quarter turn that does not fit a non-square plane is
+            # dropped (k & 2) — so every env IS loaded and the episode / cur_task bookkeeping below is true for all of them
+            k = np.where(self._entry_turns[idx.cpu().numpy()], k, k & 2).astype(k.dtype)
             self.batch.reset_from_table(idx, mask, k if self.aug_flags & AUG_ROT90 else None, perm if self.aug_flags & AUG_PERMUTE else None)
             self.batch.episode[m] += 1
         else:
@@ -477,7 +485,8 @@ class ARCVecEnv:
         shapes = {"bbox": (self.N, 4), "point": (self.N, 2), "bbox5": (self.N, 5), "mask": (self.N, self.H, self.W), "bits": (self.N, 128)}
         dt = {"mask": torch.int8, "bits": torch.uint8}.get(form, torch.int32)
         assert form in shapes, f"unknown action form {form!r}"
-        assert payload.dtype == dt and tuple(payload.shape[1:]) == shapes[form] and payload.is_contiguous() and payload.device == self.device
+        on_dev = payload.device == self.device or (form == "bbox5" and payload.is_pinned())  # (records of a host-resident policy: pinned memory)
+        assert payload.dtype == dt and tuple(payload.shape[1:]) == shapes[form] and payload.is_contiguous() and on_dev
         if form != "bbox5":
             assert operation is not None and operation.dtype == torch.int32 and tuple(operation.shape) == (payload.shape[0], self.N)
             assert operation.is_contiguous() and operation.device == self.device
@@ -506,7 +515,7 @@ class ARCVecEnv:
         self._check_many(form, payload, operation)
         K = int(payload.shape[0])
         reward, term, trunc, dense = self._many_buffers(K)
-        self.batch.set_dispatch_order(True)  # (allocates the dispatch-order tables now: inside the capture the library cannot)
+        self.batch.prepare_dispatch_order()  # (allocates the dispatch-order tables now — inside the capture the library cannot — unless the caller turned ordered dispatch off)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         g = torch.cuda.CUDAGraph()
@@ -568,16 +577,19 @@ class ARCVecEnv:
         For callers that already hold the action sequence (trace replay, scripted policies); the state is only
         observable after the last step."""
         reward, term = self.batch.rollout(bbox, operation, self._rollout_flags())
+        self._refresh_rows()  # (a rollout keeps no per-step rows: the live mirror is rewritten from the final state)
         return self._obs, reward, term.bool(), self._info()
 
     def rollout_point(self, xy, operation):
         reward, term = self.batch.rollout(xy, operation, self._rollout_flags(), point=True)
+        self._refresh_rows()
         return self._obs, reward, term.bool(), self._info()
 
     def _rollout_flags(self):
         if self._host_slots or self.flags & (STEP_RESAMPLE | STEP_TRUNCATE | STEP_DENSE):
             raise NotImplementedError("rollouts support plain and same-task autoreset envs with device-only op tables")
-        return self.flags & ~STEP_PACK_OBS  # (only the final state of a rollout is observable: no per-step packed rows)
+        # (only the final state of a rollout is observable: no per-step packed / flat rows — the callers refresh the live rows afterwards)
+        return self.flags & ~(STEP_PACK_OBS | STEP_FLAT_OBS | STEP_ROWS_INCREMENTAL)
 
     def flat_obs(self, out=None, filtered=False):
         """The observation as one [N, L] int8 tensor in FlattenObservation key order (what the reference's policies

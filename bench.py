@@ -8,12 +8,17 @@
 
 A "step" is ONE pass of the hot path over one batch: a single launch of the step kernel that applies one (selection,
 operation) action to every env of this GPU.  Tasks, state and the whole action stream are resident in HBM before the
-timed region starts.  c3 enqueues a region's K launches with ONE `arcle_step_many` call (what `ARCVecEnv.capture` records): the
-library then knows the next step's op array while a step runs, and every launch's eight front workgroups sort the next launch's
-dispatch slots — Move / Rotate / Flip to the waves that start first — which shortens the launch's tail (scheduling only: the same
-K launches with the same results; `--no-ordered` enqueues them call by call, and `timing.per_step_calls` times that form beside
-the headline in every run).  Envs are independent, so N GPUs = N shards, no data-path collective (weak scaling); rank 0
-prints ONE JSON line.  Workloads (`config.workload` names the one that ran):
+timed region starts.  HEADLINE (`value`, `ms_per_step`, `roofline`) = the step()-per-call form: a region's K launches are K
+`arcle_step_bbox` calls, none of which sees the next step's actions (the loop a(t+1) = policy(obs(t)) of the reference's
+examples/example_bbox.py:13-15).  c3 times beside it — same run, same event clock, top-level `ordered` block — the same K launches
+enqueued by ONE `arcle_step_many` call (what `ARCVecEnv.capture` records): the library then knows the next step's op array while a
+step runs, and every launch's eight front workgroups sort the next launch's dispatch slots — Move / Rotate / Flip to the waves that
+start first — which shortens the launch's tail (scheduling only: the same K launches with the same results; `--no-ordered` skips that
+leg).  Envs are independent, so N GPUs = N shards, no data-path collective (weak scaling).
+OUTPUT: rank 0 prints ONE compact JSON line on stdout (< 3 KB, the LAST line; the contract fields + `ordered`, `roofline`,
+`cpu_baseline`, `sustained`, `legs_us_per_step`, `collective` for N > 1); the full record (every leg with its own roofline block,
+per-region times) goes to stderr as one `BENCH_FULL {...}` line and to gpurun_out/bench_full_<config>_n<N>_k<K>.json.
+Workloads (`config.workload` names the one that ran):
   c3 (default, the headline: BASELINE configs[2])  O2ARCv2Env 30x30, 8192 envs/GPU, 35 ops uniform, BBox 5-tuples
       uniform, on-device auto-reset of terminated envs
   c2  O2ARCv2Env 10x10, 1024 envs, ops 0-23, 50 % rectangle / 40 % point / 10 % empty selections
@@ -40,8 +45,10 @@ batches on an evolving state.)  Besides the contract fields the line carries
                 batched transition), rollout, batch_sweep (32 768 and 131 072 envs: the out-of-cache fraction), other_configs
                 (c2 / c4 on one rank / c5 with their real bounds);
   cpu_baseline  (N=1) on this box's host, bounded samples of the same workload: the oracle's C restatement (1 thread /
-                all cores) and `numpy_step` = a plain-NumPy one-env-at-a-time step() loop with the reference's call
-                structure (oracle/numpy_env.py), 1 process / all cores.
+                ALL host cores) and `numpy_step` = a plain-NumPy one-env-at-a-time step() loop with the reference's call
+                structure (oracle/numpy_env.py; leaner than the reference itself, labelled so), 1 process / all cores;
+  sustained     (N=1) the headline graph replayed back to back on a side thread for the ~15 s of the single-threaded CPU legs;
+  collective    (N>1) backend, world size and the number of ranks an all-reduce of ones actually counted.
 """
 import argparse
 import json
@@ -50,6 +57,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -195,7 +203,7 @@ CONFIGS = {
 def _cpu_run(threads, seed, budget_s):
     from oracle import oracle as O
     O.set_threads(threads)
-    n = 2048 if threads == 1 else 8192
+    n = 2048 if threads == 1 else max(8192, 256 * threads)  # (>= 256 envs per thread and parallel region)
     env = O.OracleEnv(n, 30, 30, -1, "o2arc")
     inp, idim, ans, adim = make_tasks(n, seed)
     env.planes["input"][:] = inp
@@ -217,7 +225,7 @@ def _cpu_run(threads, seed, budget_s):
     return done / dt, n, done // n
 
 
-def _numpy_baseline(avail):
+def _numpy_baseline(avail, before_fork=None):
     """The plain-NumPy per-env step() loop (oracle/numpy_env.py): one process, then one process per host core."""
     import multiprocessing as mp
     from oracle import numpy_env as NE
@@ -225,31 +233,159 @@ def _numpy_baseline(avail):
     steps1 = max(50, int(150 * 6.0 / max(sec, 1e-3)))  # aim at ~6 s of single-process stepping
     done, sec = NE.run_chunk((12, 64, min(steps1, 4000), 30, 30))
     one = done / sec
-    procs = max(1, min(avail, 64))
+    procs = max(1, avail)  # every host core
     per = max(20, int(one * 5.0 / 64))  # ~5 s per worker
+    if before_fork is not None:
+        before_fork()
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(procs) as pool:
         res = pool.map(NE.run_chunk, [(100 + i, 64, per, 30, 30) for i in range(procs)])
     wall = time.perf_counter() - t0
     return {"value": one, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "note": "a leaner NumPy port than the reference itself (which measured 36 k env-steps/s/core, BASELINE.md 2): NOT the reference's CPU path",
             "sample": f"64 envs x {done // 64} C3 steps, one Python step() per env, oracle/numpy_env.py",
             "all_cores": {"value": sum(d for d, _ in res) / max(max(s for _, s in res), 1e-9), "unit": "env-steps/s",
                           "cores": procs, "sample": f"{procs} processes x 64 envs x {per} steps (wall incl. fork {wall:.1f} s)"}}
 
 
-def cpu_baseline(seed):
-    v1, n1, s1 = _cpu_run(1, seed, 10.0)
+class Sustained(threading.Thread):
+    """The headline hipGraph replayed back to back on a side thread while rank 0 times the single-threaded CPU baselines (the
+    oracle's C call releases the GIL): the SUSTAINED rate over ~15 s of wall clock next to the burst figure of the timed regions
+    — and a GPU that an outside sampler (rocm-smi) can see busy.  Never part of `value`."""
+
+    def __init__(self, graph, dev, steps_per_replay, us_per_replay):
+        super().__init__(daemon=True)
+        self.graph, self.dev, self.per = graph, dev, steps_per_replay
+        self.reps = max(1, min(400, int(20000.0 / max(us_per_replay, 1.0))))  # ~20 ms of queued work between synchronisations
+        self.halt = threading.Event()
+        self.done, self.sec, self.err = 0, 0.0, None
+
+    def run(self):
+        try:
+            torch.cuda.set_device(self.dev)
+            st = torch.cuda.Stream(self.dev)
+            with torch.cuda.stream(st):
+                t0 = time.perf_counter()
+                while not self.halt.is_set():
+                    for _ in range(self.reps):
+                        self.graph.replay()
+                    st.synchronize()
+                    self.done += self.reps * self.per
+                self.sec = time.perf_counter() - t0
+        except Exception as exc:  # noqa: BLE001 - reported, never fatal
+            self.err = f"{type(exc).__name__}: {exc}"
+
+    def result(self):
+        if self.err or self.sec <= 0:
+            return {"error": self.err or "did not run"}
+        return {"value": self.done / self.sec, "unit": "env-steps/s", "seconds": round(self.sec, 2), "env_steps": self.done,
+                "note": "host clock over back-to-back replays of the headline graph (incl. one synchronisation per ~20 ms), run on a side "
+                        "thread during the single-threaded CPU-baseline legs"}
+
+
+def cpu_baseline(seed, sustain=None):
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(avail, 64))
+    if sustain is not None:
+        sustain.start()
+    v1, n1, s1 = _cpu_run(1, seed, 10.0)
+
+    def stop_sustain():  # (stopped before the fork pool and the all-cores leg: they want every core)
+        if sustain is not None:
+            sustain.halt.set()
+            sustain.join(30.0)
+    numpy_step = _numpy_baseline(avail, stop_sustain)
+    threads = max(1, avail)  # every host core
     vt, nt, st = _cpu_run(threads, seed, 6.0)
     return {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n1} envs x {s1} steps of the same C3 action stream, oracle/arcle_oracle.c, 1 thread",
             "host_cores_available": avail,
             "all_cores": {"value": vt, "unit": "env-steps/s", "cores": threads,
                           "sample": f"{nt} envs x {st} steps, same code, OpenMP over envs"},
-            "numpy_step": _numpy_baseline(avail),
+            "numpy_step": numpy_step,
             "reference_note": "the reference itself cannot travel to this box; survey container: 36 k env-steps/s/core "
                               "(Xeon 2.10 GHz, BASELINE.md §2)"}
+
+
+def _r(x, nd=4):
+    """Rounds floats for the compact line (4 significant digits)."""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    return x
+
+
+def emit(out, a):
+    """stdout gets ONE compact JSON line (< 3 KB: the driver keeps an 8 KB tail and parses the last line); the full record — every
+    leg with its own roofline block, the per-region times — goes to stderr as one `BENCH_FULL ` line and, when the directory is
+    writable, to gpurun_out/bench_full.json."""
+    full = json.dumps(out)
+    print("BENCH_FULL " + full, file=sys.stderr, flush=True)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"bench_full_{a.config}_n{out['n_gpus']}_k{out['steps']}.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError:
+        pass
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data")}
+    c["value"], c["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 6)
+    cfg = out["config"]
+    c["config"] = {"workload": cfg["workload"][:150], "id": cfg["id"], "envs_per_gpu": cfg["envs_per_gpu"], "global_envs": cfg["global_envs"],
+                   "grid": cfg["grid"], "ingress": cfg["ingress"], "parallelism": cfg["parallelism"][:90]}
+    c["headline_form"] = "per_step_calls"
+    t = out["timing"]
+    c["timing"] = {"regions": t["regions"], "stat": "median region, max over ranks", "clock": "hip_events" if t["clock"].startswith("HIP") else "host",
+                   "launch": "hipGraph of K arcle_step_bbox calls" if t["launch"] != "eager" else "eager",
+                   "host_region_ms_median": _r(float(np.median(t["host_region_ms"])))}
+    if out.get("ordered"):
+        o = out["ordered"]
+        c["ordered"] = {"value": _r(o["value"], 6), "ms_per_step": _r(o["ms_per_step"], 6), "avg_launch_us": _r(o["avg_launch_us"]),
+                        "frac": _r(o.get("frac")), "form": "one arcle_step_many call (ordered dispatch), same clock"}
+    rl = out.get("roofline")
+    if rl:
+        c["roofline"] = {k: _r(rl[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_by_traffic", "kernel", "avg_launch_us",
+                                                 "algorithmic_bytes_per_launch", "algorithmic_bytes_per_env_step") if k in rl}
+        c["roofline"]["kernel"] = str(rl["kernel"])[:70]
+        c["roofline"]["traffic_source"] = "kernel-counted issued bytes, this run"
+        c["roofline"]["fits_infinity_cache"] = rl["note_cache"]["fits_infinity_cache"]
+        if rl.get("pmc_crosscheck"):
+            c["roofline"]["pmc_hbm_bytes_per_launch"] = rl["pmc_crosscheck"]["hbm_bytes_per_launch"]
+    ex = out.get("extras") or {}
+    sweep = ex.get("batch_sweep")
+    if isinstance(sweep, list) and rl:
+        c["roofline"]["frac_out_of_cache"] = {str(e["envs"]): {"frac": _r(e["roofline"]["frac"]), "frac_by_traffic": _r(e["roofline"]["frac_by_traffic"]),
+                                                              "us": _r(e["us_per_step_batch"])} for e in sweep}
+    if ex:
+        def us(*path):
+            d = ex
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return _r(d) if isinstance(d, float) else ("err" if isinstance(ex.get(path[0]), dict) and "error" in ex[path[0]] else None)
+        c["legs_us_per_step"] = {"vec_api_capture": us("vec_api", "us_per_step_batch"), "vec_api_python_loop": us("vec_api", "python_loop_us"),
+                                 "research_env": us("research_env", "us_per_step_batch"), "mask_int8": us("mask_ingress", "mask", "us_per_step_batch"),
+                                 "mask_bits": us("mask_ingress", "bits", "us_per_step_batch"), "host_actions": us("host_actions", "us_per_step_batch"),
+                                 "single_env_step": us("single_env", "us_per_step"), "transition_rows": us("transition_rows", "us_per_step_batch"),
+                                 "rollout": us("rollout", "us_per_step_batch"), "c2": us("other_configs", "c2", "us_per_step_batch"),
+                                 "c4": us("other_configs", "c4", "us_per_step_batch"), "c5": us("other_configs", "c5", "us_per_step_batch")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        ns = cb["numpy_step"]
+        c["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:110],
+                             "host_cores_available": cb["host_cores_available"],
+                             "all_cores": {"value": _r(cb["all_cores"]["value"]), "cores": cb["all_cores"]["cores"]},
+                             "numpy_step": {"value": _r(ns["value"]), "cores": 1, "all_cores": {"value": _r(ns["all_cores"]["value"]), "cores": ns["all_cores"]["cores"]},
+                                            "note": "leaner NumPy port, not the reference's own step (36 k/s/core, BASELINE.md)"}}
+    if out.get("sustained"):
+        c["sustained"] = {k: _r(v, 6) for k, v in out["sustained"].items() if k in ("value", "seconds", "error")}
+    for k in ("collective", "floodfill"):
+        if k in out:
+            c[k] = out[k]
+    c["full_record"] = "stderr line BENCH_FULL / gpurun_out/bench_full_*.json"
+    line = json.dumps(c)
+    if len(line) > 3800:  # never let the headline grow past what the driver keeps
+        for k in ("legs_us_per_step", "sustained", "floodfill"):
+            c.pop(k, None)
+        line = json.dumps(c)
+    print(line, flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -714,8 +850,8 @@ def main():
     ap.add_argument("--regions", type=int, default=0, help="timed regions of K steps (default: 5, more for small K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-headline legs (kernel A/B runs)")
-    ap.add_argument("--no-ordered", action="store_true", help="enqueue the region's K launches one arcle_step_bbox call at a time instead of one "
-                    "arcle_step_many call (whose launches sort the next step's dispatch slots, object operations first)")
+    ap.add_argument("--no-ordered", action="store_true", help="skip the `ordered` leg (the region's K launches as ONE arcle_step_many call, "
+                    "whose launches sort the next step's dispatch slots, object operations first)")
     ap.add_argument("--no-graph", action="store_true", help="launch the K steps of a region eagerly instead of as one hipGraph")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp launches (counter-collection runs)")
     a = ap.parse_args()
@@ -843,15 +979,16 @@ def main():
     snap = {k: v.clone() for k, v in batch.planes.items()}
     snap_rec, snap_cnt = batch.rec.clone(), batch.cnt.clone()
 
-    # The K steps of a region are captured once into a hipGraph (K launches of arcle_step_kernel, each with its own
-    # action batch) and replayed per region: a launch-bound inner loop belongs in a graph, and the host then issues one
-    # call per region instead of K.  (With more than one rank c4 keeps eager launches: its collective is not captured.)
-    # c3: the region is ONE arcle_step_many call (what ARCVecEnv.capture records): the library holds the K steps' actions, and every
-    # launch's front workgroups sort the NEXT step's dispatch slots from its op array — object operations to the waves that start
-    # first (scheduling only: same launches, same results).  The same K launches enqueued one arcle_step_bbox call at
-    # a time (no look at the next step's actions) are captured into a second graph and timed beside it: timing.per_step_calls.
+    # The K steps of a region are captured once into a hipGraph (K launches of arcle_step_kernel, each with its own action batch)
+    # and replayed per region: a launch-bound inner loop belongs in a graph, and the host then issues one call per region instead
+    # of K.  (With more than one rank c4 keeps eager launches when ranks share a GPU: its collective goes through the host.)
+    # HEADLINE = the step()-per-call form: K arcle_step_bbox calls, none of which knows the next step's actions (the loop
+    # a(t+1) = policy(obs(t)) of examples/example_bbox.py:13-15).  c3 also times, beside it and with the same clock, the same K
+    # launches enqueued by ONE arcle_step_many call (what ARCVecEnv.capture records): the library then holds the next step's op
+    # array while a step runs and every launch's front workgroups sort the NEXT launch's dispatch slots — object operations to
+    # the waves that start first (scheduling only: same launches, same results) -> the top-level `ordered` block.
     graph = None
-    graph_calls = None
+    graph_ordered = None
     many = a.config == "c3" and gather is None and not a.no_ordered and K > 1
     many_out = (torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)) if many else None
     if not a.no_graph and not (gather is not None and shared_gpu):
@@ -861,38 +998,37 @@ def main():
             cap.wait_stream(stream)
             if gather is not None:
                 done[0] = done[1] = None
-            if many:
-                batch.set_dispatch_order(True)  # (allocates the order tables: inside a capture the library cannot)
-                graph_calls = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_calls, stream=cap):
-                    cs = torch.cuda.current_stream(dev)
-                    for i in range(Wm, Wm + K):
-                        step(i, cs.cuda_stream, cs)
             with torch.cuda.graph(graph, stream=cap):
                 cs = torch.cuda.current_stream(dev)
-                if many:
-                    batch.step_many("bbox", bbox[Wm:Wm + K], op[Wm:Wm + K], FL, many_out[0], many_out[1])
-                else:
-                    for i in range(Wm, Wm + K):  # (c4 with a process group: the RCCL collectives are captured as well, on the forked side stream)
-                        step(i, cs.cuda_stream, cs)
+                for i in range(Wm, Wm + K):  # (c4 with a process group: the RCCL collectives are captured as well, on the forked side stream)
+                    step(i, cs.cuda_stream, cs)
                 join_side(cs)
             if gather is not None:
                 done[0] = done[1] = None
+            if many:
+                batch.set_dispatch_order(True)  # (allocates the order tables: inside a capture the library cannot)
+                graph_ordered = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_ordered, stream=cap):
+                    batch.step_many("bbox", bbox[Wm:Wm + K], op[Wm:Wm + K], FL, many_out[0], many_out[1])
         except Exception as exc:  # capture unsupported: eager launches
             print(f"bench: hipGraph capture failed ({exc}); eager launches", file=sys.stderr)
-            graph = None
+            graph = graph_ordered = None
             if gather is not None:
                 done[0] = done[1] = None
 
     def region(r):
         if graph is not None:
             graph.replay()
-        elif many:
-            batch.step_many("bbox", bbox[Wm:Wm + K], op[Wm:Wm + K], FL, many_out[0], many_out[1])
         else:
             for i in range(Wm + r * K, Wm + (r + 1) * K):
                 step(i)
             join_side()
+
+    def restore_snapshot():
+        for k, v in snap.items():  # back to the state the regions are defined to start from
+            batch.planes[k].copy_(v)
+        batch.rec.copy_(snap_rec)
+        batch.cnt.copy_(snap_cnt)
 
     # untimed clock ramp (the chip idles at low clocks before the first launch): the region's own launches, ~80 ms of them
     t_ramp, r = time.perf_counter(), 0
@@ -901,10 +1037,7 @@ def main():
         region(r)
         r += 1
         torch.cuda.synchronize(dev)
-    for k, v in snap.items():  # back to the state the regions are defined to start from
-        batch.planes[k].copy_(v)
-    batch.rec.copy_(snap_rec)
-    batch.cnt.copy_(snap_cnt)
+    restore_snapshot()
     torch.cuda.synchronize(dev)
 
     # ---- R timed regions of exactly K steps, each bracketed by barrier + synchronize ---------------------------
@@ -927,30 +1060,37 @@ def main():
         wall.append(time.perf_counter() - t0)
         devt.append(ev0.elapsed_time(ev1) * 1e-3)
         kern.append(devt[-1] / K)
-    host_ms = [round(x * 1e3, 4) for x in wall][:12]
-    per_step_calls = None
-    if graph_calls is not None:  # the same K launches, enqueued call by call (untimed for the headline; same event clock)
+    ordered = None
+    if graph_ordered is not None:  # the same K launches as ONE arcle_step_many call (ordered dispatch); same event clock, this rank
         ts = []
-        for r in range(min(R, 7)):
-            for k, v in snap.items():
-                batch.planes[k].copy_(v)
-            batch.rec.copy_(snap_rec)
-            batch.cnt.copy_(snap_cnt)
+        for w_ in range(3):  # (the first replays fill the order tables' caches)
+            restore_snapshot()
+            graph_ordered.replay()
+        for r in range(min(R, 9)):
+            restore_snapshot()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(dev)
             ev0.record(stream)
-            graph_calls.replay()
+            graph_ordered.replay()
             ev1.record(stream)
             wait_gpu(ev1)
             ts.append(ev0.elapsed_time(ev1) * 1e-3)
-        t_calls = float(np.median(ts))
-        per_step_calls = {"us_per_step_batch": t_calls / K * 1e6, "value": K * n / t_calls, "unit": "env-steps/s (this rank)",
-                          "launch": "hipGraph of K arcle_step_bbox calls: every launch hands envs to its waves in index order"}
+        t_ord = float(np.median(ts))
+        ordered = {"value": K * n * world / t_ord, "unit": "env-steps/s", "ms_per_step": t_ord / K * 1e3, "avg_launch_us": t_ord / K * 1e6,
+                   "kernel": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|ordered, 30>",
+                   "form": "ONE arcle_step_many call for the K steps (ARCVecEnv.capture): launch t sorts step t+1's dispatch slots, object ops first; "
+                           "scheduling only; timed on this rank with the same event clock, N x this for the node"}
     wall_t = torch.tensor(devt if device_clock else wall, dtype=torch.float64)
+    ranks_seen = world
     if dist is not None:  # max over ranks, per region
         wt = wall_t if shared_gpu else wall_t.to(dev)
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
         wall_t = wt.cpu()
+        one = torch.ones(1, dtype=torch.float64) if shared_gpu else torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one)  # every rank of the group adds 1: what the collective itself saw
+        ranks_seen = int(one.item())
+        print(f"bench: rank {rank}/{dist.get_world_size()} backend={dist.get_backend()} device={dev} ({torch.cuda.get_device_name(dev)}) "
+              f"envs [{rank * n}, {(rank + 1) * n}) median region {float(np.median(devt if device_clock else wall)) * 1e3:.4f} ms", file=sys.stderr, flush=True)
     elapsed = float(wall_t.median())
     kernel_avg_s = float(np.median(kern))
     status = batch.status()
@@ -961,11 +1101,7 @@ def main():
     #      the accounting instantiation — algorithmic bytes (the numerator of `frac`) and issued bytes (`traffic`) ----
     roofline = None
     if rank == 0:
-        for k, v in snap.items():
-            batch.planes[k].copy_(v)
-        batch.rec.copy_(snap_rec)
-        batch.cnt.copy_(snap_cnt)
-
+        restore_snapshot()
         if gather is not None:
             batch.set_packed_output(packed2[0])
 
@@ -973,7 +1109,7 @@ def main():
             for i in range(Wm, Wm + K):
                 batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, sh_)
         per_launch_bytes, issued_bytes, _ = counted_bytes(batch, replay_region0, K, dev)
-        kname = {"c3": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|ordered, 30>" if many else "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>",
+        kname = {"c3": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>",
                  "c4": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|pack, 30> (fused packed-row epilogue; a multi-rank run has the all-gather inside the event pair)"}.get(a.config, "arcle_step_kernel")
         roofline = roofline_block(kname, kernel_avg_s, per_launch_bytes, issued_bytes, n, PS=batch.PS, planes=len(batch.planes),
                                   note="algorithmic bytes follow SURVEY.md 8d and include the reset_sel zero-fills of `selected` that "
@@ -987,6 +1123,8 @@ def main():
             roofline.update({"bound": "launch-floor", "launch_floor_us": 2.5})
         if a.config == "c5":
             roofline.update({"bound": "iteration (dependent flood-fill passes)"})
+        if ordered is not None:
+            ordered["frac"] = per_launch_bytes / (ordered["avg_launch_us"] * 1e-6) / HBM_PEAK
 
     if rank == 0:
         out = {
@@ -1000,15 +1138,19 @@ def main():
                        "parallelism": f"env-shard x{world} (no data-path collective)" if gather is None
                        else (f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL on a side stream, double-buffered rows, overlapping the next step'})"
                              if dist is not None else "one rank: step with the fused packed-row epilogue, nothing to gather")},
+            "headline_form": "per_step_calls: K arcle_step_* calls, one launch each, none sees the next step's actions",
             "timing": {"regions": R, "stat": "median region, max over ranks per region",
                        "clock": "HIP events on the launch stream, recorded between the region's two synchronisations" if device_clock else "host perf_counter between the region's two synchronisations",
-                       "host_region_ms": host_ms,
-                       "launch": ("hipGraph of ONE arcle_step_many call (K step launches; launch t orders step t+1's dispatch slots from its op array), one replay per region"
-                                  if many else "hipGraph of the K step launches, one replay per region") if graph is not None else "eager",
-                       "per_step_calls": per_step_calls,
+                       "host_region_ms": [round(x * 1e3, 4) for x in wall][:12],
+                       "launch": "hipGraph of the K step launches (K arcle_step_bbox calls), one replay per region" if graph is not None else "eager",
                        "region_ms": [round(float(x) * 1e3, 4) for x in wall_t.tolist()][:12]},
+            "ordered": ordered,
             "roofline": roofline,
         }
+        if dist is not None:
+            out["collective"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_seen": ranks_seen,
+                                 "devices_visible": ndev, "shared_gpu": bool(shared_gpu),
+                                 "data_path": "none (envs are independent)" if gather is None else "one all_gather_into_tensor of the packed rows per step"}
         if a.config == "c5":
             seeds = [(int(bbox_np[0, e, 0]), int(bbox_np[0, e, 1])) for e in range(n) if 10 <= op_np[0, e] < 20]
             grids = [tasks[0][e] for e in range(n) if 10 <= op_np[0, e] < 20]
@@ -1032,8 +1174,11 @@ def main():
                 torch.cuda.empty_cache()
             out["extras"] = ex
         if world == 1 and not a.no_cpu_baseline and a.config == "c3":
-            out["cpu_baseline"] = cpu_baseline(1000)
-        print(json.dumps(out), flush=True)
+            sustain = Sustained(graph, dev, K * n, K * kernel_avg_s * 1e6) if graph is not None else None
+            out["cpu_baseline"] = cpu_baseline(1000, sustain)
+            if sustain is not None:
+                out["sustained"] = sustain.result()
+        emit(out, a)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

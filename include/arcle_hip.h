@@ -311,7 +311,8 @@ int arcle_reset_from_table_aug(arcle_env* env, const int32_t* task_idx, const ui
                                const uint8_t* aug_perm, void* stream);
 /* Installs the output of ARCLE_STEP_DENSE: dense_out device int32 [n_envs][2]; NULL removes it.  (0, 0) is written for a step that
  * executed no action (the auto-reset step of an env, a skipped step): "no dense term".  The library keeps the pair of every env's
- * current grid in a cache of its own and recomputes it only when a step stored the grid plane. */
+ * current grid in a cache of its own and recomputes it only when a step stored the grid plane; a step or rollout launched WITHOUT
+ * ARCLE_STEP_DENSE on such a handle drops the whole cache first (stream-ordered), so the pairs never describe a grid that moved. */
 int arcle_set_dense_output(arcle_env* env, int32_t* dense_out);
 /* For code that edits state planes BEHIND the library's back (plain copies into the buffers of arcle_get_buffers, host-applied
  * op slots): forget everything derived from the state (the dense-pair cache).  The library's own writers (reset kernels,
@@ -403,6 +404,14 @@ int arcle_get_accounting_ex(arcle_env* env, uint64_t* bytes, uint64_t* issued, u
 
 const char* arcle_last_error(const arcle_env* env);
 int arcle_abi_version(void);
+
+/* ---- test hooks (stable, but not part of the drop-in surface) ---------------------------------------------------------------
+ * The dispatch-order tables the last ordered arcle_step_many / hinted step wrote, copied to host_out uint32 [3][n_envs] after a
+ * device synchronisation: [0] and [1] alternate by step parity, [2] is the identity.  Lets a test check that a table is a
+ * permutation of every XCD's env range with the object operations in the lowest slots.  (Diagnostic builds compiled with
+ * -DARCLE_TRACE_WAVES additionally export a per-wave timestamp dump used by tools/wavetrace.py; it does not exist in the shipped
+ * library and is therefore not declared here.) */
+int arcle_debug_copy_order(arcle_env* env, uint32_t* host_out);
 
 #ifdef __cplusplus
 }

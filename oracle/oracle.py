@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libarcle_oracle.so")
+# ARCLE_ORACLE_LIB: load another build of the same source instead (the ASan / UBSan build of tests/test_oracle_sanitized.py)
+_LIB_PATH = os.environ.get("ARCLE_ORACLE_LIB") or os.path.join(_HERE, "libarcle_oracle.so")
 
 PLANES = ["input", "grid", "selected", "clip", "object", "object_sel", "background", "answer"]
 REC = {  # name -> (byte offset, length) in rec[env]
@@ -83,13 +84,27 @@ def build(force=False):
     return _LIB_PATH
 
 
+def build_sanitized(force=False):
+    """The same source under AddressSanitizer + UndefinedBehaviorSanitizer (gcc), as libarcle_oracle_san.so next to it: the C
+    restatement is pointer arithmetic over int8 planes, the sanitizers check what the golden vectors cannot (reads past a plane,
+    signed overflow, misaligned access).  Loaded through ARCLE_ORACLE_LIB with libasan preloaded (tests/test_oracle_sanitized.py)."""
+    src = os.path.join(_HERE, "arcle_oracle.c")
+    out = os.path.join(_HERE, "libarcle_oracle_san.so")
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    subprocess.check_call(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fopenmp",
+                           "-fPIC", "-shared", "-Wall", "-o", out, src])
+    return out
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not os.environ.get("ARCLE_ORACLE_LIB"):
+            build()
         L = ctypes.CDLL(_LIB_PATH)
         L.oracle_create.restype = ctypes.c_void_p
         L.oracle_create.argtypes = [ctypes.c_int] * 4

@@ -397,6 +397,8 @@ class EmuBackend:
         p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
         if ingress == "bbox5":
             p.op = None
+        if getattr(self, "dense_cache", None) is not None and not flags & 16:
+            self.dense_cache[:] = 0  # (the launcher's rule, arcle_hip.hip launch_step: a step without ARCLE_STEP_DENSE drops the pair cache)
         rc = emu_lib().emu_run(0, ctypes.byref(p))
         assert rc == 0, f"wave emulator reported error {rc} (divergent cross-lane op / non-uniform value)"
         return self.reward.copy(), self.term.copy()

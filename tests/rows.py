@@ -349,6 +349,11 @@ def dense_cache(cls):
                 dst = orc.env.planes[f] if f in orc.env.planes else orc.env.field(f)
                 dst[:] = rows[:, off:off + n].reshape(dst.shape)
                 off += n
+        if s % 7 == 3:  # a step WITHOUT the dense flag moves grids behind the cache's back: the launcher drops the cache for it
+            ing0, pay0, op0 = _random_actions(rng, N, H, W, len(ops))
+            op0[:] = rng.integers(0, 10, N)  # Color: every grid changes
+            be.step(ing0, pay0, op0, 0)
+            orc.step(ing0, pay0, op0)
         r1, t1 = be.step(ing, pay, op, STEP_DENSE)
         r2, t2 = orc.step(ing, pay, op)
         if not (np.array_equal(r1, r2) and np.array_equal(t1, t2)):

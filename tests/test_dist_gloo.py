@@ -124,6 +124,30 @@ def _worker(rank, world, port, out_q):
             assert ggrid.shape == (4, G, H, W) and gr.shape == (4, G)
             chunks.append(ggrid.numpy().copy())
     out["every"] = np.concatenate(chunks)
+    # (5) a consumer that never waits for half of its gathers: the work of step s is dropped for even s, and the work of an odd step
+    # is only waited for after TWO more steps were issued.  The step that re-enters a slot must itself wait for the collective that
+    # still reads that slot's packed rows (ShardedVecEnv._before_step) — the rows SENT are then never rewritten under a gather.
+    env = ShardedVecEnv(G, lambda n, lo, hi: OracleVecEnv(n, lo, hi, tasks))
+    waited, sparse, held = [], [], None
+    grp = env.groups[0]
+    orig_before = env._before_step
+
+    def spy(g):
+        pend = g.inflight[g.slot] if g.t == 0 else None
+        orig_before(g)
+        if pend is not None:
+            assert g.inflight[g.slot] is None and pend.is_completed(), "the slot's gather must have finished before the slot is rewritten"
+            waited.append(1)
+    env._before_step = spy
+    for s in range(S):
+        env.step_bbox(env.local_slice(bbox[s]), env.local_slice(op[s]))
+        work = env.gather_async()
+        if s % 2 == 1:
+            if held is not None:  # the gather of step s-2, two steps (and one slot reuse) late: its OUTPUT buffer has been reused by
+                held[1].wait()    # gather s (documented: valid until the gather after the next one) — only completion is checked
+            held = (s, work)
+            sparse.append(work.wait()[0].numpy().copy())
+    out["sparse"] = (np.stack(sparse), len(waited))
     if rank == 0:
         out_q.put(out)
     dist.barrier()
@@ -163,6 +187,9 @@ def test_two_shards_equal_one_process():
     assert sorted(ia.tolist() + ib.tolist()) == list(range(G))
     assert np.array_equal(ga, want[:, ia]) and np.array_equal(gb, want[:, ib]), "ping-pong groups differ from the 1-process run"
     assert np.array_equal(out["every"], want), "every=4 gathers differ from the 1-process run"
+    sparse, n_waited = out["sparse"]
+    assert np.array_equal(sparse, want[1::2]), "gathers of a consumer that drops every other work differ from the 1-process run"
+    assert n_waited >= S - 2, "every step that re-entered a slot must have waited for the gather still reading it"
 
 
 def test_shard_ranges():

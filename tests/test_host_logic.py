@@ -207,3 +207,26 @@ def test_augmentation_draw_mirror_matches_the_scalar_mirror():
         for i, (g, e) in enumerate(zip(gids, eps)):
             _, _, kk, pp = S.draw_task(99, g, e, [2, 3, 4], flags)
             assert kk == int(k[i]) and pp == perm[i].tolist()
+
+
+@pytest.mark.parametrize("size", [(33, 32), (32, 33), (1, 1025), (128, 4), (40, 40)])
+def test_grid_larger_than_one_wavefront_is_refused_by_name(size):
+    """The reference takes any max_grid_size (base.py:37-49); the HIP path keeps a plane in ONE wavefront: H * W <= 1024, H, W <= 127.
+    Every constructor refuses a larger grid with a ValueError that names the limit — before it touches a device (this runs on CPU)."""
+    from arcle_amd.engine import EnvBatch
+    from arcle_amd.envs import ARCEnv, ARCVecEnv, O2ARCv2Env, RawARCEnv
+    from arcle_amd.loaders import SyntheticLoader
+    loader = SyntheticLoader(n_tasks=2, seed=0, max_size=(5, 5))
+    for make in (lambda: EnvBatch(4, *size), lambda: O2ARCv2Env(data_loader=loader, max_grid_size=size),
+                 lambda: ARCEnv(data_loader=loader, max_grid_size=size), lambda: RawARCEnv(data_loader=loader, max_grid_size=size),
+                 lambda: ARCVecEnv(O2ARCv2Env, 4, loader, max_grid_size=size)):
+        with pytest.raises(ValueError, match=r"H \* W <= 1024"):
+            make()
+
+
+def test_largest_supported_grids_pass_the_size_check():
+    from arcle_amd.engine import check_grid_size
+    for size in ((32, 32), (30, 30), (8, 127), (127, 8), (1, 127), (1, 1)):
+        check_grid_size(*size)
+    with pytest.raises(ValueError):
+        check_grid_size(0, 5)
