@@ -87,6 +87,16 @@ ARCLE_DEV U4 load16(const int8_t* base, uint32_t off) {
 ARCLE_DEV void store16(int8_t* base, uint32_t off, const U4& v) {
   asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 " ARCLE_STORE_POLICY "\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
+// Non-temporal forms for the streaming instantiations (ARCLE_STEPX_STORE_NT / _EARLY_NT; which batch sizes take which is the launcher's
+// table, measured in profiles/round4_experiments.txt).  The load is only used for the speculative grid request the KERNEL issues:
+// a per-instantiation hint on Wave::load_hbm does not survive the optimiser (the method is simplified as a function of its own before it
+// is inlined, and two arms loading the same address become ONE load without the hint).
+ARCLE_DEV U4 load16_nt(const int8_t* base, uint32_t off) {
+  return __builtin_nontemporal_load(reinterpret_cast<const ARCLE_AS_GLOBAL U4*>((uintptr_t)base + off));
+}
+ARCLE_DEV void store16_nt(int8_t* base, uint32_t off, const U4& v) {
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
 // lane-0 stores of the step outputs: uniform base + byte offset held in a VGPR -> `global_store v_off, data, s[base]` (the saddr
 // form).  With the offset in an SGPR the compiler forms the 64-bit address with s_add_u32 / s_addc_u32 per store — scalar
 // instructions, the one kind this kernel is short of (profiles/round3_experiments.txt: 8-11 ns per launch each)
@@ -148,6 +158,12 @@ ARCLE_DEV void arrived(U4& a, U2& b, uint32_t& c, U4& d) { asm volatile("" : "+s
 ARCLE_DEV void arrived3(U4& a, U2& b, uint32_t& c) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c)); }
 #ifndef ARCLE_STOP_AT
 #define ARCLE_STOP_AT 0
+#endif
+#ifndef ARCLE_SPEC_SMALL_MAX
+#define ARCLE_SPEC_SMALL_MAX 2048  // (0 = off) batches up to this size take the speculative grid load as well: one latency chain per launch
+#endif
+#ifndef ARCLE_STREAM_MIN_ENVS
+#define ARCLE_STREAM_MIN_ENVS 28672  // batches from this size on (state 8 x N x 1 KiB ~ the 256 MiB Infinity Cache and beyond) take a streaming instantiation
 #endif
 // Reading back what this wave stored earlier needs no cache maintenance and no wait: a wave's vector memory operations reach its
 // write-through L1 in issue order, so a load issued after a store to the same address returns the stored data (the guarantee
@@ -216,14 +232,21 @@ __device__ __forceinline__ void order_next_step(const StepParams& p, uint32_t xc
   __shared__ uint16_t early_other[ARCLE_ORD_MAX_SLOTS], late_long[ARCLE_ORD_MAX_SLOTS], slot_of[ARCLE_ORD_MAX_SLOTS];
   const uint32_t t = threadIdx.x, wave = t >> 6, base = xcd * rs;
   const uint32_t s0 = t, s1 = t + 512u;
+  // With a step limit (ARCLE_STEP_TRUNCATE, the research env) the longest waves of the next launch are not its object operations but its
+  // auto-resets (new task from the table, augmentation, nine plane stores, the whole observation row): an env whose step counter reads
+  // limit - 1 now will be re-initialised by the next launch.  The counter is read while this launch's waves update it — a stale or
+  // fresh value only moves an env between the two classes (scheduling only).
+  const bool by_limit = (p.flags & ARCLE_STEP_TRUNCATE) != 0u && p.step_limit > 0;
   bool lg0 = false, lg1 = false;
   if (s0 < rs) {
     const uint32_t o = (uint32_t)p.next_op[(size_t)(base + s0) * (size_t)p.next_op_stride];
     lg0 = (p.long_mask >> (o < 63u ? o : 63u)) & 1ull;
+    if (by_limit) lg0 = lg0 || p.cnt[2 * (size_t)(base + s0)] == p.step_limit - 1;
   }
   if (s1 < rs) {
     const uint32_t o = (uint32_t)p.next_op[(size_t)(base + s1) * (size_t)p.next_op_stride];
     lg1 = (p.long_mask >> (o < 63u ? o : 63u)) & 1ull;
+    if (by_limit) lg1 = lg1 || p.cnt[2 * (size_t)(base + s1)] == p.step_limit - 1;
   }
   const unsigned long long b0 = __ballot(lg0), b1 = __ballot(lg1);
   if ((t & 63u) == 0) {
@@ -332,10 +355,29 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = (int)__builtin_elementwise_min((uint32_t)wv, (uint32_t)n_envs - 1u);  // (surplus waves load env N-1's inputs and leave)
   arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0);
+  constexpr bool STREAM = FL >= 0 && (FL & ARCLE_STEPX_STREAM) != 0;
+  w.store_nt = FL >= 0 && (FL & ARCLE_STEPX_STORE_NT) != 0;
   // ordered dispatch: the slot's table entry is requested beside the inputs of the env in the same position — most slots keep it
   uint32_t slot_env = (uint32_t)env;
   if (ORD) slot_env = xl::uload1(arcle::at(order, 4u * (uint32_t)env));
   arcle::StepInputs in = arcle::load_inputs<ING>(w, env, rec, cnt, op, sel);  // in flight while the expansion table is built
+  // streaming regime: the env's grid plane is requested NOW, beside the scalar inputs (its address needs nothing but the env index; the
+  // plane's base travels in the preloaded `order` argument, which these launches do not use otherwise) — two of three steps of the O2ARC
+  // mix read it, and with every wave waiting on HBM the bytes in flight per resident wave are what sets the rate
+  arcle::U4 early_grid = arcle::u4_zero();
+  bool early = false;
+  if (STREAM) {
+    const uint32_t goff = (uint32_t)env * (uint32_t)ARCLE_MAX_CELLS + 16u * (threadIdx.x & 63u);
+    early_grid = (FL & ARCLE_STEPX_EARLY_NT) ? xl::load16_nt(reinterpret_cast<const int8_t*>(order), goff) : xl::load16(reinterpret_cast<const int8_t*>(order), goff);
+    early = true;
+  } else if (WC == 0 && !ACCT && !FEAT && !ORD && ING != arcle::INGRESS_BBOX5_PF) {
+    // small batches of other grid shapes (at most a wave or two per SIMD: the launch is one wave's latency chain, nothing competes for
+    // the memory pipes): the same speculative request, decided by the launcher (StepParams::spec_grid)
+    if (pa.spec_grid) {
+      if (w.live) early_grid = xl::load16(pa.plane[ARCLE_PL_GRID], (uint32_t)env * (uint32_t)pa.PS + 16u * (threadIdx.x & 63u));
+      early = true;
+    }
+  }
   // (the always-true scalar test keeps a block boundary between the loads and the barrier: with straight-line code here the
   // optimiser sinks the four loads below the barrier — into the only block that uses them — and their latency is exposed)
   if (wpw > 0) arcle::lut_init(lds.lut, (int)threadIdx.x);
@@ -352,7 +394,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #ifdef ARCLE_TRACE_WAVES
   arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, t_entry, xl::clock());
 #else
-  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in);
+  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, 0, 0, early, early_grid);
 #endif
 }
 
@@ -471,6 +513,16 @@ struct arcle_env {
   uint32_t* ord_next;
   const int32_t* ord_next_op;
   int32_t ord_next_stride;
+  // one-shot hint of single-step callers (arcle_hint_next_ops): the NEXT step's op indices, consumed by the next arcle_step_* launch,
+  // whose front workgroups then write table [ord_parity ^ 1]; ord_have: table [ord_parity] was written for the step about to be launched
+  const int32_t* hint_op;
+  int32_t hint_stride;
+  int ord_have, ord_parity;
+  int in_many;                // inside arcle_step_many's loop (it manages the tables itself)
+  int stream_min;             // batches of at least this many envs take the streaming instantiations (ARCLE_STREAM_MIN_ENVS / env override)
+  int spec_small_max;         // batches of at most this many envs request the grid plane speculatively (ARCLE_SPEC_SMALL_MAX env override)
+  int stream_policy_override; // tuning runs: ARCLE_STREAM_POLICY = 0 | A | B | H | J for every batch size
+  int wpw_override;           // tuning runs: waves per workgroup of the step launches (ARCLE_WPW = 4 or 8), 0 = the library's choice
   int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
   uint32_t* d_acct;
   uint64_t acct_steps;
@@ -509,6 +561,17 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   if (!e) return ARCLE_ERR_ARG;
   memset(e, 0, sizeof(*e));
   e->order_enabled = 1;
+  e->stream_min = ARCLE_STREAM_MIN_ENVS;
+  if (const char* sm = getenv("ARCLE_STREAM_MIN_ENVS")) e->stream_min = atoi(sm);  // (tuning runs)
+  if (const char* sp = getenv("ARCLE_STREAM_POLICY")) {
+    if (sp[0] == '0' || sp[0] == 'A' || sp[0] == 'B' || sp[0] == 'H' || sp[0] == 'J') e->stream_policy_override = sp[0];
+  }
+  e->spec_small_max = ARCLE_SPEC_SMALL_MAX;
+  if (const char* ss = getenv("ARCLE_SPEC_SMALL_MAX")) e->spec_small_max = atoi(ss);
+  if (const char* wp = getenv("ARCLE_WPW")) {
+    const int v = atoi(wp);
+    if (v == 4 || v == 8) e->wpw_override = v;  // (the expansion table is filled by 256 threads: no smaller workgroups)
+  }
   e->cfg = *cfg;
   int caller_dev = 0;
   (void)hipGetDevice(&caller_dev);
@@ -748,6 +811,7 @@ static bool research_shape(const StepParams& p, uint32_t extra = 0) {
   return p.flags == ((uint32_t)RESEARCH_FLAGS | extra) && p.flat_filter == 1 && p.flat_tail == 0 && p.flat_stride == ARCLE_ROW30_FILTERED_STRIDE;
 }
 #ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiations exist (seconds instead of a minute)
+static bool ordered_instantiation(int ingress, const StepParams& p) { return ingress == arcle::INGRESS_BBOX && p.flags == (uint32_t)HOT_FLAGS; }
 template <int ING>
 static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || p.H != 30 || p.W != 30) return ARCLE_ERR_CONFIG;
@@ -759,16 +823,33 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
     const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));
     hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, 0, st,
                        (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);
+  } else if (p.flags == (uint32_t)HOT_FLAGS && p.spec_grid) {
+#define LAUNCH_STREAM(BITS)                                                                                                                    \
+  hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_STREAM | (BITS), 30>), g, b, 0, st, (const int8_t*)p.rec, \
+                     (const int32_t*)p.cnt, p.op, p.sel, (const uint32_t*)p.plane[ARCLE_PL_GRID], p.n_envs, p.wpw, g.x >> 3, p)
+    switch (p.spec_grid) {
+      case 'B': LAUNCH_STREAM(ARCLE_STEPX_STORE_NT); break;
+      case 'H': LAUNCH_STREAM(ARCLE_STEPX_EARLY_NT); break;
+      case 'J': LAUNCH_STREAM(ARCLE_STEPX_STORE_NT | ARCLE_STEPX_EARLY_NT); break;
+      default: LAUNCH_STREAM(0); break;
+    }
+#undef LAUNCH_STREAM
   } else if (p.flags == (uint32_t)HOT_FLAGS) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS, 30);
   else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, -1, 30);
   return ARCLE_OK;
 }
 #else
+// which (ingress, flag set) combinations have an ordered-dispatch instantiation (30 x 30, FW_FULL, no accounting, 8-wave workgroups)
+static bool ordered_instantiation(int ingress, const StepParams& p) {
+  const bool tuple5 = ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5;
+  if (p.flags == (uint32_t)HOT_FLAGS) return tuple5 || ingress == arcle::INGRESS_POINT;
+  if (p.flags == (uint32_t)HOT_PACK_FLAGS) return tuple5;
+  return tuple5 && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL);
+}
 template <int ING, int FW>
 static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if constexpr (FW == arcle::FW_FULL) {  // the standard 30 x 30 grid: lean instantiations with the dimensions as compile-time constants
     if (p.H == 30 && p.W == 30 && !acct) {
-      if (p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_PACK_FLAGS, 30); return; }
       if constexpr (ING == arcle::INGRESS_BBOX5) {
         if (p.flags == (uint32_t)HOT_FLAGS && p.next_sel && p.wpw == WAVES_PER_WG) {  // records prefetched by the launch's front workgroups
           const dim3 gp(g.x + ARCLE_PF_BLOCKS);
@@ -777,11 +858,38 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
           return;
         }
       }
+      // ordered dispatch (arcle_step_many, or a single step after arcle_hint_next_ops): waves take their env from the order table, the
+      // launch's front workgroups (one per XCD, present iff there is a next step to sort) write the next table
+#define LAUNCH_ORDERED(FLSET, FEATV)                                                                                                  \
+  do {                                                                                                                                \
+    const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));                                                                     \
+    hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, FEATV, (FLSET) | ARCLE_STEPX_ORDERED, 30>), go, b, 0, st, (const int8_t*)p.rec, \
+                       (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);         \
+    return;                                                                                                                           \
+  } while (0)
+      if (p.order && p.wpw == WAVES_PER_WG) {
+        if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5 || ING == arcle::INGRESS_POINT) {
+          if (p.flags == (uint32_t)HOT_FLAGS) LAUNCH_ORDERED(HOT_FLAGS, 0);
+        }
+        if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
+          if (p.flags == (uint32_t)HOT_PACK_FLAGS) LAUNCH_ORDERED(HOT_PACK_FLAGS, 0);
+          if (research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) LAUNCH_ORDERED(RESEARCH_INC_FL, 1);
+        }
+      }
+#undef LAUNCH_ORDERED
+      if (p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_PACK_FLAGS, 30); return; }
       if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
-        if (p.flags == (uint32_t)HOT_FLAGS && p.order && p.wpw == WAVES_PER_WG) {  // arcle_step_many: waves take their env from the order table
-          const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));
-          hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, 0, st, (const int8_t*)p.rec,
-                             (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);
+        if (p.flags == (uint32_t)HOT_FLAGS && p.spec_grid) {  // speculative grid request: the plane's base rides in the preloaded `order` argument
+#define LAUNCH_STREAM(BITS)                                                                                                                    \
+  hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS | ARCLE_STEPX_STREAM | (BITS), 30>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, \
+                     p.op, p.sel, (const uint32_t*)p.plane[ARCLE_PL_GRID], p.n_envs, p.wpw, g.x >> 3, p)
+          switch (p.spec_grid) {
+            case 'B': LAUNCH_STREAM(ARCLE_STEPX_STORE_NT); break;
+            case 'H': LAUNCH_STREAM(ARCLE_STEPX_EARLY_NT); break;
+            case 'J': LAUNCH_STREAM(ARCLE_STEPX_STORE_NT | ARCLE_STEPX_EARLY_NT); break;
+            default: LAUNCH_STREAM(0); break;
+          }
+#undef LAUNCH_STREAM
           return;
         }
       }
@@ -804,6 +912,32 @@ static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStre
   return ARCLE_OK;
 }
 #endif
+
+static bool ensure_order_tables(arcle_env* e);
+
+// Which batches request the grid plane speculatively, and with which cache policies (profiles/round4_experiments.txt,
+// profiles/round4_stream_policy_sweep.txt: us per launch of the C3 mix, same box, plain kernel -> policy):
+//   'A' spec, write-through stores          N <= 2048: the launch is ONE wave's latency chain          3.82 -> 3.68 (1024 envs)
+//   'B' spec, non-temporal stores            state around / beyond the 256 MiB Infinity Cache           16.7 -> 15.3 (32 768), 27.0 -> 21.0 (49 152), 36.5 -> 27.4 (65 536)
+//   'H' non-temporal spec, write-through     ~0.7-1.5 GB of state                                       45.8 -> 40.2 (81 920), 73.6 -> 63.0 (131 072), 90.0 -> 82.9 (163 840)
+//   'J' non-temporal spec, nt stores         multi-GB state                                             108.6 -> 95.2 (196 608), 143.6 -> 126.8 (262 144), 220 -> 196 (393 216)
+// 4096-24576 envs (one to three occupancy rounds, state inside the cache) keep the plain kernel: every variant loses there.
+static int stream_policy(const arcle_env* e, int n) {
+  if (e->stream_policy_override) return e->stream_policy_override == '0' ? 0 : e->stream_policy_override;
+  if (n <= e->spec_small_max) return 'A';
+  if (e->stream_min <= 0 || n < e->stream_min) return 0;
+  if (n < 73728) return 'B';
+  if (n < 180224) return 'H';
+  return 'J';
+}
+
+// workgroups of 8 waves while the batch is one occupancy round or two (7.3 vs 7.7 us per launch at 8192 envs), 4 waves in the streaming
+// regime (76-79 vs 85-88 us at 131072 envs; in-box A/B, profiles/round2_experiments.txt) and for batches of at most two waves per SIMD
+// (256-thread workgroups spread them over twice the CUs: c2 3.85 -> 3.69 us, profiles/round4_experiments.txt)
+static int launch_wpw(const arcle_env* e) {
+  if (e->wpw_override) return e->wpw_override;
+  return (e->cfg.n_envs >= 65536 || e->cfg.n_envs <= e->spec_small_max) ? 4 : WAVES_PER_WG;
+}
 
 static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t* op, int32_t* reward, uint8_t* term,
                        uint32_t flags, void* stream) {
@@ -835,9 +969,12 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.order_next = e->ord_next;
   p.next_op = e->ord_next_op;
   p.next_op_stride = e->ord_next_stride;
-  // workgroups of 8 waves while the batch is one occupancy round or two (7.3 vs 7.7 us per launch at 8192 envs), 4 waves in
-  // the streaming regime (76-79 vs 85-88 us at 131072 envs): in-box A/B, profiles/round2_experiments.txt
-  const int wpw = p.n_envs >= 65536 ? 4 : WAVES_PER_WG;
+  // Speculative grid request / store policy by batch size (StepParams::spec_grid: 0 none, else the policy letter):
+  const bool std30 = p.H == 30 && p.W == 30 && p.PS == ARCLE_MAX_CELLS;
+  const int policy = stream_policy(e, p.n_envs);
+  if (std30) p.spec_grid = (policy && flags == (uint32_t)HOT_FLAGS && (ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5)) ? policy : 0;
+  else p.spec_grid = (policy == 'A' && !(flags & ARCLE_STEP_FEATURE_FLAGS) && ingress != arcle::INGRESS_MASK) ? policy : 0;
+  const int wpw = launch_wpw(e);
   p.wpw = wpw;
   if (flags & ARCLE_STEP_FLAT_OBS) {
     if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
@@ -855,6 +992,32 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   const int fw = width_class(p);
   const bool acct = e->d_acct != nullptr;
   const bool feat = (flags & ARCLE_STEP_FEATURE_FLAGS) != 0;
+  // Ordered dispatch for single-step callers: arcle_hint_next_ops left the NEXT step's op indices (one-shot), and / or the previous
+  // hinted launch left the table for THIS step.  Scheduling only — whatever a table holds is a permutation of every XCD's env range.
+  bool hinted = false;
+  if (!e->in_many && (e->hint_op || e->ord_have)) {
+    const size_t n = (size_t)p.n_envs;
+    const uint32_t slots = g.x * (uint32_t)wpw;
+    bool ok = e->order_enabled && fw == arcle::FW_FULL && p.H == 30 && p.W == 30 && !acct && wpw == WAVES_PER_WG && (size_t)slots == n &&
+              slots / 8u <= ARCLE_ORD_MAX_SLOTS && ordered_instantiation(ingress, p);
+    if (ok && !e->d_order) {  // (allocated by the first such call outside a stream capture, or by arcle_set_dispatch_order(env, 1))
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        ok = false;
+      } else {
+        ok = ensure_order_tables(e);
+      }
+    }
+    if (ok) {
+      p.order = e->ord_have ? e->d_order + (size_t)e->ord_parity * n : e->d_order + 2 * n;
+      p.order_next = e->hint_op ? e->d_order + (size_t)(e->ord_parity ^ 1) * n : nullptr;
+      p.next_op = e->hint_op;
+      p.next_op_stride = e->hint_stride;
+      p.spec_grid = 0;
+      hinted = true;
+    }
+  }
   int rc;
   switch (ingress) {
     case arcle::INGRESS_BBOX: rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, acct, feat, g, b, st, p); break;
@@ -863,6 +1026,15 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     case arcle::INGRESS_BBOX5: rc = launch_step_ing<arcle::INGRESS_BBOX5>(fw, acct, feat, g, b, st, p); break;
     case arcle::INGRESS_BITS: rc = launch_step_ing<arcle::INGRESS_BITS>(fw, acct, feat, g, b, st, p); break;
     default: return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  }
+  if (!e->in_many) {  // the hint is consumed by this launch, sorted or not; the table it wrote (if any) serves the next step only
+    if (hinted && e->hint_op) {
+      e->ord_parity ^= 1;
+      e->ord_have = 1;
+    } else {
+      e->ord_have = 0;
+    }
+    e->hint_op = nullptr;
   }
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
@@ -911,7 +1083,8 @@ static bool ensure_order_tables(arcle_env* e) {
   bool ok = ident && hipMalloc((void**)&e->d_order, 3 * n * sizeof(uint32_t)) == hipSuccess;
   if (ok) {
     for (size_t i = 0; i < n; i++) ident[i] = (uint32_t)i;
-    ok = hipMemcpy(e->d_order + 2 * n, ident, n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    // (all three start as the identity: whatever a launch finds in a table — also one nobody wrote for THIS step — is a permutation)
+    for (int k = 0; k < 3 && ok; k++) ok = hipMemcpy(e->d_order + (size_t)k * n, ident, n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) (void)hipFree(e->d_order);
   }
   if (!ok) {
@@ -927,13 +1100,15 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
   if (!e) return ARCLE_ERR_ARG;
   if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  if (n_steps == 1)  // one step is a single-step call (a pending arcle_hint_next_ops applies to it)
+    return launch_step(e, ingress, sel, op, reward, term, flags, stream);
   const size_t n = (size_t)e->cfg.n_envs, pb = payload_bytes(e, ingress);
   // Host-resident 5-tuple records (a policy on the CPU): step t reads its records from a device staging buffer that the FRONT
   // workgroups of launch t-1 filled from pinned host memory while that launch ran; only step 0 reads across PCIe itself.
   bool prefetch = false;
   // (only where the lean instantiation that carries the copy workgroups applies: the standard 30 x 30 batch with ARCVecEnv's flags)
   const bool pf_kernel = width_class(e->base) == arcle::FW_FULL && e->base.H == 30 && e->base.W == 30 && flags == (uint32_t)HOT_FLAGS &&
-                         !e->d_acct && e->cfg.n_envs < 65536;
+                         !e->d_acct && launch_wpw(e) == WAVES_PER_WG;
   if (pf_kernel && ingress == arcle::INGRESS_BBOX5 && n_steps > 1 && (n & 3) == 0 && sel) {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, sel) == hipSuccess && attr.type == hipMemoryTypeHost) prefetch = true;
@@ -957,8 +1132,15 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
   // Ordered dispatch (device-resident bbox + op arrays or 5-tuple records, the lean 30 x 30 instantiation): launch t's front workgroups
   // sort step t+1's slots — object operations first — from that step's op array; see order_next_step.
   const uint32_t slots = grid_for((int)n, WAVES_PER_WG).x * (uint32_t)WAVES_PER_WG;
-  bool ordered = e->order_enabled && pf_kernel && !prefetch && n_steps > 1 && sel && (size_t)slots == n && slots / 8u <= ARCLE_ORD_MAX_SLOTS &&
-                 ((ingress == arcle::INGRESS_BBOX && op) || ingress == arcle::INGRESS_BBOX5);
+  StepParams probe = e->base;  // (the flag sets that have an ordered instantiation: ARCVecEnv's, + the packed row, + the research step)
+  probe.flags = flags;
+  probe.flat_filter = e->flat_filtered ? 1 : 0;
+  probe.flat_tail = e->flat_tail ? 1 : 0;
+  probe.flat_stride = e->flat_stride;
+  const bool ord_kernel = width_class(e->base) == arcle::FW_FULL && e->base.H == 30 && e->base.W == 30 && !e->d_acct && launch_wpw(e) == WAVES_PER_WG &&
+                          ordered_instantiation(ingress, probe);
+  bool ordered = e->order_enabled && ord_kernel && !prefetch && n_steps > 1 && sel && (size_t)slots == n && slots / 8u <= ARCLE_ORD_MAX_SLOTS &&
+                 (((ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_POINT) && op) || ingress == arcle::INGRESS_BBOX5);
   if (ordered && ingress == arcle::INGRESS_BBOX5) {  // (host-resident records take the prefetch path above, or none)
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, sel) != hipSuccess || attr.type != hipMemoryTypeDevice) ordered = false;
@@ -974,6 +1156,9 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
     }
   }
   int rc = ARCLE_OK;
+  e->in_many = 1;
+  e->hint_op = nullptr;  // (a pending single-step hint does not survive a multi-step call: the tables are this call's now)
+  e->ord_have = 0;
   for (int32_t t = 0; t < n_steps && rc == ARCLE_OK; t++) {
     if (ordered) {
       e->ord_cur = t == 0 ? e->d_order + 2 * n : e->d_order + (size_t)(t & 1) * n;  // (step 0: the identity; nobody looked ahead for it)
@@ -1000,7 +1185,16 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
   e->ord_cur = nullptr;
   e->ord_next = nullptr;
   e->ord_next_op = nullptr;
+  e->in_many = 0;
   return rc;
+}
+
+extern "C" int arcle_hint_next_ops(arcle_env* e, const int32_t* next_op, int32_t stride) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (next_op && stride <= 0) return fail(e, ARCLE_ERR_ARG, "arcle_hint_next_ops: stride must be positive (1 for op arrays, 5 for BBoxWrapper records)");
+  e->hint_op = next_op;
+  e->hint_stride = stride;
+  return ARCLE_OK;
 }
 
 extern "C" int arcle_set_dispatch_order(arcle_env* e, int enable) {

@@ -47,6 +47,14 @@ enum { INGRESS_MASK = 0,    // int8 [N][P] selection masks as given (action['sel
 #define ARCLE_STEPX_FLAT_FILTERED 0x10000
 // ... and that its waves take their env from a dispatch-order table (arcle_step_many: longest operations first, see the kernel)
 #define ARCLE_STEPX_ORDERED 0x20000
+// ... the grid plane is requested speculatively beside the per-env scalar loads — one memory round trip per wave instead of two dependent
+// ones.  Pays where a launch is made of memory latency: the streaming regime (state beyond the 256 MiB Infinity Cache, 16+ occupancy rounds
+// of waves that each wait on HBM) and batches of at most a wave or two per SIMD (the launch IS one wave's latency chain); at 8192 envs —
+// one occupancy round, issue-bound — it loses (profiles/round3_experiments.txt), so it is an instantiation of its own
+#define ARCLE_STEPX_STREAM 0x40000
+// ... with non-temporal plane stores / a non-temporal speculative load (which pays where depends on the batch size: the launcher picks)
+#define ARCLE_STEPX_STORE_NT 0x80000
+#define ARCLE_STEPX_EARLY_NT 0x100000
 // row strides of the 30 x 30 lean instantiations: 3*900 + 10 and 7*900 + 14, rounded up to 16
 #define ARCLE_ROW30_FILTERED_STRIDE 2720
 #define ARCLE_ROW30_FULL_STRIDE 6320
@@ -113,6 +121,8 @@ struct StepParams {
   const int32_t* next_op;  // the next step's op indices: element s at next_op[s * next_op_stride]
   int32_t next_op_stride;  // 1 (op arrays) / 5 (the op field of BBoxWrapper records)
   uint64_t long_mask;      // bit i: op table slot i is an object operation (Move / Rotate / Flip: the longest-running waves)
+  int32_t spec_grid;       // 1: the launch's lean twin loads the grid plane speculatively (ARCLE_STEPX_STREAM); the accounting instantiation
+                           // then counts that load as issued also for the steps that never use it
 };
 
 // 16 bytes of a plane = 4 VGPRs; a first-class vector value so that it always lives in registers
@@ -297,12 +307,14 @@ struct Wave {
   bool count;
   mutable uint32_t issued;
   mutable uint32_t stored;  // planes written (through `store`) since the wave picked up its env: what changed in this step
+  bool store_nt;            // ARCLE_STEPX_STORE_NT instantiations: plane stores are non-temporal instead of write-through
 
   ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, const U2* lut_, int lane_, int ingress_, int fw_, bool resident_, bool count_ = false)
       : p(p_), lds(l), lut(lut_), lane(lane_) {
     count = count_;
     issued = 0;
     stored = 0;
+    store_nt = false;
     ingress = (ingress_ == INGRESS_BBOX5 || ingress_ == INGRESS_BBOX5_PF) ? INGRESS_BBOX : ingress_;  // (the record forms only differ in where the kernel loads from)
     fw = fw_;
     resident = resident_;
@@ -334,7 +346,10 @@ struct Wave {
     return v;
   }
   ARCLE_DEV void store_hbm(int pl, const U4& v) const {
-    if (live) xl::store16(p.plane[pl], poff, v);
+    if (live) {
+      if (store_nt) xl::store16_nt(p.plane[pl], poff, v);
+      else xl::store16(p.plane[pl], poff, v);
+    }
     if (count) issued += (uint32_t)p.PS;
   }
   ARCLE_DEV U4 load_from_row(int pl) const;  // (defined with the row layout, below)
@@ -671,6 +686,7 @@ struct Scratch {
   U4 grid;
   bool have_grid;    // `grid` holds the current grid plane (loaded, requested early, or just produced by the op)
   bool grid_counted; // ACCT: the byte count already includes the grid read (or the op replaced the plane)
+  bool loaded;       // the grid plane was fetched from memory by this step (need_grid)
   uint32_t sel_pending;  // what reset_sel / keep_sel still owe the `selected` plane after the op: 0 nothing (or the op wrote the plane
                          // itself: place), bit 1 = keep_sel's copy of the selection, 1 = reset_sel's zero-fill
   uint32_t bytes;  // algorithmic HBM bytes of this step (SURVEY.md §8d accounting; ACCT instantiations only)
@@ -685,6 +701,7 @@ ARCLE_DEV void need_grid(const Wave& w, Scratch& s) {
   if (!s.have_grid) {
     s.grid = w.load(ARCLE_PL_GRID);
     s.have_grid = true;
+    s.loaded = true;
   }
   if (ACCT && !s.grid_counted) {
     s.bytes += w.p.P;  // the op semantically reads the grid
@@ -1219,6 +1236,7 @@ struct StepOut {
   bool term;       // bool(state['terminated'])
   uint32_t bytes;  // algorithmic HBM bytes of the step (0 for skipped steps)
   uint32_t status; // ARCLE_ST_* bits this env raised in this step (also OR-ed into the handle's sticky status word)
+  bool grid_loaded; // the step loaded the grid plane (accounting of the streaming instantiation's speculative load)
 };
 ARCLE_DEV void raise_status(const StepParams& p, StepOut& out, uint32_t bits) {
   xl::atomic_or(p.status, bits);
@@ -1247,13 +1265,15 @@ ARCLE_DEV void dense_forget(const Wave& w) {
 // re-sampling + augmentation, dense reward, continuation rule, reset_on_submit); the plain instantiations (FEAT = 0) keep
 // them out of the hot kernel's code, registers and SGPR spills
 template <int ING, int FW, int ACCT, int FEAT, int FL = -1>
-ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, const int op) {
+ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, const int op, const bool early = false,
+                            const U4 early_grid = U4{0u, 0u, 0u, 0u}) {
   const StepParams& p = w.p;
   const int P = p.P, W = p.W, lane = w.lane;
   StepOut out;
   out.reward = 0;
   out.bytes = 0;
   out.status = 0;
+  out.grid_loaded = false;
   // FL >= 0: the launch's step flags are this compile-time constant (the launcher picks the instantiation for the common
   // combination), so the flag tests below fold away
   const uint32_t flags = FL >= 0 ? ((uint32_t)FL & 0xffffu) : p.flags;
@@ -1307,6 +1327,11 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   Scratch s;
   s.have_grid = false;
   s.grid_counted = false;
+  s.loaded = false;
+  if (early) {  // (streaming instantiation: the plane was requested beside the per-env scalars and is in registers by now)
+    s.grid = early_grid;
+    s.have_grid = true;
+  }
   s.bytes = 2 * ARCLE_REC_BYTES + 24;  // record R/W + action in + reward/term out
   int submit_inc = 0;
   bool domain_error = false;
@@ -1645,6 +1670,7 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   out.reward = reward;
   out.term = r.term() != 0;
   out.bytes = s.bytes;
+  out.grid_loaded = s.loaded;
   return out;
 }
 
@@ -1697,7 +1723,8 @@ ARCLE_DEV StepInputs load_inputs(const Wave& w, int env) {
 // prefetched — measured no faster on this access pattern, tools/membench.hip "E=2/4/8 seq", and its loop-invariant
 // code motion costs SGPRs on the single-env path.)
 template <int ING, int FW, int ACCT, int FEAT, int FL = -1>
-ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0, uint64_t t_lut = 0) {
+ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0, uint64_t t_lut = 0, const bool early = false,
+                         const U4 early_grid = U4{0u, 0u, 0u, 0u}) {
   const StepParams& p = w.p;
   const int lane = w.lane;
   // (FL >= 0: the kernel wrote the compile-time flag set into its copy of the parameters, so p.flags folds as well)
@@ -1736,7 +1763,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   xl::sink_s(r.w[0] + r.w[1] + r.w[2] + r.w[3] + (uint32_t)cnt0.x + (uint32_t)cnt0.y + in.op + in.payload[0] + in.payload[3]);
   return;
 #endif
-  StepOut out = step_core<ING, FW, ACCT, FEAT, FL>(w, r, cnt0, in.payload, (int)in.op);
+  StepOut out = step_core<ING, FW, ACCT, FEAT, FL>(w, r, cnt0, in.payload, (int)in.op, early, early_grid);
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_core = xl::clock();
 #endif
@@ -1761,6 +1788,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   if (ACCT) {  // what the wave moved besides planes: record + counters in and out, action in, outputs out
     const uint32_t act = ING == INGRESS_MASK ? (uint32_t)p.P : ING == INGRESS_BITS ? 2u * 64u : ING == INGRESS_POINT ? 12u : 20u;  // (records: 20)
     w.issued += 2u * ARCLE_REC_BYTES + 16u + act + 5u;
+    if (p.spec_grid && !out.grid_loaded) w.issued += (uint32_t)p.PS;  // (the lean twin's speculative grid load of a step that never used it)
     if (flags & ARCLE_STEP_TRUNCATE) { w.issued += 1u; out.bytes += 1u; }
     if (FEAT && (flags & ARCLE_STEP_DENSE)) w.issued += 8u;
   }
@@ -2145,6 +2173,7 @@ ARCLE_DEV void wave_transition_row(const StepParams& p, WaveLDS* lds, const U2* 
   out.term = false;
   out.bytes = 0;
   out.status = 0;
+  out.grid_loaded = false;
   I2 cnt;
   cnt.x = cnt.y = 0;
   const int8_t* rin = p.rows_in + (size_t)row * p.rows_in_stride;

@@ -327,6 +327,26 @@ class EnvBatch:
         self._check(self.L.arcle_set_dispatch_order(self._h, 1 if enable else 0), "arcle_set_dispatch_order")
         self._order_enabled = bool(enable)
 
+    def hint_next_ops(self, next_op, stride=1):
+        """One-shot hint for single-step callers (arcle_hint_next_ops): `next_op` = the operations of the step AFTER the next step_*
+        call — an int32 [N] device tensor (stride 1), an int32 [N, 5] record tensor (its op column is used, stride 5), or a raw device
+        address with `stride`.  The next step launch then sorts the following launch's dispatch slots (object operations first) while
+        it runs; scheduling only, results never depend on it.  None withdraws a pending hint."""
+        if next_op is None:
+            ptr, stride = 0, 1
+        elif isinstance(next_op, int):
+            ptr = next_op
+        else:
+            assert next_op.dtype == torch.int32 and next_op.is_contiguous() and next_op.shape[0] == self.N
+            if next_op.dim() == 2:
+                assert next_op.shape[1] == 5, "records are int32 [N, 5] = (x1, y1, x2, y2, operation)"
+                ptr, stride = next_op.data_ptr() + 16, 5
+            else:
+                ptr = next_op.data_ptr()
+        rc = self.L.arcle_hint_next_ops(self._h, ptr, int(stride))
+        if rc != 0:
+            self._check(rc, "arcle_hint_next_ops")
+
     def prepare_dispatch_order(self):
         """Before capturing step_many into a hipGraph: allocate the dispatch-order tables (a capture cannot) — but only if ordered
         dispatch is on; a caller's set_dispatch_order(False) stays in force."""

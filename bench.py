@@ -340,6 +340,8 @@ def emit(out, a):
         o = out["ordered"]
         c["ordered"] = {"value": _r(o["value"], 6), "ms_per_step": _r(o["ms_per_step"], 6), "avg_launch_us": _r(o["avg_launch_us"]),
                         "frac": _r(o.get("frac")), "form": "one arcle_step_many call (ordered dispatch), same clock"}
+        if o.get("per_step_calls_hinted"):
+            c["ordered"]["per_step_calls_hinted_us"] = _r(o["per_step_calls_hinted"]["avg_launch_us"])
     rl = out.get("roofline")
     if rl:
         c["roofline"] = {k: _r(rl[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_by_traffic", "kernel", "avg_launch_us",
@@ -549,15 +551,16 @@ def research_env_leg(dev, n, bbox, op, K=200):
             ops = super().create_operations()
             ops[33] = actions.reset_sel(actions.crop_grid)
             return ops
+    limit = int(os.environ.get("ARCLE_BENCH_RESEARCH_LIMIT", "100"))  # (tuning runs: how much of the step its auto-resets are)
     v = ARCVecEnv(Crop, n, SyntheticLoader(n_tasks=400, seed=1, max_size=(30, 30)), device=dev, seed=7, autoreset="resample", augment=("permute", "rot90"),
-                  dense_reward=True, max_episode_steps=100)
+                  dense_reward=True, max_episode_steps=limit)
     v.reset()
     rows = v.enable_flat_rows(filtered=True)  # a live [N, 2710] mirror of the FilterO2ARC rows, kept by the step kernel
     K = min(K, bbox.shape[0])
     b = v.batch
     # desynchronise the episodes first (all envs start at step 0: left alone, every env would hit TimeLimit in the same launch —
     # a training run is never in that state after its first episode)
-    b.cnt[:, 0] = torch.randint(0, 100, (n,), device=dev, dtype=torch.int32)
+    b.cnt[:, 0] = torch.randint(0, min(limit, 100), (n,), device=dev, dtype=torch.int32)
     for i in range(100):
         b.step_bbox_ptr(bbox[i % K].data_ptr(), op[(i * 7 + 3) % K].data_ptr(), v.flags, torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
@@ -569,6 +572,16 @@ def research_env_leg(dev, n, bbox, op, K=200):
         alg, issued, _ = counted_bytes(b, enqueue, K, dev)
         v._refresh_rows()  # (the byte count replayed the steps and restored the state: bring the mirrored rows back in line)
         sec, _ = graph_time(dev, enqueue, K)
+        if name == "rows_incremental":  # ... and with every step hinting the next step's operations (what ARCVecEnv.step_many / capture do)
+            b.set_dispatch_order(True)
+
+            def enqueue_hinted(sh, FL=FL):
+                for i in range(K):
+                    b.hint_next_ops(op[(i + 1) % K].data_ptr())
+                    b.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, sh)
+            sec_h, _ = graph_time(dev, enqueue_hinted, K)
+            v._refresh_rows()
+            out["rows_incremental_hinted_us"] = sec_h * 1e6
         out[name] = {"value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6,
                      "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 1, research flags, 30>", sec, alg, issued, n,
                                                 note="algorithmic = the step's planes + 56 B, + the dense reward's answer read when the grid moved, "
@@ -611,13 +624,21 @@ def ingress_leg(dev, n, bbox, op, K=64):
                 assert rc == 0
         alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
         sec, _ = graph_time(dev, enqueue, K)
+
+        def enqueue_warm(sh, pay=pay, fn=fn, batch=batch, FL=FL):  # the same launches over 8 payload batches: payload + state stay inside the
+            for i in range(K):                                      # Infinity Cache — masks a policy wrote on the device just before the step
+                rc = fn(batch._h, pay[i & 7].data_ptr(), op[i].data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh)
+                assert rc == 0
+        sec_warm, _ = graph_time(dev, enqueue_warm, K)
+        out[form + "_payload_cache_resident_us"] = sec_warm * 1e6
         out[form] = {"value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6,
                      "payload_bytes_per_env": 900 if form == "mask" else 128,
                      "roofline": roofline_block(f"arcle_step_kernel<{form}, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, n)}
     batch = make_batch(dev, n)
     sec, _ = graph_time(dev, lambda sh: [batch.pack_mask_bits(masks[i], pay[i]) for i in range(K)], K)
     out["pack_mask_bits_us"] = sec * 1e6
-    out["mode"] = "full H x W selection masks: int8 [N,900] / bit-packed [N,128]"
+    out["mode"] = ("full H x W selection masks: int8 [N,900] / bit-packed [N,128]; headline figures with 64 distinct payload batches (472 MB of int8 "
+                   "masks: every launch streams its 7.4 MB from HBM), *_payload_cache_resident_us with 8")
     out["value"], out["unit"], out["us_per_step_batch"] = out["mask"]["value"], "env-steps/s", out["mask"]["us_per_step_batch"]
     return out
 
@@ -804,6 +825,15 @@ def other_configs_leg(dev, K=100):
         alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
         sec, _ = graph_time(dev, enqueue, K)
         leg = {"workload": cfg["name"], "envs": n, "us_per_step_batch": sec * 1e6, "value": n / sec, "unit": "env-steps/s"}
+        if name == "c4":  # the same single-step calls with the next step's ops hinted (ordered dispatch of the packed-row instantiation)
+            batch.set_dispatch_order(True)
+
+            def enqueue_hinted(sh, batch=batch, bbd=bbd, ood=ood, FL=FL):
+                for i in range(K):
+                    batch.hint_next_ops(ood[(i + 1) % K].data_ptr())
+                    batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), FL, sh)
+            sec_h, _ = graph_time(dev, enqueue_hinted, K)
+            leg["hinted_us_per_step_batch"] = sec_h * 1e6
         rl = roofline_block("arcle_step_kernel", sec, alg, issued, n, PS=batch.PS, planes=len(batch.planes))
         if name == "c2":
             rl.update({"bound": "launch-floor", "launch_floor_us": 2.5,
@@ -988,7 +1018,7 @@ def main():
     # array while a step runs and every launch's front workgroups sort the NEXT launch's dispatch slots — object operations to
     # the waves that start first (scheduling only: same launches, same results) -> the top-level `ordered` block.
     graph = None
-    graph_ordered = None
+    graph_ordered = graph_hinted = None
     many = a.config == "c3" and gather is None and not a.no_ordered and K > 1
     many_out = (torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)) if many else None
     if not a.no_graph and not (gather is not None and shared_gpu):
@@ -1010,9 +1040,17 @@ def main():
                 graph_ordered = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_ordered, stream=cap):
                     batch.step_many("bbox", bbox[Wm:Wm + K], op[Wm:Wm + K], FL, many_out[0], many_out[1])
+                # ... and the single-step calls again, each preceded by the one-shot hint arcle_hint_next_ops(next step's ops): what a
+                # caller of step() gets who knows its operations one step ahead (the last step hints the region's first: replays chain)
+                graph_hinted = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_hinted, stream=cap):
+                    cs = torch.cuda.current_stream(dev)
+                    for i in range(Wm, Wm + K):
+                        batch.hint_next_ops(optr[(i + 1) % S if i + 1 < Wm + K else Wm % S])
+                        step(i, cs.cuda_stream, cs)
         except Exception as exc:  # capture unsupported: eager launches
             print(f"bench: hipGraph capture failed ({exc}); eager launches", file=sys.stderr)
-            graph = graph_ordered = None
+            graph = graph_ordered = graph_hinted = None
             if gather is not None:
                 done[0] = done[1] = None
 
@@ -1060,26 +1098,30 @@ def main():
         wall.append(time.perf_counter() - t0)
         devt.append(ev0.elapsed_time(ev1) * 1e-3)
         kern.append(devt[-1] / K)
-    ordered = None
-    if graph_ordered is not None:  # the same K launches as ONE arcle_step_many call (ordered dispatch); same event clock, this rank
+    def time_graph(g):  # same event clock and the same number of regions as the headline; the state simply keeps evolving
+        for w_ in range(3):
+            g.replay()
         ts = []
-        for w_ in range(3):  # (the first replays fill the order tables' caches)
-            restore_snapshot()
-            graph_ordered.replay()
-        for r in range(min(R, 9)):
-            restore_snapshot()
+        for r in range(min(R, 15)):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(dev)
             ev0.record(stream)
-            graph_ordered.replay()
+            g.replay()
             ev1.record(stream)
             wait_gpu(ev1)
             ts.append(ev0.elapsed_time(ev1) * 1e-3)
-        t_ord = float(np.median(ts))
+        return float(np.median(ts))
+    ordered = None
+    if graph_ordered is not None:  # the same K launches as ONE arcle_step_many call (ordered dispatch); same event clock, this rank
+        t_ord = time_graph(graph_ordered)
         ordered = {"value": K * n * world / t_ord, "unit": "env-steps/s", "ms_per_step": t_ord / K * 1e3, "avg_launch_us": t_ord / K * 1e6,
                    "kernel": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|ordered, 30>",
                    "form": "ONE arcle_step_many call for the K steps (ARCVecEnv.capture): launch t sorts step t+1's dispatch slots, object ops first; "
                            "scheduling only; timed on this rank with the same event clock, N x this for the node"}
+        if graph_hinted is not None:
+            t_h = time_graph(graph_hinted)
+            ordered["per_step_calls_hinted"] = {"value": K * n * world / t_h, "ms_per_step": t_h / K * 1e3, "avg_launch_us": t_h / K * 1e6,
+                                                "form": "K arcle_step_bbox calls, each preceded by arcle_hint_next_ops(next step's ops)"}
     wall_t = torch.tensor(devt if device_clock else wall, dtype=torch.float64)
     ranks_seen = world
     if dist is not None:  # max over ranks, per region

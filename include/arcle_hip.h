@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ARCLE_ABI_VERSION 3
+#define ARCLE_ABI_VERSION 4
 #define ARCLE_MAX_OPS 64
 #define ARCLE_MAX_CELLS 1024 /* H*W <= 1024 (one 64-lane wavefront x 16 cells) */
 /* default per-env plane stride: H*W rounded up to a whole number of 128-byte lines (30x30 -> 1024 B), so that no two
@@ -272,11 +272,21 @@ int arcle_pack_mask_bits(arcle_env* env, const int8_t* sel, uint8_t* bits, void*
  * records, the same 30 x 30 batch and flags, n_envs a multiple of 64 and <= 8192, one extra workgroup per XCD at the front of
  * launch t reads step t+1's op indices and writes the order in which launch t+1 hands envs to its waves: object operations to the
  * waves that start first (a permutation inside every XCD's env range; 12 B per env of tables, allocated by the first such call
- * outside a stream capture).  It is scheduling only — results, outputs and their order in memory are exactly those of n_steps
+ * outside a stream capture).  The same holds for BBOX / BBOX5 with the fused packed row (ARCLE_STEP_PACK_OBS) or the research env's flag set
+ * with incremental FilterO2ARC rows, and for POINT tuples.  It is scheduling only — results, outputs and their order in memory are exactly those of n_steps
  * arcle_step_* calls, and a caller that rewrites step t+1's actions while step t runs loses nothing but the ordering.
  * arcle_set_dispatch_order(env, 0) turns it off (default on); (env, 1) also allocates the tables at once — call it before capturing
  * arcle_step_many into a hipGraph on a handle that has not run an ordered arcle_step_many yet. */
 int arcle_set_dispatch_order(arcle_env* env, int enable);
+/* Ordered dispatch for callers that step ONE launch at a time (the Gym loop, examples/example_bbox.py:13-15) but know the next step's
+ * operations a step ahead (action chunks, scripted / replayed policies, actors that run one step behind their learner): a ONE-SHOT
+ * hint.  next_op: device int32, element s at next_op[s * stride] = the operation env s will receive in the step AFTER the next
+ * arcle_step_* call (stride 1: an op array; 5: the op field of BBoxWrapper records, pass act5 + 4).  The next arcle_step_bbox / _bbox5 /
+ * _point launch (the flag sets ARCVecEnv / ShardedVecEnv / the research env step with, 30 x 30, n_envs a multiple of 64 and <= 8192)
+ * then carries the front workgroups that sort the following launch's dispatch slots, and that following launch hands out its envs in
+ * that order — exactly what arcle_step_many does between its own launches.  Scheduling only: results do not depend on the hint, a
+ * wrong or stale hint costs nothing but the ordering, an ineligible launch ignores it.  NULL withdraws a pending hint. */
+int arcle_hint_next_ops(arcle_env* env, const int32_t* next_op, int32_t stride);
 int arcle_step_many(arcle_env* env, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
                     uint8_t* term, uint32_t flags, void* stream);
 

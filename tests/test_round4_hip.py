@@ -56,7 +56,7 @@ def _compare_sample(batch, orc, sample, fields, what):
     assert np.array_equal(batch.cnt[idx].cpu().numpy(), orc.counters()), f"{what}: counters differ"
 
 
-@pytest.mark.parametrize("form", ["per_step_calls", "ordered_step_many", "ordered_bbox5"])
+@pytest.mark.parametrize("form", ["per_step_calls", "ordered_step_many", "ordered_bbox5", "hinted_calls"])
 @pytest.mark.parametrize("max_trial", [-1, 3])
 def test_bench_headline_kernels_vs_oracle_8192(form, max_trial):
     """What bench.py times, checked DIRECTLY against the oracle: 8192 envs x 64 steps of bench.make_tasks / make_actions with
@@ -83,6 +83,13 @@ def test_bench_headline_kernels_vs_oracle_8192(form, max_trial):
         for s in range(K):
             r, t = batch.step_bbox(bb[s], op[s], FL)
             rew[s], trm[s] = r, t
+    elif form == "hinted_calls":  # single-step calls, each told the NEXT step's operations (arcle_hint_next_ops)
+        rew, trm = torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)
+        for s in range(K):
+            if s + 1 < K:
+                batch.hint_next_ops(op[s + 1])
+            r, t = batch.step_bbox(bb[s], op[s], FL)
+            rew[s], trm[s] = r, t
     elif form == "ordered_step_many":
         batch.set_dispatch_order(True)
         rew, trm = batch.step_many("bbox", bb, op, FL)
@@ -101,6 +108,209 @@ def test_bench_headline_kernels_vs_oracle_8192(form, max_trial):
         ended += int(t2.sum())
     assert ended > 0, "the trace must exercise the auto-reset path"
     _compare_sample(batch, orc, sample, FIELDS_O2, form)
+
+
+def _order_tables(b):
+    n = b.N
+    tab = np.zeros((3, n), np.uint32)
+    assert b.L.arcle_debug_copy_order(b._h, tab.ctypes.data) == 0
+    return tab.astype(np.int64)
+
+
+@pytest.mark.parametrize("variant", ["bbox", "point", "bbox5", "bbox_pack"])
+def test_hinted_single_steps_are_scheduling_only(variant):
+    """arcle_hint_next_ops + single-step calls (the flag sets ARCVecEnv / ShardedVecEnv step with): rewards, terminated flags, packed
+    rows and every byte of state equal the unhinted run — wrong hints (the ops of some other step) and dropped hints included — and
+    the table a hinted launch wrote is a permutation of every XCD's env range with the hinted step's object operations in the lowest
+    slots."""
+    import torch
+    import bench
+    from arcle_amd.engine import STEP_PACK_OBS
+    n, K, dev = 4096, 20, torch.device("cuda:0")
+    bb_np, op_np = bench.make_actions(K, n, 321)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    xy = bb[:, :, :2].contiguous()
+    act5 = torch.cat([bb, op[:, :, None]], 2).contiguous()
+    a, b = bench.make_batch(dev, n, seed=11), bench.make_batch(dev, n, seed=11)
+    FL = a.elide_flag | 1
+    if variant == "bbox_pack":
+        FL |= STEP_PACK_OBS
+        pa, pb = a.set_packed_output(), b.set_packed_output()
+
+    def one(batch, s):
+        if variant == "point":
+            return batch.step_point(xy[s], op[s], FL)
+        if variant == "bbox5":
+            return batch.step_bbox5(act5[s], FL)
+        return batch.step_bbox(bb[s], op[s], FL)
+    for s in range(K):
+        ra, ta = one(a, s)
+        ra, ta = ra.clone(), ta.clone()
+        if s + 1 < K and s % 7 != 5:  # (every 7th step: no hint — the next launch must fall back to the identity order)
+            wrong = s % 5 == 3        # (every 5th: the ops of ANOTHER step — costs nothing but the ordering)
+            nxt = (s + 4) % K if wrong else s + 1
+            b.hint_next_ops(act5[nxt] if variant == "bbox5" else op[nxt])
+            hinted_for = nxt
+        else:
+            hinted_for = None
+        rb, tb = one(b, s)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb), (variant, s)
+        if variant == "bbox_pack":
+            assert torch.equal(pa, pb), (variant, s)
+        if hinted_for is not None and s in (0, 1, 8):
+            torch.cuda.synchronize()
+            tabs, rs = _order_tables(b), n // 8
+            lg = (op_np[hinted_for] >= 20) & (op_np[hinted_for] < 28)
+            good = 0
+            for t in tabs[:2]:
+                ok = True
+                for x in range(8):
+                    seg = t[x * rs:(x + 1) * rs]
+                    assert sorted(seg.tolist()) == list(range(x * rs, (x + 1) * rs)), f"{variant} step {s}: XCD {x} is not a permutation of its env range"
+                    L = int(lg[x * rs:(x + 1) * rs].sum())
+                    ok = ok and bool(lg[seg[:L]].all()) and not bool(lg[seg[L:]].any())
+                good += ok
+            assert good >= 1, f"{variant} step {s}: no table holds the hinted step's object operations in the lowest slots"
+    torch.cuda.synchronize()
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), (variant, k)
+    assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt) and a.status() == b.status() == 0
+
+
+def test_vec_env_next_operation_argument_and_research_flags_ordered():
+    """ARCVecEnv.step_bbox(bbox, op, next_operation=...) and the research env's flag set (dense reward, TimeLimit, device-drawn tasks,
+    incremental FilterO2ARC rows) with ordered dispatch: identical to a twin that never hints / has ordered dispatch switched off."""
+    import torch
+    import bench
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    n, K, dev = 2048, 24, torch.device("cuda:0")
+    bb_np, op_np = bench.make_actions(K, n, 99)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    kw = dict(device=dev, seed=5, autoreset="resample", augment=("permute", "rot90"), dense_reward=True, max_episode_steps=9)
+    va = ARCVecEnv(O2ARCv2Env, n, SyntheticLoader(n_tasks=60, seed=2, max_size=(30, 30)), **kw)
+    vb = ARCVecEnv(O2ARCv2Env, n, SyntheticLoader(n_tasks=60, seed=2, max_size=(30, 30)), **kw)
+    va.batch.set_dispatch_order(False)
+    for v in (va, vb):
+        v.reset()
+        v.enable_flat_rows(filtered=True)
+    for s in range(K):
+        _, ra, ta, tra, _ = va.step_bbox(bb[s], op[s])
+        _, rb, tb, trb, _ = vb.step_bbox(bb[s], op[s], next_operation=op[s + 1] if s + 1 < K else None)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(tra, trb), s
+        assert torch.equal(va.rows, vb.rows), s
+    # K steps per call: step_many on the ordered twin (the library hints every step itself) vs single steps on the other
+    _, rm, tm, trm, _ = vb.step_many(bb, op)
+    for s in range(K):
+        _, ra, ta, tra, _ = va.step_bbox(bb[s], op[s])
+        assert torch.equal(ra, rm[s]) and torch.equal(ta, tm[s]) and torch.equal(tra, trm[s]), s
+    assert torch.equal(va.rows, vb.rows)
+    for k in va.batch.planes:
+        assert torch.equal(va.batch.planes[k], vb.batch.planes[k]), k
+    va.check_errors(), vb.check_errors()
+    assert _order_tables(vb.batch)[:2].std() > 0, "the research step must have run with ordered dispatch (tables written)"
+
+
+class _Env:
+    """Tuning overrides the library reads at arcle_create (ARCLE_STREAM_POLICY, ARCLE_SPEC_SMALL_MAX, ARCLE_WPW)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("policy", ["0", "A", "B", "H", "J"])
+@pytest.mark.parametrize("form", ["bbox", "bbox5"])
+def test_speculative_grid_instantiations_vs_oracle(policy, form):
+    """The instantiations that request the grid plane beside the per-env scalars (ARCLE_STEPX_STREAM with write-through / non-temporal
+    stores and a plain / non-temporal speculative load: policies A, B, H, J — what small and very large batches run), forced onto an
+    8192-env batch through ARCLE_STREAM_POLICY, against the oracle: rewards and terminated flags of every step, every state field of a
+    448-env sample, max_trial = 3 so that auto-resets (which discard the speculative plane) are frequent."""
+    import torch
+    import bench
+    n, K, dev = 8192, 48, torch.device("cuda:0")
+    tasks = bench.make_tasks(n, 1000)
+    bb_np, op_np = bench.make_actions(K, n, 2000)
+    with _Env(ARCLE_STREAM_POLICY=policy):
+        from arcle_amd import actions
+        from arcle_amd.engine import EnvBatch
+        from arcle_amd.envs import O2ARCv2Env
+        batch = EnvBatch(n, 30, 30, 3, "o2arc", dev)
+    batch.set_op_table(actions.table_descs(O2ARCv2Env.default_operations()))
+    batch.set_tasks_padded(*tasks)
+    batch.reset()
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    act5 = torch.cat([bb, op[:, :, None]], 2).contiguous()
+    rew, trm = torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)
+    for s in range(K):
+        r, t = batch.step_bbox(bb[s], op[s], 3) if form == "bbox" else batch.step_bbox5(act5[s], 3)
+        rew[s], trm[s] = r, t
+    torch.cuda.synchronize()
+    assert batch.status() == 0
+    sample = _sample(n, 352, 15)
+    orc = _oracle_for(sample, tasks, 30, 30, 3, "o2arc", O.o2arc_ops())
+    rew, trm = rew.cpu().numpy(), trm.cpu().numpy()
+    for s in range(K):
+        r2, t2 = orc.step("bbox", bb_np[s][sample], op_np[s][sample], O.STEP_AUTORESET)
+        assert np.array_equal(rew[s][sample], r2) and np.array_equal(trm[s][sample], t2), f"policy {policy} {form}: reward / terminated differ at step {s}"
+    _compare_sample(batch, orc, sample, FIELDS_O2, f"policy {policy} {form}")
+
+
+@pytest.mark.parametrize("n", [40960, 131072, 196608])
+def test_streaming_regime_at_its_own_sizes_vs_oracle(n):
+    """The batch sizes at which the launcher itself switches policy (B from 28 672, H from 73 728, J from 180 224 envs): 131 072 envs is
+    bench.py's out-of-cache leg.  10 steps of bench's streams, a 600-env sample against the oracle, every field."""
+    import torch
+    import bench
+    K, dev = 10, torch.device("cuda:0")
+    tasks = bench.make_tasks(n, 1000)
+    bb_np, op_np = bench.make_actions(K, n, 2000)
+    batch = bench.make_batch(dev, n, seed=1000)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    rew, trm = batch.step_many("bbox", bb, op, 3)
+    torch.cuda.synchronize()
+    assert batch.status() == 0
+    sample = _sample(n, 504, 21)
+    orc = _oracle_for(sample, tasks, 30, 30, -1, "o2arc", O.o2arc_ops())
+    rew, trm = rew.cpu().numpy(), trm.cpu().numpy()
+    for s in range(K):
+        r2, t2 = orc.step("bbox", bb_np[s][sample], op_np[s][sample], O.STEP_AUTORESET)
+        assert np.array_equal(rew[s][sample], r2) and np.array_equal(trm[s][sample], t2), s
+    _compare_sample(batch, orc, sample, FIELDS_O2, f"streaming @ {n}")
+    del batch
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("small_max,wpw", [(0, None), (4096, None), (4096, 8), (0, 4)])
+def test_small_batch_speculation_and_workgroup_size_are_invisible(small_max, wpw):
+    """Batches of at most 2048 envs request the grid speculatively and run 256-thread workgroups by default; every test of this suite
+    with a small batch therefore exercises those paths.  Here the same differential traces run with the speculation off / on and both
+    workgroup sizes (ARCLE_SPEC_SMALL_MAX, ARCLE_WPW): 30x30 with ARCVecEnv's flags (the lean instantiations), a FAST-width and a
+    generic-width shape, ARCEnv / RawARCEnv tables, record and point ingress."""
+    with _Env(ARCLE_SPEC_SMALL_MAX=small_max, ARCLE_WPW=wpw):
+        for H, W, flags in ((30, 30, 3), (30, 30, 0), (24, 32, 1), (10, 10, 3), (7, 12, 1)):
+            errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), H, W, N=160, S=64, seed=H * 17 + W + flags, max_trial=3, flags=flags,
+                                          bad_ops=True)
+            assert not errs, f"{H}x{W} flags {flags}: " + "\n".join(errs[:6])
+        errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), 30, 30, N=96, S=48, seed=4, max_trial=3, flags=3, new_forms=True)
+        assert not errs, "\n".join(errs[:6])
+        for kind, ops in (("arc", O.arc_ops()), ("raw", O.raw_ops())):
+            errs = B.random_trace_compare(B.HipBackend, kind, ops, 10, 10, N=64, S=64, seed=9, max_trial=3, flags=1)
+            assert not errs, kind + ": " + "\n".join(errs[:6])
 
 
 def test_c4_65536_envs_packed_rows_vs_oracle():
