@@ -163,7 +163,7 @@ ARCLE_DEV void arrived3(U4& a, U2& b, uint32_t& c) { asm volatile("" : "+s"(a), 
 #define ARCLE_SPEC_SMALL_MAX 2048  // (0 = off) batches up to this size take the speculative grid load as well: one latency chain per launch
 #endif
 #ifndef ARCLE_STREAM_MIN_ENVS
-#define ARCLE_STREAM_MIN_ENVS 28672  // batches from this size on (state 8 x N x 1 KiB ~ the 256 MiB Infinity Cache and beyond) take a streaming instantiation
+#define ARCLE_STREAM_MIN_ENVS 34816  // batches from this size on (state 8 x N x 1 KiB beyond the 256 MiB Infinity Cache) take a streaming instantiation
 #endif
 // Reading back what this wave stored earlier needs no cache maintenance and no wait: a wave's vector memory operations reach its
 // write-through L1 in issue order, so a load issued after a store to the same address returns the stored data (the guarantee
@@ -176,6 +176,8 @@ ARCLE_DEV void own_stores_visible() { asm volatile("" ::: "memory"); }
 // scalar instruction costs a launch 8-11 ns, the first ~40 extra vector instructions per wave nothing), so the per-env
 // arithmetic that only feeds cell masks and LDS addresses is moved over with this.
 ARCLE_DEV uint32_t tov(uint32_t x) { return __builtin_amdgcn_perm(x, x, 0x03020100u); }
+// v_perm_b32: byte k of the result = byte sel.b[k] of the 8-byte table {hi, lo} (selector values 0-3: lo, 4-7: hi)
+ARCLE_DEV uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // a volatile no-op on a scalar: the optimiser can neither speculate it nor fold the branch it sits in into a select — keeps a rare
 // case a BRANCH, so that its arithmetic stays off the common path
 ARCLE_DEV int rare_s(int v) {
@@ -915,19 +917,22 @@ static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStre
 
 static bool ensure_order_tables(arcle_env* e);
 
-// Which batches request the grid plane speculatively, and with which cache policies (profiles/round4_experiments.txt,
-// profiles/round4_stream_policy_sweep.txt: us per launch of the C3 mix, same box, plain kernel -> policy):
+// Which batches request the grid plane speculatively, and with which cache policies (profiles/round4_experiments.txt; sweeps in
+// profiles/round4_stream_policy_sweep*.txt: us per launch of the C3 mix, same box, action stream cache-resident, plain kernel -> policy):
 //   'A' spec, write-through stores          N <= 2048: the launch is ONE wave's latency chain          3.82 -> 3.68 (1024 envs)
-//   'B' spec, non-temporal stores            state around / beyond the 256 MiB Infinity Cache           16.7 -> 15.3 (32 768), 27.0 -> 21.0 (49 152), 36.5 -> 27.4 (65 536)
-//   'H' non-temporal spec, write-through     ~0.7-1.5 GB of state                                       45.8 -> 40.2 (81 920), 73.6 -> 63.0 (131 072), 90.0 -> 82.9 (163 840)
-//   'J' non-temporal spec, nt stores         multi-GB state                                             108.6 -> 95.2 (196 608), 143.6 -> 126.8 (262 144), 220 -> 196 (393 216)
-// 4096-24576 envs (one to three occupancy rounds, state inside the cache) keep the plain kernel: every variant loses there.
+//   'B' spec, non-temporal stores            state beyond the 256 MiB Infinity Cache                    19.0 -> 17.1 (36 864), 29.2 -> 21.2 (49 152), 37.4 -> 26.2 (65 536),
+//                                                                                                       55.4 -> 40.9 (98 304)
+//   'H' non-temporal spec, write-through     ~1 GB of state                                             65.5 -> 57.2 (114 688), 77.3 -> 67.0 (131 072)
+//   'J' non-temporal spec, nt stores         multi-GB state                                             97.2 -> 82.9 (163 840), 117 -> 99.2 (196 608), 228 -> 199 (393 216)
+// 4096-32768 envs (state inside the cache: what a launch writes through is what the next one finds there) keep the plain kernel — every
+// variant loses there (32 768: 14.0 plain, 15.5 B, 16.5 H).  With an action stream that itself streams from HBM (hundreds of distinct
+// action batches) the windows shift (B already wins at 32 768, H from 81 920): the table is set for a policy that writes one batch per step.
 static int stream_policy(const arcle_env* e, int n) {
   if (e->stream_policy_override) return e->stream_policy_override == '0' ? 0 : e->stream_policy_override;
   if (n <= e->spec_small_max) return 'A';
   if (e->stream_min <= 0 || n < e->stream_min) return 0;
-  if (n < 73728) return 'B';
-  if (n < 180224) return 'H';
+  if (n < 110592) return 'B';
+  if (n < 155648) return 'H';
   return 'J';
 }
 

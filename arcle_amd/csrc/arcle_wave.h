@@ -1062,48 +1062,89 @@ ARCLE_HD uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
 struct TaskDraw {
   int problem, sub;  // index into pair_off / pair_cnt, pair within the problem
   int rot_k;         // np.rot90 count 0..3
-  uint64_t perm;     // colour permutation, nibble c = perm[c] (c < 10); identity = 0x9876543210
+  uint64_t perm;     // colour permutation, nibble c = perm[c] (c < 10; nibbles 10..15 stay the identity)
 };
-#define ARCLE_PERM_IDENTITY 0x9876543210ull
+#define ARCLE_PERM_IDENTITY 0xFEDCBA9876543210ull
+// floor(r / 2^32 * n) for a 32-bit fraction r: the range reduction without a division (n < 2^32)
+ARCLE_HD uint32_t mulhi32(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * (uint64_t)n) >> 32); }
+// Two splitmix64 outputs per draw: z0 -> problem (high word) and pair (low word) by multiply-shift range reduction; z1 -> the quarter
+// turns (two low bits) and the colour permutation: its high word is a 32-bit fraction that the Fisher-Yates loop consumes digit by digit
+// (j = floor(frac * (i + 1)), frac = the fractional part of frac * (i + 1): one mul-hi and one mul-lo per swap, no division anywhere).
+// An auto-reset onto a device-drawn task runs this on the wave that resets the env: the first version (one splitmix64 and one modulo per
+// swap, ~1000 scalar instructions) made those waves the tail of the research step's launch (profiles/round4_experiments.txt).
 ARCLE_HD TaskDraw draw_task(uint64_t seed, uint64_t gid, uint32_t episode, int n_problems, const int32_t* pair_cnt,
                             uint32_t aug_flags) {
   const uint64_t G = 0x9E3779B97F4A7C15ull;
   TaskDraw d;
-  uint64_t z = mix64(seed + gid * G + (uint64_t)episode * 0xD1B54A32D192ED03ull);
-  d.problem = (int)((uint32_t)(z >> 32) % (uint32_t)n_problems);
-  z = mix64(z + G);
-  d.sub = (int)((uint32_t)(z >> 32) % (uint32_t)pair_cnt[d.problem]);
-  z = mix64(z + G);
-  d.rot_k = (aug_flags & ARCLE_AUG_ROT90) ? (int)(z & 3u) : 0;
+  const uint64_t z0 = mix64(seed + gid * G + (uint64_t)episode * 0xD1B54A32D192ED03ull);
+  d.problem = (int)mulhi32((uint32_t)(z0 >> 32), (uint32_t)n_problems);
+  d.sub = (int)mulhi32((uint32_t)z0, (uint32_t)pair_cnt[d.problem]);
+  const uint64_t z1 = mix64(z0 + G);
+  d.rot_k = (aug_flags & ARCLE_AUG_ROT90) ? (int)(z1 & 3u) : 0;
   d.perm = ARCLE_PERM_IDENTITY;
   if (aug_flags & ARCLE_AUG_PERMUTE) {  // Fisher-Yates over the ten colours
+    uint32_t r = (uint32_t)(z1 >> 32);
+#pragma unroll
     for (int i = 9; i > 0; i--) {
-      z = mix64(z + G);
-      const int j = (int)((uint32_t)(z >> 32) % (uint32_t)(i + 1));
+      const int j = (int)mulhi32(r, (uint32_t)(i + 1));
+      r *= (uint32_t)(i + 1);
       const uint64_t a = (d.perm >> (4 * i)) & 15u, b = (d.perm >> (4 * j)) & 15u;
       d.perm = (d.perm & ~((15ull << (4 * i)) | (15ull << (4 * j)))) | (b << (4 * i)) | (a << (4 * j));
     }
   }
   return d;
 }
-ARCLE_DEV U4 permute_colours(const U4& v, uint64_t perm) {  // byte c < 10 -> perm[c]; other values unchanged
+// eight nibbles -> eight bytes (nibble k of x = byte k of the result)
+ARCLE_HD uint64_t spread_nibbles(uint32_t x) {
+  uint64_t v = x;
+  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  return v;
+}
+// byte c < 10 -> perm[c]; other values unchanged.  The sixteen nibbles become a 16-byte table in four (uniform) dwords, and a dword of
+// cells is looked up with two v_perm_b32 (table bytes 0-7 / 8-15 by the cell's low three bits) and a select on bit 3 — 9 vector
+// instructions per four cells; a cell >= 16 (never in ARC data) keeps its value through the byte-wise path.
+ARCLE_DEV U4 permute_colours(const U4& v, uint64_t perm) {
+  const uint64_t tlo = spread_nibbles((uint32_t)perm), thi = spread_nibbles((uint32_t)(perm >> 32));
   U4 o;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    uint32_t x = 0;
+    const uint32_t x = v[i], sel = x & 0x07070707u;
+    const uint32_t lo = xl::perm_bytes((uint32_t)(tlo >> 32), (uint32_t)tlo, sel), hi = xl::perm_bytes((uint32_t)(thi >> 32), (uint32_t)thi, sel);
+    uint32_t m = (x >> 3) & 0x01010101u;
+    m = (m << 8) - m;  // 0xff where bit 3 of the cell is set
+    uint32_t r = (hi & m) | (lo & ~m);
+    if (x & 0xf0f0f0f0u) {  // (out-of-palette cells: unchanged)
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const uint32_t c = (v[i] >> (8 * b)) & 0xffu;
-      const uint32_t m = c < 10u ? (uint32_t)(perm >> (4 * c)) & 15u : c;
-      x |= m << (8 * b);
+      for (int b = 0; b < 4; b++) {
+        const uint32_t c = (x >> (8 * b)) & 0xffu;
+        if (c >= 16u) r = (r & ~(0xffu << (8 * b))) | (c << (8 * b));
+      }
     }
-    o[i] = x;
+    o[i] = r;
   }
   return o;
 }
 // np.rot90(plane[:h,:w], k) zero-padded; updates (h, w)
+// (16 <= W <= 32: the affine window gather the Rotate / Flip operations use — no per-cell bounds arithmetic)
+ARCLE_DEV U4 plane_transform_fast(const Wave& w, const U4& v, int nh, int nw, int ai, int bj, int c0) {
+  w.stage(w.lds->a, v);
+  const int B0 = ai * w.r0 + bj * w.c0 + c0, B1 = ai * (w.r0 + 1) - bj * w.k1 + c0;
+  return u4_and(gather_affine(w, w.lds->a, B0, B1, bj), w.expand16(w.rect16(0, nh - 1, 0, nw - 1)));
+}
 ARCLE_DEV U4 rot90_plane(const Wave& w, const U4& v, int& h, int& wd, int k) {
   const int W = w.p.W;
+  if (w.fw != FW_GENERIC && k != 0) {
+    int nh = h, nw = wd, ai, bj, c0;
+    if (k == 1) { ai = -1; bj = W; c0 = wd - 1; nh = wd; nw = h; }
+    else if (k == 2) { ai = -W; bj = -1; c0 = (h - 1) * W + wd - 1; }
+    else { ai = 1; bj = -W; c0 = (h - 1) * W; nh = wd; nw = h; }
+    const U4 o = plane_transform_fast(w, v, nh, nw, ai, bj, c0);
+    h = nh;
+    wd = nw;
+    return o;
+  }
   if (k == 1) {
     const U4 o = plane_transform(w, v, wd, h, -1, W, wd - 1);
     const int t = h; h = wd; wd = t;
@@ -1128,8 +1169,11 @@ ARCLE_DEV bool load_task(const Wave& w, Rec& r, int t, int rot_k, uint64_t perm,
     in = *reinterpret_cast<const U4*>(p.tbl_in + (size_t)t * p.PS + 16 * w.lane);
     an = *reinterpret_cast<const U4*>(p.tbl_ans + (size_t)t * p.PS + 16 * w.lane);
   }
-  int ih = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_in_dim[2 * t]), iw = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_in_dim[2 * t + 1]);
-  int ah = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_ans_dim[2 * t]), aw = (int)xl::uniform((uint32_t)(uint8_t)p.tbl_ans_dim[2 * t + 1]);
+  // (the two dims of an entry are an aligned int8 pair inside a dword of the [n_tasks][2] arrays: one scalar load each)
+  const uint32_t dsh = 8u * ((2u * (uint32_t)t) & 2u);
+  const uint32_t din = xl::uload1(at(p.tbl_in_dim, (2u * (uint32_t)t) & ~3u)) >> dsh, dan = xl::uload1(at(p.tbl_ans_dim, (2u * (uint32_t)t) & ~3u)) >> dsh;
+  int ih = (int)(din & 0xffu), iw = (int)((din >> 8) & 0xffu);
+  int ah = (int)(dan & 0xffu), aw = (int)((dan >> 8) & 0xffu);
   if (perm != ARCLE_PERM_IDENTITY) {  // the reference permutes the un-padded grids: the padding stays 0
     in = u4_and(permute_colours(in, perm), w.expand16(w.rect16(0, ih - 1, 0, iw - 1)));
     an = u4_and(permute_colours(an, perm), w.expand16(w.rect16(0, ah - 1, 0, aw - 1)));
@@ -1919,7 +1963,7 @@ ARCLE_DEV void wave_reset_table(const StepParams& p, WaveLDS* lds, const U2* lut
     uint64_t perm = ARCLE_PERM_IDENTITY;
     if (p.aug_k) k = (int)xl::uniform((uint32_t)p.aug_k[env]) & 3;
     if (p.aug_perm) {
-      perm = 0;
+      perm = ARCLE_PERM_IDENTITY & ~0xFFFFFFFFFFull;  // (nibbles 10..15 stay the identity: the lookup table has sixteen entries)
       for (int c = 0; c < 10; c++) perm |= (uint64_t)(xl::uniform((uint32_t)p.aug_perm[16 * (size_t)env + c]) & 15u) << (4 * c);
     }
     ok = load_task(w, r, t, k, perm, in);

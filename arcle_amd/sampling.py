@@ -17,20 +17,26 @@ def mix64(z):
     return z ^ (z >> 31)
 
 
+def _mulhi32(r, n):
+    return ((r & 0xFFFFFFFF) * int(n)) >> 32
+
+
 def draw_task(seed, gid, episode, pair_cnt, aug_flags=0):
-    """-> (problem index into pair_off/pair_cnt, pair index, rot90 count, permutation list of the colours 0..9)."""
+    """-> (problem index into pair_off/pair_cnt, pair index, rot90 count, permutation list of the colours 0..9).
+    Two splitmix64 outputs: z0 gives the problem (high word) and the pair (low word) by multiply-shift range reduction, z1 the quarter
+    turns (two low bits) and — its high word read as a 32-bit fraction, consumed digit by digit — the Fisher-Yates swaps."""
     n = len(pair_cnt)
-    z = mix64((seed + gid * GOLD + episode * 0xD1B54A32D192ED03) & M64)
-    problem = (z >> 32) % n
-    z = mix64((z + GOLD) & M64)
-    sub = (z >> 32) % int(pair_cnt[problem])
-    z = mix64((z + GOLD) & M64)
-    k = int(z & 3) if aug_flags & AUG_ROT90 else 0
+    z0 = mix64((seed + gid * GOLD + episode * 0xD1B54A32D192ED03) & M64)
+    problem = _mulhi32(z0 >> 32, n)
+    sub = _mulhi32(z0, int(pair_cnt[problem]))
+    z1 = mix64((z0 + GOLD) & M64)
+    k = int(z1 & 3) if aug_flags & AUG_ROT90 else 0
     perm = list(range(10))
     if aug_flags & AUG_PERMUTE:
+        r = z1 >> 32
         for i in range(9, 0, -1):
-            z = mix64((z + GOLD) & M64)
-            j = (z >> 32) % (i + 1)
+            j = _mulhi32(r, i + 1)
+            r = (r * (i + 1)) & 0xFFFFFFFF
             perm[i], perm[j] = perm[j], perm[i]
     return int(problem), int(sub), k, perm
 
@@ -49,16 +55,16 @@ def draw_aug_batch(seed, gids, episodes, aug_flags):
         return z ^ (z >> np.uint64(31))
     with np.errstate(over="ignore"):
         G = np.uint64(GOLD)
-        z = mix(np.uint64(seed & M64) + g * G + e * np.uint64(0xD1B54A32D192ED03))  # problem draw
-        z = mix(z + G)                                                              # pair draw
-        z = mix(z + G)                                                              # rot90 draw
-        k = (z & np.uint64(3)).astype(np.uint8) if aug_flags & AUG_ROT90 else np.zeros(len(g), np.uint8)
+        z0 = mix(np.uint64(seed & M64) + g * G + e * np.uint64(0xD1B54A32D192ED03))  # problem / pair draw
+        z1 = mix(z0 + G)                                                             # augmentation draw
+        k = (z1 & np.uint64(3)).astype(np.uint8) if aug_flags & AUG_ROT90 else np.zeros(len(g), np.uint8)
         perm = np.tile(np.arange(10, dtype=np.uint8), (len(g), 1))
         if aug_flags & AUG_PERMUTE:
             rows = np.arange(len(g))
+            r = z1 >> np.uint64(32)
             for i in range(9, 0, -1):
-                z = mix(z + G)
-                j = ((z >> np.uint64(32)) % np.uint64(i + 1)).astype(np.int64)
+                j = ((r * np.uint64(i + 1)) >> np.uint64(32)).astype(np.int64)
+                r = (r * np.uint64(i + 1)) & np.uint64(0xFFFFFFFF)
                 a, b = perm[rows, i].copy(), perm[rows, j].copy()
                 perm[rows, i], perm[rows, j] = b, a
     return k, perm

@@ -259,7 +259,8 @@ def run_chunk(args):
     """Worker of the multi-process baseline: steps `n_envs` envs for `steps` C3-style random actions; returns env-steps done
     and the elapsed seconds of the stepping loop alone."""
     import time
-    seed, n_envs, steps, H, W = args
+    seed, n_envs, steps, H, W = args[:5]
+    budget_s = args[5] if len(args) > 5 else None  # optional wall-clock budget: stop after the step during which it runs out
     rng = np.random.default_rng(seed)
     envs = []
     for _ in range(n_envs):
@@ -271,8 +272,12 @@ def run_chunk(args):
     bb = rng.integers(0, H, (steps, n_envs, 4))
     ops = rng.integers(0, 35, (steps, n_envs))
     t0 = time.perf_counter()
+    done = 0
     for s in range(steps):
         for n, e in enumerate(envs):
             b = bb[s, n]
             e.step(bbox_action(H, W, int(b[0]), int(b[1]), int(b[2]), int(b[3]), int(ops[s, n])))
-    return n_envs * steps, time.perf_counter() - t0
+        done += n_envs
+        if budget_s is not None and time.perf_counter() - t0 > budget_s:
+            break
+    return done, time.perf_counter() - t0

@@ -121,6 +121,12 @@ ARCLE_DEV uint32_t opaque(uint32_t v) { return v; }
 ARCLE_DEV int rare_s(int v) { return v; }
 ARCLE_DEV int rare_v(int v) { return v; }
 ARCLE_DEV uint32_t tov(uint32_t x) { return x; }
+ARCLE_DEV uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) {  // v_perm_b32 for selector bytes 0..7
+  const uint64_t t = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int k = 0; k < 4; k++) r |= (uint32_t)((t >> (8 * ((sel >> (8 * k)) & 7u))) & 0xffu) << (8 * k);
+  return r;
+}
 template <typename T>
 ARCLE_DEV void store_at(void* base, uint32_t off, const T& v) { memcpy((char*)base + off, &v, sizeof(T)); }
 ARCLE_DEV uint32_t bfrev(uint32_t v) {

@@ -223,6 +223,57 @@ def sampler(cls, kind_flags=AUG_PERMUTE | AUG_ROT90):
     return errs
 
 
+def resample_content(cls):
+    """What a device-drawn, augmented task LOOKS like after sampled resets and ARCLE_STEP_RESAMPLE auto-resets inside the step kernel
+    (where the wave runs the width class's fast paths: v_perm colour lookup, affine window gather for np.rot90): input / answer planes
+    and dims of every env == np.rot90(perm[pair], k) of the table entry the host mirror predicts for (seed, global env id, episode) —
+    30 x 30 (FW_FULL), 20 x 24 (FW_FAST, non-square: a quarter turn that does not fit is dropped), 12 x 12 (generic width)."""
+    from arcle_amd.sampling import draw_task
+    errs = []
+    for (H, W), seed in (((30, 30), 11), ((20, 24), 12), ((12, 12), 13)):
+        N, T, S = 24, 12, 14
+        rng = np.random.default_rng(seed)
+        ins = [rng.integers(0, 10, (rng.integers(1, H + 1), rng.integers(1, W + 1))).astype(np.int8) for _ in range(T)]
+        outs = [rng.integers(0, 10, (rng.integers(1, H + 1), rng.integers(1, W + 1))).astype(np.int8) for _ in range(T)]
+        pair_off, pair_cnt = np.array([0, 3, 4, 9], np.int32), np.array([3, 1, 5, 3], np.int32)
+        be = cls(N, H, W, 1, "o2arc", O.o2arc_ops())
+        be.set_task_table(ins, outs)
+        be.set_sampler(pair_off, pair_cnt, 1000 + seed, 7, AUG_PERMUTE | AUG_ROT90)
+        be.set_truncation(3)
+        be.reset_sampled()
+
+        def check(tag):
+            ep, got_in, got_an = be.episode, be.get("input"), be.get("answer")
+            din, dan = be.get("input_dim"), be.get("answer_dim")
+            for n in range(N):
+                p_, s_, k, perm = draw_task(1000 + seed, 7 + n, int(ep[n]) - 1, pair_cnt, AUG_PERMUTE | AUG_ROT90)
+                t = pair_off[p_] + s_
+                a, b = ins[t], outs[t]
+                if k & 1 and (a.shape[1] > H or a.shape[0] > W or b.shape[1] > H or b.shape[0] > W):
+                    k &= 2  # (documented softening of a quarter turn that does not fit a non-square plane)
+                lut = np.asarray(perm, np.int8)
+                wa, wb = np.rot90(lut[a], k), np.rot90(lut[b], k)
+                ea, eb = np.zeros((H, W), np.int8), np.zeros((H, W), np.int8)
+                ea[:wa.shape[0], :wa.shape[1]] = wa
+                eb[:wb.shape[0], :wb.shape[1]] = wb
+                if not (np.array_equal(got_in[n], ea) and np.array_equal(got_an[n], eb) and tuple(din[n]) == wa.shape and tuple(dan[n]) == wb.shape):
+                    errs.append(f"{H}x{W} {tag}: env {n} (episode {int(ep[n])}, entry {t}, k {k}) does not hold the augmented task the mirror predicts")
+        check("after reset_sampled")
+        bb = rng.integers(0, H, (S, N, 4)).astype(np.int32)
+        bb[..., 1], bb[..., 3] = bb[..., 1] % W, bb[..., 3] % W
+        for s in range(S):
+            be.step("bbox", bb[s], rng.integers(0, 35, N).astype(np.int32), STEP_RESAMPLE | STEP_TRUNCATE | STEP_ELIDE)
+            if s % 4 == 3:
+                check(f"step {s}")
+            if len(errs) > 6:
+                return errs
+        if be.episode.min() < 3:
+            errs.append(f"{H}x{W}: the trace did not exercise re-sampling")
+        if be.status():
+            errs.append(f"{H}x{W}: status flag raised")
+    return errs
+
+
 def truncation(cls):
     errs = []
     N, H, W = 8, 10, 10

@@ -7,7 +7,7 @@ import features as F
 import rows as R
 
 
-@pytest.mark.parametrize("check", [F.wrappers, F.augment, F.dense, F.reset_on_submit, F.flat, F.continue_rule, F.sampler,
+@pytest.mark.parametrize("check", [F.wrappers, F.augment, F.dense, F.reset_on_submit, F.flat, F.continue_rule, F.sampler, F.resample_content,
                                    F.truncation, F.packed, F.bad_selection], ids=lambda f: f.__name__)
 def test_emulated_kernel_feature(check):
     errs = check(B.EmuBackend)

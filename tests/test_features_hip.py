@@ -25,7 +25,7 @@ def _gpu():
     _lib.lib()
 
 
-@pytest.mark.parametrize("check", [F.wrappers, F.augment, F.dense, F.reset_on_submit, F.flat, F.continue_rule, F.sampler,
+@pytest.mark.parametrize("check", [F.wrappers, F.augment, F.dense, F.reset_on_submit, F.flat, F.continue_rule, F.sampler, F.resample_content,
                                    F.truncation, F.packed, F.bad_selection], ids=lambda f: f.__name__)
 def test_hip_feature(check):
     errs = check(B.HipBackend)

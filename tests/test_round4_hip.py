@@ -184,7 +184,7 @@ def test_vec_env_next_operation_argument_and_research_flags_ordered():
     import bench
     from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
     from arcle_amd.loaders import SyntheticLoader
-    n, K, dev = 2048, 24, torch.device("cuda:0")
+    n, K, dev = 4096, 24, torch.device("cuda:0")  # (batches of at most 2048 envs run 256-thread workgroups, unordered)
     bb_np, op_np = bench.make_actions(K, n, 99)
     bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
     kw = dict(device=dev, seed=5, autoreset="resample", augment=("permute", "rot90"), dense_reward=True, max_episode_steps=9)
@@ -272,7 +272,7 @@ def test_speculative_grid_instantiations_vs_oracle(policy, form):
 
 @pytest.mark.parametrize("n", [40960, 131072, 196608])
 def test_streaming_regime_at_its_own_sizes_vs_oracle(n):
-    """The batch sizes at which the launcher itself switches policy (B from 28 672, H from 73 728, J from 180 224 envs): 131 072 envs is
+    """The batch sizes at which the launcher itself switches policy (B from 34 816, H from 110 592, J from 155 648 envs): 131 072 envs is
     bench.py's out-of-cache leg.  10 steps of bench's streams, a 600-env sample against the oracle, every field."""
     import torch
     import bench

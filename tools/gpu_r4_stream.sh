@@ -8,7 +8,7 @@ LIB=${LIB:-gpurun_lib_fast.so}
 SIZES=${SIZES:-"32768 131072 524288"}
 POLICIES=${POLICIES:-"0 A B H J"}
 run() {  # N, policy, wpw
-  ARCLE_HIP_LIB=$R/$LIB ARCLE_STREAM_POLICY=$2 ARCLE_WPW=$3 timeout 300 python bench.py --no-cpu-baseline --no-extras --no-ordered --steps 60 --warmup 10 --regions 12 \
+  ARCLE_HIP_LIB=$R/$LIB ARCLE_STREAM_POLICY=$2 ARCLE_WPW=$3 timeout 300 python bench.py --no-cpu-baseline --no-extras --no-ordered --steps ${STEPS:-60} --warmup 10 --regions 12 ${EXTRA:-} \
     --envs-per-gpu $1 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
