@@ -159,6 +159,10 @@ ARCLE_DEV void arrived3(U4& a, U2& b, uint32_t& c) { asm volatile("" : "+s"(a), 
 #ifndef ARCLE_STOP_AT
 #define ARCLE_STOP_AT 0
 #endif
+#ifndef ARCLE_PACK_SPEC
+#define ARCLE_PACK_SPEC 0  // 1: packed-row instantiations also request the grid plane beside the per-env scalar loads — every wave needs it for
+                           // its row, yet it loses (c4 6.57 -> 6.62 us, hinted 6.21 -> 6.50: profiles/round4_experiments.txt); kept as a knob
+#endif
 #ifndef ARCLE_SPEC_SMALL_MAX
 #define ARCLE_SPEC_SMALL_MAX 2048  // (0 = off) batches up to this size take the speculative grid load as well: one latency chain per launch
 #endif
@@ -372,6 +376,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     const uint32_t goff = (uint32_t)env * (uint32_t)ARCLE_MAX_CELLS + 16u * (threadIdx.x & 63u);
     early_grid = (FL & ARCLE_STEPX_EARLY_NT) ? xl::load16_nt(reinterpret_cast<const int8_t*>(order), goff) : xl::load16(reinterpret_cast<const int8_t*>(order), goff);
     early = true;
+  } else if (ARCLE_PACK_SPEC && FL >= 0 && (FL & ARCLE_STEP_PACK_OBS) && WC == 30) {
+    // fused packed rows: EVERY wave needs the grid plane at its end (the row it packs), so the speculative request is never wasted —
+    // and the epilogue no longer waits for a read-back (a traded slot of an ordered launch drops it below: it belongs to another env)
+    early_grid = xl::load16(pa.plane[ARCLE_PL_GRID], (uint32_t)env * (uint32_t)ARCLE_MAX_CELLS + 16u * (threadIdx.x & 63u));
+    early = true;
   } else if (WC == 0 && !ACCT && !FEAT && !ORD && ING != arcle::INGRESS_BBOX5_PF) {
     // small batches of other grid shapes (at most a wave or two per SIMD: the launch is one wave's latency chain, nothing competes for
     // the memory pipes): the same speculative request, decided by the launcher (StepParams::spec_grid)
@@ -392,6 +401,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   if (ORD && slot_env != (uint32_t)env) {  // a traded slot: one more round trip for the other env's inputs
     my_env = (int)slot_env;
     in = arcle::load_inputs<ING>(w, my_env, rec, cnt, op, sel);
+    early = false;
   }
 #ifdef ARCLE_TRACE_WAVES
   arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, t_entry, xl::clock());

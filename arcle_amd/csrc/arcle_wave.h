@@ -1281,6 +1281,8 @@ struct StepOut {
   uint32_t bytes;  // algorithmic HBM bytes of the step (0 for skipped steps)
   uint32_t status; // ARCLE_ST_* bits this env raised in this step (also OR-ed into the handle's sticky status word)
   bool grid_loaded; // the step loaded the grid plane (accounting of the streaming instantiation's speculative load)
+  bool have_grid;   // `grid` holds the env's grid plane as the step left it (loaded, requested early, or just produced): the fused
+  U4 grid;          // packed-row epilogue takes it from here instead of reading the plane back (dead in every other instantiation)
 };
 ARCLE_DEV void raise_status(const StepParams& p, StepOut& out, uint32_t bits) {
   xl::atomic_or(p.status, bits);
@@ -1318,6 +1320,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   out.bytes = 0;
   out.status = 0;
   out.grid_loaded = false;
+  out.have_grid = false;
+  out.grid = u4_zero();
   // FL >= 0: the launch's step flags are this compile-time constant (the launcher picks the instantiation for the common
   // combination), so the flag tests below fold away
   const uint32_t flags = FL >= 0 ? ((uint32_t)FL & 0xffffu) : p.flags;
@@ -1715,6 +1719,8 @@ ARCLE_DEV StepOut step_core(const Wave& w, Rec& r, I2& cnt0, const U4& payload, 
   out.term = r.term() != 0;
   out.bytes = s.bytes;
   out.grid_loaded = s.loaded;
+  out.have_grid = s.have_grid;
+  out.grid = s.grid;
   return out;
 }
 
@@ -1722,7 +1728,8 @@ ARCLE_DEV void flat_row(const Wave& w, const Rec& r, bool only_stored = false); 
 struct StepOut;
 ARCLE_DEV void flat_tail(const Wave& w, const StepOut& out, const I2& cnt, bool truncated);
 ARCLE_HD int flat_obs_len(const StepParams& p, int filtered);
-ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride);
+ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride, bool have_grid = false,
+                        U4 grid = U4{0u, 0u, 0u, 0u});
 ARCLE_HD int packed_stride(int P);
 
 // The per-env inputs of one step: record, op index, counters and the selection payload — four independent loads
@@ -1854,7 +1861,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
   // the lean ones whose compile-time flags ask for it
   if ((FEAT || FL >= 0) && (flags & ARCLE_STEP_PACK_OBS)) {
     xl::own_stores_visible();
-    pack_row(w, r, (uint32_t)out.reward, (uint32_t)out.term, p.pack_out, packed_stride(p.P));
+    pack_row(w, r, (uint32_t)out.reward, (uint32_t)out.term, p.pack_out, packed_stride(p.P), out.have_grid, out.grid);
     if (ACCT) {
       out.bytes += (uint32_t)(p.P + packed_stride(p.P));
       w.issued += (uint32_t)packed_stride(p.P);
@@ -2218,6 +2225,7 @@ ARCLE_DEV void wave_transition_row(const StepParams& p, WaveLDS* lds, const U2* 
   out.bytes = 0;
   out.status = 0;
   out.grid_loaded = false;
+  out.have_grid = false;
   I2 cnt;
   cnt.x = cnt.y = 0;
   const int8_t* rin = p.rows_in + (size_t)row * p.rows_in_stride;
@@ -2261,10 +2269,11 @@ ARCLE_DEV void wave_flatten(const StepParams& p, WaveLDS* lds, const U2* lut, in
 // ------------------------------------------------------------------------------------------------
 ARCLE_HD int packed_stride(int P) { return (P + 7 + 15) & ~15; }
 // `reward` / `term`: the step outputs of this env (the fused epilogue passes what it just computed)
-ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride) {
+// `have_grid` / `grid`: the plane as the step left it in registers (the fused epilogue: no read-back, no extra round trip at the end of the wave)
+ARCLE_DEV void pack_row(const Wave& w, const Rec& r, uint32_t reward, uint32_t term, int8_t* out, int stride, bool have_grid, U4 grid) {
   const int P = w.p.P, lane = w.lane;
   if (16 * lane >= stride) return;
-  U4 v = w.load(ARCLE_PL_GRID);  // (bytes >= P of the plane row are zero padding)
+  U4 v = have_grid ? grid : w.load(ARCLE_PL_GRID);  // (bytes >= P of the plane row are zero padding)
   if (16 * lane + 16 > P) {          // this lane's window holds the metadata bytes
     // the 7 metadata bytes as one little-endian word: grid_dim (2), reward int32 (4), terminated (1)
     const uint64_t meta = (uint64_t)(uint32_t)r.gh() | ((uint64_t)(uint32_t)r.gw() << 8) | ((uint64_t)reward << 16) | ((uint64_t)(term & 0xffu) << 48);

@@ -244,7 +244,7 @@ def _host_capacity():
     return avail, quota
 
 
-def _numpy_baseline(avail, before_fork=None):
+def _numpy_baseline(avail, before_fork=None, quota=None):
     """The plain-NumPy per-env step() loop (oracle/numpy_env.py): one process, then one process per host core — every worker runs
     against the same 5 s wall-clock budget, so the leg is bounded whatever the box really grants the container."""
     import multiprocessing as mp
@@ -253,7 +253,9 @@ def _numpy_baseline(avail, before_fork=None):
     steps1 = max(50, int(150 * 6.0 / max(sec, 1e-3)))  # aim at ~6 s of single-process stepping
     done, sec = NE.run_chunk((12, 64, min(steps1, 4000), 30, 30))
     one = done / sec
-    procs = max(1, avail)  # every host core
+    # one process per core the container may really use: every schedulable CPU, capped by the cgroup quota (256 CPUs visible / 16 granted
+    # on the driver's boxes: 256 workers time-slicing 16 cores measure the scheduler)
+    procs = max(1, min(avail, int(math.ceil(quota))) if quota else avail)
     per = max(20, int(one * 5.0 / 64))  # ~5 s per worker if it had a core to itself
     if before_fork is not None:
         before_fork()
@@ -313,7 +315,7 @@ def cpu_baseline(seed, sustain=None):
         if sustain is not None:
             sustain.halt.set()
             sustain.join(30.0)
-    numpy_step = _numpy_baseline(avail, stop_sustain)
+    numpy_step = _numpy_baseline(avail, stop_sustain, quota)
     # all host cores: OpenMP over envs with every schedulable CPU — and, because a container may see far more CPUs than it is granted
     # (256 visible here; with 256 threads the same code ran SLOWER than with one), a short scan of smaller teams; `all_cores` is the
     # best of them with the thread count it really used, the scan is kept beside it
