@@ -989,7 +989,11 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   const int policy = stream_policy(e, p.n_envs);
   if (std30) p.spec_grid = (policy && flags == (uint32_t)HOT_FLAGS && (ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5)) ? policy : 0;
   else p.spec_grid = (policy == 'A' && !(flags & ARCLE_STEP_FEATURE_FLAGS) && ingress != arcle::INGRESS_MASK) ? policy : 0;
-  const int wpw = launch_wpw(e);
+  int wpw = launch_wpw(e);
+  // ... and for a batch of at most one occupancy round whose launch has no front workgroups to carry (no dispatch order to read or
+  // write, no records to prefetch): 5.40 -> 5.35 us at 8192 envs, 4.28 -> 4.25 at 4096; from 16384 envs on 8 waves are the better shape
+  // (profiles/round4_experiments.txt §9)
+  if (!e->wpw_override && wpw == WAVES_PER_WG && p.n_envs <= 8192 && !e->ord_cur && !e->pf_next && !(!e->in_many && (e->hint_op || e->ord_have))) wpw = 4;
   p.wpw = wpw;
   if (flags & ARCLE_STEP_FLAT_OBS) {
     if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
