@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   const int wv = wave_of_launch(wpw, nb8, pf_off);
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = (int)__builtin_elementwise_min((uint32_t)wv, (uint32_t)n_envs - 1u);  // (surplus waves load env N-1's inputs and leave)
-  arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], lds.lut, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0);
+  arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], nullptr, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0, false);  // (no expansion table: Wave::expand16)
   constexpr bool STREAM = FL >= 0 && (FL & ARCLE_STEPX_STREAM) != 0;
   w.store_nt = FL >= 0 && (FL & ARCLE_STEPX_STORE_NT) != 0;
   // ordered dispatch: the slot's table entry is requested beside the inputs of the env in the same position — most slots keep it
@@ -389,10 +389,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
       early = true;
     }
   }
-  // (the always-true scalar test keeps a block boundary between the loads and the barrier: with straight-line code here the
-  // optimiser sinks the four loads below the barrier — into the only block that uses them — and their latency is exposed)
-  if (wpw > 0) arcle::lut_init(lds.lut, (int)threadIdx.x);
-  xl::wg_barrier();
+  // (round 4: no expansion table, hence no workgroup barrier — every wave goes on as soon as its own inputs arrive: ordered launches
+  // 5.04 -> 4.95 us, research step 10.0 -> 9.85; the always-true scalar test keeps a block boundary behind the loads, as the barrier did)
+  if (wpw > 0) asm volatile("" ::: "memory");
   if (!valid) return;
 #if ARCLE_STOP_AT == 1
   return;

@@ -308,9 +308,14 @@ struct Wave {
   mutable uint32_t issued;
   mutable uint32_t stored;  // planes written (through `store`) since the wave picked up its env: what changed in this step
   bool store_nt;            // ARCLE_STEPX_STORE_NT instantiations: plane stores are non-temporal instead of write-through
+  bool table;               // expand16 reads the workgroup's LDS table (false: computes the byte masks on the vector ALUs)
 
-  ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, const U2* lut_, int lane_, int ingress_, int fw_, bool resident_, bool count_ = false)
+  // (table_: a compile-time constant at every call site — a null test of `lut_` is not: LDS offset 0 is a valid address, and a kernel
+  // that cannot fold the test carries both expansions)
+  ARCLE_DEV Wave(const StepParams& p_, WaveLDS* l, const U2* lut_, int lane_, int ingress_, int fw_, bool resident_, bool count_ = false,
+                 bool table_ = true)
       : p(p_), lds(l), lut(lut_), lane(lane_) {
+    table = table_;
     count = count_;
     issued = 0;
     stored = 0;
@@ -373,7 +378,19 @@ struct Wave {
   }
 
   // ---- 16-bit cell mask -> 16 byte masks (0x00 / 0xff), through the workgroup's LDS table ----------
+  // (table == false — the step kernel since round 4: the expansion on the vector ALUs, 5 instructions per four cells, no table to build and
+  // no workgroup barrier in front of the op; the rollout kernel, whose steps are pure instruction issue, keeps the table: 2.62 vs 3.77 us
+  // per step without it — profiles/round4_experiments.txt §11)
   ARCLE_DEV U4 expand16(uint32_t m) const {
+    if (!table) {
+      U4 e;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t x = xl::mul24((m >> (4 * i)) & 0xfu, 0x00204081u) & 0x01010101u;
+        e[i] = (x << 8) - x;
+      }
+      return e;
+    }
     const U2 lo = lut[m & 0xffu], hi = lut[(m >> 8) & 0xffu];
     U4 r;
     r[0] = lo[0];

@@ -154,7 +154,7 @@ const size_t STACK = 256 * 1024;
 
 #define RUN_STEP(I, F)                                                                      \
   do {                                                                                      \
-    arcle::Wave w(*g_p, &g_lds.wave[0], g_lds.lut, lane, I, F, false, true);                \
+    arcle::Wave w(*g_p, &g_lds.wave[0], nullptr, lane, I, F, false, true, false); /* as the step kernel: no expansion table */ \
     arcle::StepInputs in = arcle::load_inputs<I>(w, g_env);                                 \
     if (g_p->flags & ARCLE_STEP_FEATURE_FLAGS) arcle::wave_step<I, F, 1, 1>(w, g_env, in);           \
     else arcle::wave_step<I, F, 1, 0>(w, g_env, in);                                        \
