@@ -353,14 +353,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     }
     return;
   }
-  __shared__ BlockLDS lds;
+  // one private 2 KiB tile pair per wave, sized by the launch (dynamic LDS: the step kernel has no workgroup-wide LDS state since the
+  // expansion table went, so any workgroup size keeps the occupancy)
+  extern __shared__ __attribute__((aligned(16))) unsigned char step_lds[];
+  WaveLDS* const tiles = reinterpret_cast<WaveLDS*>(step_lds);
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_entry = xl::clock();
 #endif
   const int wv = wave_of_launch(wpw, nb8, pf_off);
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = (int)__builtin_elementwise_min((uint32_t)wv, (uint32_t)n_envs - 1u);  // (surplus waves load env N-1's inputs and leave)
-  arcle::Wave w(p, &lds.wave[threadIdx.x >> 6], nullptr, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0, false);  // (no expansion table: Wave::expand16)
+  arcle::Wave w(p, &tiles[threadIdx.x >> 6], nullptr, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0, false);  // (no expansion table: Wave::expand16)
   constexpr bool STREAM = FL >= 0 && (FL & ARCLE_STEPX_STREAM) != 0;
   w.store_nt = FL >= 0 && (FL & ARCLE_STEPX_STORE_NT) != 0;
   // ordered dispatch: the slot's table entry is requested beside the inputs of the env in the same position — most slots keep it
@@ -533,7 +536,7 @@ struct arcle_env {
   int stream_min;             // batches of at least this many envs take the streaming instantiations (ARCLE_STREAM_MIN_ENVS / env override)
   int spec_small_max;         // batches of at most this many envs request the grid plane speculatively (ARCLE_SPEC_SMALL_MAX env override)
   int stream_policy_override; // tuning runs: ARCLE_STREAM_POLICY = 0 | A | B | H | J for every batch size
-  int wpw_override;           // tuning runs: waves per workgroup of the step launches (ARCLE_WPW = 4 or 8), 0 = the library's choice
+  int wpw_override;           // tuning runs: waves per workgroup of the step launches (ARCLE_WPW = 1, 2, 4 or 8), 0 = the library's choice
   int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
   uint32_t* d_acct;
   uint64_t acct_steps;
@@ -581,7 +584,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   if (const char* ss = getenv("ARCLE_SPEC_SMALL_MAX")) e->spec_small_max = atoi(ss);
   if (const char* wp = getenv("ARCLE_WPW")) {
     const int v = atoi(wp);
-    if (v == 4 || v == 8) e->wpw_override = v;  // (the expansion table is filled by 256 threads: no smaller workgroups)
+    if (v == 1 || v == 2 || v == 4 || v == 8) e->wpw_override = v;
   }
   e->cfg = *cfg;
   int caller_dev = 0;
@@ -807,7 +810,8 @@ static int width_class(const StepParams& p) {
   return p.PS == ARCLE_MAX_CELLS ? arcle::FW_FULL : arcle::FW_FAST;
 }
 #define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw, g.x >> 3, p
-#define LAUNCH_STEP(...) hipLaunchKernelGGL((arcle_step_kernel<__VA_ARGS__>), g, b, 0, st, STEP_ARGS)
+#define STEP_LDS(b) ((size_t)((b).x / 64u) * sizeof(arcle::WaveLDS))
+#define LAUNCH_STEP(...) hipLaunchKernelGGL((arcle_step_kernel<__VA_ARGS__>), g, b, STEP_LDS(b), st, STEP_ARGS)
 // the flag combination ARCVecEnv steps with (next-step autoreset, elided zero-fill of `selected`) has its own instantiation
 // with the flags as a compile-time constant
 static constexpr int HOT_FLAGS = ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED;
@@ -832,11 +836,11 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
     else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 1);
   } else if (p.flags == (uint32_t)HOT_FLAGS && p.order && p.wpw == WAVES_PER_WG) {
     const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));
-    hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, 0, st,
+    hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, STEP_LDS(b), st,
                        (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);
   } else if (p.flags == (uint32_t)HOT_FLAGS && p.spec_grid) {
 #define LAUNCH_STREAM(BITS)                                                                                                                    \
-  hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_STREAM | (BITS), 30>), g, b, 0, st, (const int8_t*)p.rec, \
+  hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_STREAM | (BITS), 30>), g, b, STEP_LDS(b), st, (const int8_t*)p.rec, \
                      (const int32_t*)p.cnt, p.op, p.sel, (const uint32_t*)p.plane[ARCLE_PL_GRID], p.n_envs, p.wpw, g.x >> 3, p)
     switch (p.spec_grid) {
       case 'B': LAUNCH_STREAM(ARCLE_STEPX_STORE_NT); break;
@@ -864,7 +868,7 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
       if constexpr (ING == arcle::INGRESS_BBOX5) {
         if (p.flags == (uint32_t)HOT_FLAGS && p.next_sel && p.wpw == WAVES_PER_WG) {  // records prefetched by the launch's front workgroups
           const dim3 gp(g.x + ARCLE_PF_BLOCKS);
-          hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX5_PF, FW, 0, 0, HOT_FLAGS, 30>), gp, b, 0, st, (const int8_t*)p.rec,
+          hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX5_PF, FW, 0, 0, HOT_FLAGS, 30>), gp, b, STEP_LDS(b), st, (const int8_t*)p.rec,
                              (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw, g.x >> 3, p);
           return;
         }
@@ -874,7 +878,7 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
 #define LAUNCH_ORDERED(FLSET, FEATV)                                                                                                  \
   do {                                                                                                                                \
     const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));                                                                     \
-    hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, FEATV, (FLSET) | ARCLE_STEPX_ORDERED, 30>), go, b, 0, st, (const int8_t*)p.rec, \
+    hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, FEATV, (FLSET) | ARCLE_STEPX_ORDERED, 30>), go, b, STEP_LDS(b), st, (const int8_t*)p.rec, \
                        (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);         \
     return;                                                                                                                           \
   } while (0)
@@ -892,7 +896,7 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
       if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
         if (p.flags == (uint32_t)HOT_FLAGS && p.spec_grid) {  // speculative grid request: the plane's base rides in the preloaded `order` argument
 #define LAUNCH_STREAM(BITS)                                                                                                                    \
-  hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS | ARCLE_STEPX_STREAM | (BITS), 30>), g, b, 0, st, (const int8_t*)p.rec, (const int32_t*)p.cnt, \
+  hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, 0, HOT_FLAGS | ARCLE_STEPX_STREAM | (BITS), 30>), g, b, STEP_LDS(b), st, (const int8_t*)p.rec, (const int32_t*)p.cnt, \
                      p.op, p.sel, (const uint32_t*)p.plane[ARCLE_PL_GRID], p.n_envs, p.wpw, g.x >> 3, p)
           switch (p.spec_grid) {
             case 'B': LAUNCH_STREAM(ARCLE_STEPX_STORE_NT); break;

@@ -394,8 +394,8 @@ def test_soak_slice():
     env = dict(os.environ, SOAK_STEPS="300")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py")], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if " S=300" in ln]
-    assert len(lines) >= 11, p.stdout
+    lines = [ln for ln in p.stdout.splitlines() if " S=300" in ln or " S=50" in ln]
+    assert len(lines) >= 11 and sum(" policy " in ln for ln in p.stdout.splitlines()) == 5, p.stdout
     bad = [ln for ln in lines if ": OK" not in ln]
     assert not bad, "\n".join(bad)
 

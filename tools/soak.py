@@ -19,6 +19,18 @@ for name, H, W, N, flags, mt in (("30x30 flags=0", 30, 30, 1024, 0, 3), ("30x30 
     errs = B.random_trace_compare(BE, "o2arc", ops, H, W, N=N // SCALE, S=S, seed=H * 131 + W + flags, max_trial=mt, flags=flags,
                                   bad_ops=True)
     print(f"{name:40s} N={N} S={S}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
+# round 4: batches of at most 2048 envs take the small-batch paths (speculative grid request, 256-thread workgroups) — the blocks above.
+# The plain lean kernel that the headline times (4096 envs: beyond that threshold) and every speculative policy forced onto the same size:
+O.set_threads(8)
+for pol in (None, "A", "B", "H", "J"):
+    if pol is None:
+        os.environ.pop("ARCLE_STREAM_POLICY", None)
+    else:
+        os.environ["ARCLE_STREAM_POLICY"] = pol
+    errs = B.random_trace_compare(BE, "o2arc", ops, 30, 30, N=4096 // SCALE, S=max(S // 6, 8), seed=4242, max_trial=3, flags=3, bad_ops=True)
+    print(f"{'30x30 autoreset|elide, policy ' + str(pol):40s} N=4096 S={max(S // 6, 8)}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
+os.environ.pop("ARCLE_STREAM_POLICY", None)
+O.set_threads(1)
 arc = O.arc_ops()
 errs = B.random_trace_compare(BE, "arc", arc, 30, 30, N=1024 // SCALE, S=S, seed=77, max_trial=3, flags=1, op_weights=[1] * 10 + [7] * 10 + [1] * 7)
 print(f"{'ARCEnv 30x30 FloodFill-heavy':40s} N=1024 S={S}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
