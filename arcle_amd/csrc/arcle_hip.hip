@@ -915,9 +915,11 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
     }
   }
   // the feature instantiation also carries the byte accounting (it adds up scalars; stored only when the handle has a counter buffer)
-  if (feat || acct) LAUNCH_STEP(ING, FW, 1, 1);
-  else if (FW != arcle::FW_GENERIC && p.flags == (uint32_t)HOT_FLAGS) LAUNCH_STEP(ING, FW, 0, 0, HOT_FLAGS);
-  else LAUNCH_STEP(ING, FW, 0, 0);
+  if (feat || acct) { LAUNCH_STEP(ING, FW, 1, 1); return; }
+  if constexpr (FW != arcle::FW_GENERIC) {  // (generic widths have no compile-time-flag twin: one instantiation less per ingress form)
+    if (p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_FLAGS); return; }
+  }
+  LAUNCH_STEP(ING, FW, 0, 0);
 }
 template <int ING>
 static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
