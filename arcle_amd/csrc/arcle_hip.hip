@@ -70,6 +70,14 @@ ARCLE_DEV U4 uload4(const void* p) { return *reinterpret_cast<const ARCLE_AS_CON
 ARCLE_DEV U4 load16(const int8_t* base, uint32_t off) {
   return *reinterpret_cast<const ARCLE_AS_GLOBAL U4*>((uintptr_t)base + off);
 }
+// DPP quad_perm: every lane of a quad takes the value of the quad's lane K / lanes 0-1 take lane 1's, lanes 2-3 lane 3's
+template <int K>
+ARCLE_DEV uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, true); }
+ARCLE_DEV uint32_t quad_bcast_odd(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xf5, 0xf, 0xf, true); }
+ARCLE_DEV U2 load8(const void* base, uint32_t off) { return *reinterpret_cast<const ARCLE_AS_GLOBAL U2*>((uintptr_t)base + off); }
+ARCLE_DEV uint32_t load32(const void* base, uint32_t off) {  // one dword per lane: SGPR base + 32-bit VGPR byte offset
+  return *reinterpret_cast<const ARCLE_AS_GLOBAL uint32_t*>((uintptr_t)base + off);
+}
 // 16 B plane store, write-through (`sc1`): the planes written by a step are only read again by the NEXT launch,
 // and per-XCD L2s are written back at every kernel boundary anyway; writing through lets that traffic overlap
 // the kernel instead of being flushed at its end (profiles/round1_store_policy_ab.txt: plain 11.46 us, nt 11.08,
@@ -145,9 +153,19 @@ ARCLE_DEV U4 load16u(const int8_t* p) {
   typedef U4 __attribute__((aligned(1))) U4a1;
   return *reinterpret_cast<const ARCLE_AS_GLOBAL U4a1*>((uintptr_t)p);
 }
+ARCLE_DEV U4 load16u_at(const void* base, uint32_t off) {  // (SGPR base + 32-bit VGPR byte offset)
+  typedef U4 __attribute__((aligned(1))) U4a1;
+  return *reinterpret_cast<const ARCLE_AS_GLOBAL U4a1*>((uintptr_t)base + off);
+}
 ARCLE_DEV uint32_t bfrev(uint32_t v) { return __builtin_bitreverse32(v); }  // v_bfrev_b32
 ARCLE_DEV uint32_t readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }  // full-rate 24-bit multiply
+// signed 24-bit multiply of a scalar by a vector value, as the ONE instruction it is (the compiler masks operands it cannot bound)
+ARCLE_DEV int mul24s(uint32_t s, int v) {
+  int r;
+  asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(v));
+  return r;
+}
 ARCLE_DEV uint32_t opaque(uint32_t v) {  // hides a value's origin from the optimiser (no instruction)
   asm volatile("" : "+v"(v));
   return v;
@@ -230,6 +248,9 @@ __device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, u
 // The table maps slot -> env and is a permutation of the XCD's own env range (L2 affinity is kept).  It is scheduling only: whatever
 // the table holds, every env is stepped exactly once, and a caller that rewrites the next actions after this ran loses nothing
 // but the ordering.
+#ifndef ARCLE_GROUP_SIZE
+#define ARCLE_GROUP_SIZE 32  // envs (= dispatch strata) per group of a self-ordering launch
+#endif
 #define ARCLE_ORD_BLOCKS 8u    // one per XCD: workgroup b < 8 runs on XCD b
 #define ARCLE_ORD_MAX_SLOTS 1024u  // slots per XCD this pass handles (2 per thread of a 512-thread workgroup): N <= 8192
 __device__ __forceinline__ void order_next_step(const StepParams& p, uint32_t xcd, uint32_t rs) {
@@ -360,6 +381,97 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #ifdef ARCLE_TRACE_WAVES
   const uint64_t t_entry = xl::clock();
 #endif
+  if constexpr (FL >= 0 && (FL & ARCLE_STEPX_GROUPED) != 0) {
+    // ---- the launch that orders itself (round 5) ------------------------------------------------------------------------------------
+    // An XCD starts the workgroups of its slot range in index order, so the range falls into GS = 32 strata of G = rs / 32 consecutive slots
+    // that start one after the other.  Group g of the XCD = the 32 slots {g + j G, j = 0..31} (one per stratum) and the 32 CONTIGUOUS envs
+    // xbase + 32 g .. + 31.  Every wave of the group loads the inputs of ALL 32 envs — records, counters, tuples, op indices: one request of
+    // the whole wave per array, 1.4 KB — ballots which ops are object operations (m, L = popc(m)) and applies order_next_step's rule inside
+    // the group: by default position j steps env j; the k-th object op found in a position >= L trades places with the k-th other op found
+    // in a position < L.  All 32 waves compute the same permutation from the same 32 ops, so every env is stepped exactly once whatever the
+    // ops are, and the slot's env is then picked out of the lanes with v_readlane: no table, no hint, no second round trip, no barrier.
+    // Measured (profiles/round5_experiments.txt): 8192 envs 5.37 -> 4.90 us per launch (the table form with hints: 4.93; ops dealt in the
+    // ideal order: 4.72); groups of 16: 5.00, of 64: 4.92; a group of 16 whose traded slots re-request their inputs (scalar loads): 5.25.
+    // Preloaded arguments of these launches: `order` carries the op table's 64-bit object-op mask, `n_envs` the reciprocal of G
+    // (floor(2^32 / G) + 1; every slot holds an env: n_envs % 256 == 0, checked by the launcher), `nb8` the slots per XCD and `wpw_front`
+    // the log2 of the waves per workgroup.
+    const uint64_t long_mask = (uint64_t)reinterpret_cast<uintptr_t>(order);
+    const uint32_t magic = (uint32_t)n_envs, rs = nb8;
+    constexpr uint32_t GS = ARCLE_GROUP_SIZE;
+    static_assert(GS == 32, "the lane layout below is written for groups of 32");
+    // (wave-uniform arithmetic on the vector ALUs — xl::tov — the CU's scalar unit is the short resource)
+    const uint32_t vb = xl::tov(blockIdx.x);
+    const uint32_t s_local = ((vb >> 3) << (uint32_t)wpw_front) + (threadIdx.x >> 6);
+    const uint32_t j = __umulhi(s_local, magic);  // stratum of this slot = its position in the group
+    // first env of the group: xcd rs + GS (s_local - j G), G = rs / GS
+    const uint32_t gfirst = (uint32_t)xl::mul24s(rs, (int)(vb & 7u) - (int)j) + (s_local << 5);
+    const uint32_t js = xl::uniform(j), gfirst_s = xl::uniform(gfirst);
+    arcle::Wave w(p, &tiles[threadIdx.x >> 6], nullptr, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0, false);
+    static_assert(arcle::is_tuple(ING) && ING != arcle::INGRESS_BBOX5_PF, "grouped launches: bbox / point tuples and 5-tuple records");
+    constexpr bool REC5 = ING == arcle::INGRESS_BBOX5;
+    constexpr bool BY_LIMIT = (FL & ARCLE_STEP_TRUNCATE) != 0;  // (the research step: an env about to be re-initialised counts as long, see order_next_step)
+    // the group's inputs: lanes 0-31 read the 32 op indices (the upper half repeats them); records (16 B per env), bbox tuples (16 B), point
+    // tuples and counters (8 B) as ONE contiguous block per array spread over the 64 lanes — env e's item in lanes 2 e, 2 e + 1
+    const uint32_t lane = threadIdx.x & 63u, e = lane & 31u;
+    const uint32_t vop = REC5 ? xl::load32(sel, 20u * (gfirst + e) + 16u) : xl::load32(op, (gfirst + e) << 2);
+    const xl::U2 vrec = xl::load8(rec, (gfirst << 4) + (lane << 3));
+    xl::U4 vsel = {0u, 0u, 0u, 0u};
+    if constexpr (REC5) vsel = xl::load16u_at(sel, 20u * (gfirst + e));  // (records are only dword aligned; per lane e)
+    else if constexpr (ING == arcle::INGRESS_BBOX) {
+      const xl::U2 t = xl::load8(sel, (gfirst << 4) + (lane << 3));
+      vsel[0] = t[0], vsel[1] = t[1];
+    } else vsel[0] = xl::load32(sel, (gfirst << 3) + (lane << 2));
+    xl::U2 vcnt = {0u, 0u};
+    if constexpr (BY_LIMIT) vcnt = xl::load8(cnt, (gfirst + e) << 3);  // (per lane e: the classification reads env e's step counter)
+    else vcnt[0] = xl::load32(cnt, (gfirst << 3) + (lane << 2));
+    // (the fetch of the argument block — plane bases, op table — is issued HERE, beside the loads above, not behind the wait for the group's ops)
+    asm volatile("" ::"s"(pa.plane[ARCLE_PL_GRID]), "s"(pa.d_ops));
+    bool lg = ((long_mask >> __builtin_elementwise_min(vop, 63u)) & 1ull) != 0ull;
+    if constexpr (BY_LIMIT) lg = lg || (pa.step_limit > 0 && (int32_t)vcnt[0] == pa.step_limit - 1);
+    const uint64_t m = xl::ballot(lg) & 0xffffffffull;
+    const uint64_t hi = xl::ballot(lane >= (uint32_t)__builtin_popcountll(m));  // positions >= L, as a lane compare
+    const uint64_t late_long = m & hi, early_other = ~(m | hi);                 // the two sides of the trade, k-th with k-th
+    const uint32_t ra = __builtin_amdgcn_mbcnt_lo((uint32_t)late_long, 0u), rb = __builtin_amdgcn_mbcnt_lo((uint32_t)early_other, 0u);
+    // code: what a position is (0x40 | rank: a late object op, 0x80 | rank: an early other op, 0x100 | lane: it keeps its env); want: the code of
+    // the position whose env it steps (the k-th of the other side, or itself) — found with ONE ballot, no branch
+    uint32_t code = 0x100u | lane;
+    code = __builtin_amdgcn_inverse_ballot_w64(late_long) ? (0x40u | ra) : code;
+    code = __builtin_amdgcn_inverse_ballot_w64(early_other) ? (0x80u | rb) : code;
+    const uint32_t want = (code & 0x100u) ? code : (code ^ 0xc0u);
+    const int pos = __builtin_ctzll(xl::ballot(code == xl::readlane(want, (int)js)));
+    const int my_env = (int)gfirst_s + pos;
+    // the env's scalars out of the lanes that hold them; an item that spans two lanes has its upper words moved to the even lane first (DPP),
+    // so that ONE lane index serves every v_readlane of the array (no scalar index arithmetic)
+    arcle::StepInputs in;
+    const int h = pos << 1;
+    in.rec[0] = xl::readlane(vrec[0], h);
+    in.rec[1] = xl::readlane(vrec[1], h);
+    in.rec[2] = xl::readlane(xl::quad_bcast_odd(vrec[0]), h);
+    in.rec[3] = xl::readlane(xl::quad_bcast_odd(vrec[1]), h);
+    if constexpr (REC5) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) in.payload[k] = xl::readlane(vsel[k], pos);
+    } else if constexpr (ING == arcle::INGRESS_BBOX) {
+      in.payload[0] = xl::readlane(vsel[0], h);
+      in.payload[1] = xl::readlane(vsel[1], h);
+      in.payload[2] = xl::readlane(xl::quad_bcast_odd(vsel[0]), h);
+      in.payload[3] = xl::readlane(xl::quad_bcast_odd(vsel[1]), h);
+    } else {
+      in.payload = arcle::u4_zero();
+      in.payload[0] = xl::readlane(vsel[0], h);
+      in.payload[1] = xl::readlane(xl::quad_bcast_odd(vsel[0]), h);
+    }
+    if constexpr (BY_LIMIT) {
+      in.cnt[0] = xl::readlane(vcnt[0], pos);
+      in.cnt[1] = xl::readlane(vcnt[1], pos);
+    } else {
+      in.cnt[0] = xl::readlane(vcnt[0], h);
+      in.cnt[1] = xl::readlane(xl::quad_bcast_odd(vcnt[0]), h);
+    }
+    in.op = xl::readlane(vop, pos);
+    arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, 0, 0, false, arcle::u4_zero());
+    return;
+  }
   const int wv = wave_of_launch(wpw, nb8, pf_off);
   const bool valid = wv < n_envs;  // (every wave of the workgroup reaches the barrier below)
   const int env = (int)__builtin_elementwise_min((uint32_t)wv, (uint32_t)n_envs - 1u);  // (surplus waves load env N-1's inputs and leave)
@@ -536,6 +648,10 @@ struct arcle_env {
   int stream_min;             // batches of at least this many envs take the streaming instantiations (ARCLE_STREAM_MIN_ENVS / env override)
   int spec_small_max;         // batches of at most this many envs request the grid plane speculatively (ARCLE_SPEC_SMALL_MAX env override)
   int stream_policy_override; // tuning runs: ARCLE_STREAM_POLICY = 0 | A | B | H | J for every batch size
+  int group_enabled;          // launches of plain single-step calls order themselves (ARCLE_GROUPED = 0 | 1 overrides; default 1)
+  int group_min, group_max;   // ... for batches of group_min .. group_max envs (ARCLE_GROUP_MIN / ARCLE_GROUP_MAX)
+  int group_wpw;              // ... in workgroups of this many waves (ARCLE_GROUP_WPW)
+  int group_over_order;       // ... also where the caller hinted the next ops / arcle_step_many could sort them (ARCLE_GROUP_OVER_ORDER, default 1)
   int wpw_override;           // tuning runs: waves per workgroup of the step launches (ARCLE_WPW = 1, 2, 4 or 8), 0 = the library's choice
   int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
   uint32_t* d_acct;
@@ -579,6 +695,19 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   if (const char* sm = getenv("ARCLE_STREAM_MIN_ENVS")) e->stream_min = atoi(sm);  // (tuning runs)
   if (const char* sp = getenv("ARCLE_STREAM_POLICY")) {
     if (sp[0] == '0' || sp[0] == 'A' || sp[0] == 'B' || sp[0] == 'H' || sp[0] == 'J') e->stream_policy_override = sp[0];
+  }
+  e->group_enabled = 1;
+  e->group_min = 2049;
+  e->group_max = 32768;
+  e->group_wpw = 4;
+  e->group_over_order = 0;
+  if (const char* gs = getenv("ARCLE_GROUP_OVER_ORDER")) e->group_over_order = atoi(gs) != 0;
+  if (const char* gs = getenv("ARCLE_GROUPED")) e->group_enabled = atoi(gs) != 0;
+  if (const char* gs = getenv("ARCLE_GROUP_MIN")) e->group_min = atoi(gs);
+  if (const char* gs = getenv("ARCLE_GROUP_MAX")) e->group_max = atoi(gs);
+  if (const char* gs = getenv("ARCLE_GROUP_WPW")) {
+    const int v = atoi(gs);
+    if (v == 1 || v == 2 || v == 4 || v == 8) e->group_wpw = v;
   }
   e->spec_small_max = ARCLE_SPEC_SMALL_MAX;
   if (const char* ss = getenv("ARCLE_SPEC_SMALL_MAX")) e->spec_small_max = atoi(ss);
@@ -812,6 +941,11 @@ static int width_class(const StepParams& p) {
 #define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw, g.x >> 3, p
 #define STEP_LDS(b) ((size_t)((b).x / 64u) * sizeof(arcle::WaveLDS))
 #define LAUNCH_STEP(...) hipLaunchKernelGGL((arcle_step_kernel<__VA_ARGS__>), g, b, STEP_LDS(b), st, STEP_ARGS)
+// a launch that orders itself: the preloaded `order` argument carries the object-op mask, `n_envs` the reciprocal of the group count
+#define LAUNCH_GROUPED(INGV, FWV, FLSET, FEATV)                                                                                             \
+  hipLaunchKernelGGL((arcle_step_kernel<INGV, FWV, 0, FEATV, (FLSET) | ARCLE_STEPX_GROUPED, 30>), g, b, STEP_LDS(b), st, (const int8_t*)p.rec,    \
+                     (const int32_t*)p.cnt, p.op, p.sel, reinterpret_cast<const uint32_t*>((uintptr_t)p.long_mask), (int)p.group_magic, __builtin_ctz((unsigned)p.wpw), \
+                     (uint32_t)p.n_envs >> 3, p)
 // the flag combination ARCVecEnv steps with (next-step autoreset, elided zero-fill of `selected`) has its own instantiation
 // with the flags as a compile-time constant
 static constexpr int HOT_FLAGS = ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED;
@@ -834,6 +968,8 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
     if (!acct && research_shape(p)) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 1, RESEARCH_FL, 30);
     else if (!acct && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 1, RESEARCH_INC_FL, 30);
     else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 1);
+  } else if (p.flags == (uint32_t)HOT_FLAGS && p.group_magic) {
+    LAUNCH_GROUPED(arcle::INGRESS_BBOX, arcle::FW_FULL, HOT_FLAGS, 0);
   } else if (p.flags == (uint32_t)HOT_FLAGS && p.order && p.wpw == WAVES_PER_WG) {
     const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));
     hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, STEP_LDS(b), st,
@@ -892,6 +1028,13 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
         }
       }
 #undef LAUNCH_ORDERED
+      if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5 || ING == arcle::INGRESS_POINT) {
+        if (p.group_magic && p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_FLAGS, 0); return; }
+      }
+      if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
+        if (p.group_magic && p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_PACK_FLAGS, 0); return; }
+        if (p.group_magic && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) { LAUNCH_GROUPED(ING, FW, RESEARCH_INC_FL, 1); return; }
+      }
       if (p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_STEP(ING, FW, 0, 0, HOT_PACK_FLAGS, 30); return; }
       if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
         if (p.flags == (uint32_t)HOT_FLAGS && p.spec_grid) {  // speculative grid request: the plane's base rides in the preloaded `order` argument
@@ -931,6 +1074,25 @@ static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStre
 #endif
 
 static bool ensure_order_tables(arcle_env* e);
+
+// which (ingress, flag set) combinations have a self-ordering instantiation (30 x 30, FW_FULL, no accounting)
+static bool grouped_instantiation(int ingress, const StepParams& p) {
+#ifdef ARCLE_FAST_BUILD
+  return ingress == arcle::INGRESS_BBOX && p.flags == (uint32_t)HOT_FLAGS;
+#else
+  const bool tuple5 = ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5;
+  if (p.flags == (uint32_t)HOT_FLAGS) return tuple5 || ingress == arcle::INGRESS_POINT;
+  if (p.flags == (uint32_t)HOT_PACK_FLAGS) return tuple5;
+  return tuple5 && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL);
+#endif
+}
+
+// ... and whether a launch of this handle with these parameters (flags, row shape already filled in) takes it
+static bool grouped_applies(const arcle_env* e, int ingress, const StepParams& p) {
+  return e->group_enabled && e->order_enabled && p.H == 30 && p.W == 30 && p.PS == ARCLE_MAX_CELLS && !e->d_acct && e->base.long_mask != 0 &&
+         (p.n_envs % (8 * ARCLE_GROUP_SIZE)) == 0 && p.n_envs >= 16 * ARCLE_GROUP_SIZE && p.n_envs >= e->group_min && p.n_envs <= e->group_max &&
+         grouped_instantiation(ingress, p);
+}
 
 // Which batches request the grid plane speculatively, and with which cache policies (profiles/round4_experiments.txt; sweeps in
 // profiles/round4_stream_policy_sweep*.txt: us per launch of the C3 mix, same box, action stream cache-resident, plain kernel -> policy):
@@ -1019,6 +1181,16 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     if (!e->pack_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output");
     p.pack_out = e->pack_out;
   }
+  // A launch that orders itself (round 5): the standard 30 x 30 batch whose op table has object operations, stepped with one of the front-ends'
+  // flag sets; every dispatch slot must hold an env and an XCD's slot range must split into ARCLE_GROUP_SIZE strata.  With group_over_order
+  // (default) it also replaces the table form: hints are accepted and ignored, arcle_step_many launches plain self-ordering steps.
+  p.group_magic = 0;
+  if (grouped_applies(e, ingress, p) && !e->ord_cur && !e->pf_next && (e->group_over_order || !(!e->in_many && (e->hint_op || e->ord_have)))) {
+    p.group_magic = (uint32_t)(0x100000000ull / (uint64_t)(p.n_envs / (8 * ARCLE_GROUP_SIZE))) + 1u;  // (G = groups per XCD >= 2)
+    p.spec_grid = 0;
+    p.wpw = wpw = e->wpw_override ? e->wpw_override : e->group_wpw;
+    if (!e->in_many) e->hint_op = nullptr, e->ord_have = 0;
+  }
   const dim3 g = grid_for(p.n_envs, wpw), b(64 * wpw);
   hipStream_t st = (hipStream_t)stream;
   const int fw = width_class(p);
@@ -1027,7 +1199,7 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   // Ordered dispatch for single-step callers: arcle_hint_next_ops left the NEXT step's op indices (one-shot), and / or the previous
   // hinted launch left the table for THIS step.  Scheduling only — whatever a table holds is a permutation of every XCD's env range.
   bool hinted = false;
-  if (!e->in_many && (e->hint_op || e->ord_have)) {
+  if (!p.group_magic && !e->in_many && (e->hint_op || e->ord_have)) {
     const size_t n = (size_t)p.n_envs;
     const uint32_t slots = g.x * (uint32_t)wpw;
     bool ok = e->order_enabled && fw == arcle::FW_FULL && p.H == 30 && p.W == 30 && !acct && wpw == WAVES_PER_WG && (size_t)slots == n &&
@@ -1171,7 +1343,8 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
   probe.flat_stride = e->flat_stride;
   const bool ord_kernel = width_class(e->base) == arcle::FW_FULL && e->base.H == 30 && e->base.W == 30 && !e->d_acct && launch_wpw(e) == WAVES_PER_WG &&
                           ordered_instantiation(ingress, probe);
-  bool ordered = e->order_enabled && ord_kernel && !prefetch && n_steps > 1 && sel && (size_t)slots == n && slots / 8u <= ARCLE_ORD_MAX_SLOTS &&
+  const bool grouped = e->group_over_order && !prefetch && grouped_applies(e, ingress, probe);  // (the launches order themselves: no tables)
+  bool ordered = e->order_enabled && ord_kernel && !grouped && !prefetch && n_steps > 1 && sel && (size_t)slots == n && slots / 8u <= ARCLE_ORD_MAX_SLOTS &&
                  (((ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_POINT) && op) || ingress == arcle::INGRESS_BBOX5);
   if (ordered && ingress == arcle::INGRESS_BBOX5) {  // (host-resident records take the prefetch path above, or none)
     hipPointerAttribute_t attr;

@@ -55,6 +55,10 @@ enum { INGRESS_MASK = 0,    // int8 [N][P] selection masks as given (action['sel
 // ... with non-temporal plane stores / a non-temporal speculative load (which pays where depends on the batch size: the launcher picks)
 #define ARCLE_STEPX_STORE_NT 0x80000
 #define ARCLE_STEPX_EARLY_NT 0x100000
+// ... the launch orders ITSELF (round 5): dispatch slots are dealt to the envs in groups of 16 — one slot from each of the 16 strata the hardware
+// starts an XCD's workgroups in, 16 contiguous envs — and every wave derives, from the group's 16 op indices alone, which env of the group its
+// slot steps: object operations (the longest waves) go to the slots that start first.  No table, no hint, no barrier (see the kernel).
+#define ARCLE_STEPX_GROUPED 0x200000
 // row strides of the 30 x 30 lean instantiations: 3*900 + 10 and 7*900 + 14, rounded up to 16
 #define ARCLE_ROW30_FILTERED_STRIDE 2720
 #define ARCLE_ROW30_FULL_STRIDE 6320
@@ -121,6 +125,7 @@ struct StepParams {
   const int32_t* next_op;  // the next step's op indices: element s at next_op[s * next_op_stride]
   int32_t next_op_stride;  // 1 (op arrays) / 5 (the op field of BBoxWrapper records)
   uint64_t long_mask;      // bit i: op table slot i is an object operation (Move / Rotate / Flip: the longest-running waves)
+  uint32_t group_magic;    // != 0: the launch orders itself (ARCLE_STEPX_GROUPED instantiations): floor(2^32 / (n_envs / 128)) + 1
   int32_t spec_grid;       // 1: the launch's lean twin loads the grid plane speculatively (ARCLE_STEPX_STREAM); the accounting instantiation
                            // then counts that load as issued also for the steps that never use it
 };

@@ -33,14 +33,22 @@ def _gpu():
     from arcle_amd import _lib
     _lib.build()
     _lib.lib()
+    yield
+    O.set_threads(1)
 
 
 def _sample(n, k, seed):
+    """Round 5: the WHOLE batch (the oracle steps 8192 envs x 64 steps in 0.03 s on 16 threads, 196 608 x 10 in 0.2 s): a slot-dependent
+    defect of a launch that permutes env <-> dispatch slot cannot hide in an env that was not sampled.  ARCLE_TEST_SAMPLED=1 restores the
+    round-4 samples (edges + k random envs) for quick local runs."""
+    if not os.environ.get("ARCLE_TEST_SAMPLED"):
+        return np.arange(n)
     edge = np.r_[0:32, n // 2 - 16:n // 2 + 16, n - 32:n]
     return np.unique(np.r_[edge, np.random.default_rng(seed).choice(n, k, replace=False)])
 
 
 def _oracle_for(sample, tasks, H, W, max_trial, kind, ops):
+    O.set_threads(16)  # (the C restatement steps envs in an OpenMP loop; the module fixture puts it back to one thread)
     orc = B.OracleBackend(len(sample), H, W, max_trial, kind, ops)
     orc.set_tasks(*(t[sample] for t in tasks))
     orc.reset()
@@ -49,11 +57,13 @@ def _oracle_for(sample, tasks, H, W, max_trial, kind, ops):
 
 def _compare_sample(batch, orc, sample, fields, what):
     import torch
-    idx = torch.as_tensor(sample, device=batch.device)
+    full = len(sample) == batch.N
+    idx = None if full else torch.as_tensor(sample, device=batch.device)
     for f in fields:
-        got = (batch.plane(f) if f in batch.planes else batch.field(f))[idx].cpu().numpy()
+        t = batch.plane(f) if f in batch.planes else batch.field(f)
+        got = (t if full else t[idx]).cpu().numpy()
         assert np.array_equal(got, orc.get(f)), f"{what}: field {f} differs from the oracle"
-    assert np.array_equal(batch.cnt[idx].cpu().numpy(), orc.counters()), f"{what}: counters differ"
+    assert np.array_equal((batch.cnt if full else batch.cnt[idx]).cpu().numpy(), orc.counters()), f"{what}: counters differ"
 
 
 @pytest.mark.parametrize("form", ["per_step_calls", "ordered_step_many", "ordered_bbox5", "hinted_calls"])

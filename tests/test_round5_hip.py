@@ -1,0 +1,148 @@
+"""Round-5 GPU tests: the launch that orders itself (ARCLE_STEPX_GROUPED).
+
+Every wave of a 32-env group derives the same permutation of the group from the group's 32 op indices and steps the env its dispatch slot
+is dealt — scheduling only.  Checked here: identical rewards, terminated / truncated flags, packed rows, observation rows and every byte
+of state against a twin handle created with ARCLE_GROUPED=0, for every ingress form and flag set that has such an instantiation, on the
+natural C3 stream and on adversarial op streams (every env the same object operation, no object operation at all, object operations
+only in the LAST positions of every group, ...), at several batch sizes incl. ones the grouping does not apply to.  The full-batch
+comparison with the oracle at BASELINE sizes is tests/test_round4_hip.py (whole batch since round 5)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _streams(K, n, seed):
+    """bench.py's C3 actions, then op streams built to break a slot <-> env permutation: positions of the object ops inside the groups"""
+    import bench
+    bb, op = bench.make_actions(K, n, seed)
+    op = op.copy()
+    lng = np.arange(20, 28)
+    g = op.reshape(K, n // 32, 32)
+    g[1] = 24                                   # every env: the same object operation (L = 32 in every group)
+    g[2] = 3                                    # no object operation anywhere (L = 0)
+    g[3, :, :] = 5; g[3, :, 31] = 21            # one object op, in the last position
+    g[4, :, :16] = 7; g[4, :, 16:] = lng[np.arange(16) % 8]   # the late half all object ops: 16 trades per group
+    g[5, :, ::2] = 22; g[5, :, 1::2] = 9        # alternating
+    g[6, :, :] = 26; g[6, :, 0] = 34            # all object ops but position 0 (Submit)
+    g[7] = np.where(np.random.default_rng(seed).random((n // 32, 32)) < 0.5, 23, 1)
+    op[8, : n // 2] = 20                        # half of the batch one object op, the other half the C3 stream
+    op[9] = np.where(np.arange(n) % 3 == 0, 40, op[9])  # out-of-range op indices in every group (ARCLE_ST_BAD_OP, skipped steps)
+    return bb, op
+
+
+@pytest.mark.parametrize("variant", ["bbox", "point", "bbox5", "bbox_pack", "bbox5_pack"])
+@pytest.mark.parametrize("n", [2304, 4096, 8192, 16384])
+def test_grouped_launches_are_scheduling_only(variant, n):
+    import torch
+    import bench
+    from arcle_amd.engine import STEP_PACK_OBS
+    K, dev = 16, torch.device("cuda:0")
+    bb_np, op_np = _streams(K, n, 77 + n)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    xy = bb[:, :, :2].contiguous()
+    act5 = torch.cat([bb, op[:, :, None]], 2).contiguous()
+    with _Env(ARCLE_GROUPED=0):
+        a = bench.make_batch(dev, n, seed=11)
+    with _Env(ARCLE_GROUPED=1, ARCLE_GROUP_MIN=0):
+        b = bench.make_batch(dev, n, seed=11)
+    FL = a.elide_flag | 1
+    pa = pb = None
+    if variant.endswith("_pack"):
+        FL |= STEP_PACK_OBS
+        pa, pb = a.set_packed_output(), b.set_packed_output()
+
+    def one(batch, s):
+        if variant == "point":
+            return batch.step_point(xy[s], op[s], FL)
+        if variant.startswith("bbox5"):
+            return batch.step_bbox5(act5[s], FL)
+        return batch.step_bbox(bb[s], op[s], FL)
+    for rep in range(2):  # (the second pass steps the states the adversarial streams left behind)
+        for s in range(K):
+            ra, ta = one(a, s)
+            ra, ta = ra.clone(), ta.clone()
+            rb, tb = one(b, s)
+            assert torch.equal(ra, rb) and torch.equal(ta, tb), (variant, n, rep, s)
+            if pa is not None:
+                assert torch.equal(pa, pb), (variant, n, rep, s)
+    torch.cuda.synchronize()
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), (variant, n, k)
+    assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt)
+    assert a.status() == b.status()
+
+
+def test_grouped_step_many_and_hints_match_single_steps():
+    """arcle_step_many and hinted single steps on a handle whose launches order themselves (the hint is accepted and ignored, step_many
+    enqueues plain self-ordering launches) against ungrouped single steps."""
+    import torch
+    import bench
+    n, K, dev = 8192, 12, torch.device("cuda:0")
+    bb_np, op_np = _streams(K, n, 5)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    with _Env(ARCLE_GROUPED=0):
+        a = bench.make_batch(dev, n, seed=3)
+    b, c = bench.make_batch(dev, n, seed=3), bench.make_batch(dev, n, seed=3)
+    FL = a.elide_flag | 1
+    rm, tm = b.step_many("bbox", bb, op, FL)
+    for s in range(K):
+        ra, ta = a.step_bbox(bb[s], op[s], FL)
+        if s + 1 < K:
+            c.hint_next_ops(op[s + 1])
+        rc, tc = c.step_bbox(bb[s], op[s], FL)
+        assert torch.equal(ra, rm[s]) and torch.equal(ta, tm[s]) and torch.equal(ra, rc) and torch.equal(ta, tc), s
+    torch.cuda.synchronize()
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]) and torch.equal(a.planes[k], c.planes[k]), k
+    assert torch.equal(a.cnt, b.cnt) and torch.equal(a.cnt, c.cnt) and torch.equal(a.rec, b.rec) and torch.equal(a.rec, c.rec)
+
+
+def test_grouped_research_step_matches_ungrouped():
+    """The research env's flag set (dense reward, TimeLimit, device-drawn augmented tasks, incremental FilterO2ARC rows): the grouped launch
+    also counts an env about to be re-initialised as a long wave (its step counter reads limit - 1) — identical to the ungrouped twin."""
+    import torch
+    import bench
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    n, K, dev = 4096, 30, torch.device("cuda:0")
+    bb_np, op_np = _streams(K, n, 99)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np % 35).to(dev)
+    kw = dict(device=dev, seed=5, autoreset="resample", augment=("permute", "rot90"), dense_reward=True, max_episode_steps=9)
+    with _Env(ARCLE_GROUPED=0):
+        va = ARCVecEnv(O2ARCv2Env, n, SyntheticLoader(n_tasks=60, seed=2, max_size=(30, 30)), **kw)
+    vb = ARCVecEnv(O2ARCv2Env, n, SyntheticLoader(n_tasks=60, seed=2, max_size=(30, 30)), **kw)
+    for v in (va, vb):
+        v.reset()
+        v.enable_flat_rows(filtered=True)
+    for s in range(K):
+        _, ra, ta, tra, ia = va.step_bbox(bb[s], op[s])
+        _, rb, tb, trb, ib = vb.step_bbox(bb[s], op[s])
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(tra, trb), s
+        assert torch.equal(va.rows, vb.rows), s
+    for k in va.batch.planes:
+        assert torch.equal(va.batch.planes[k], vb.batch.planes[k]), k
+    assert torch.equal(va.batch.cnt, vb.batch.cnt)
+    va.check_errors(), vb.check_errors()
