@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ARCLE_HIP_LIB") or os.path.join(_CSRC, "libarcle_hip.
 SOURCES = [os.path.join(_CSRC, "arcle_hip.hip"), os.path.join(_CSRC, "arcle_wave.h"),
            os.path.join(_CSRC, "..", "..", "include", "arcle_hip.h")]
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 N_PLANES = 8
 MAX_OPS = 64
 BITS_STRIDE = 128  # bytes between envs of a bit-packed mask array (ARCLE_MAX_CELLS / 8)
@@ -21,12 +21,12 @@ INGRESS = {"mask": 0, "bbox": 1, "point": 2, "bbox5": 3, "bits": 4}  # enum arcl
 EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buffers", "arcle_set_op_table",
            "arcle_can_elide_selected", "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table",
            "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_step_bbox5", "arcle_step_bits", "arcle_pack_mask_bits",
-           "arcle_step_many", "arcle_set_dispatch_order", "arcle_hint_next_ops", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation",
+           "arcle_step_many", "arcle_set_dispatch_order", "arcle_hint_next_ops", "arcle_launch_info", "arcle_autotune", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation",
            "arcle_packed_obs_size", "arcle_pack_obs", "arcle_set_packed_output", "arcle_set_sampler", "arcle_reset_sampled",
            "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_invalidate", "arcle_flat_obs_size", "arcle_flatten_obs",
            "arcle_set_flat_output", "arcle_set_flat_output_ex", "arcle_get_state_rows", "arcle_set_state_rows",
            "arcle_transition_rows", "arcle_get_plane", "arcle_set_plane", "arcle_get_status",
-           "arcle_enable_accounting", "arcle_get_accounting", "arcle_get_accounting_ex", "arcle_last_error", "arcle_debug_copy_order"]
+           "arcle_enable_accounting", "arcle_get_accounting", "arcle_get_accounting_ex", "arcle_last_error"]
 
 
 class ArcleHipError(RuntimeError):
@@ -91,6 +91,8 @@ def lib():
     L.arcle_step_many.argtypes = [vp, ctypes.c_int, i32, vp, vp, vp, vp, u32, vp]
     L.arcle_set_dispatch_order.argtypes = [vp, ctypes.c_int]
     L.arcle_hint_next_ops.argtypes = [vp, vp, i32]
+    L.arcle_launch_info.argtypes = [vp, ctypes.c_int, u32, vp]
+    L.arcle_autotune.argtypes = [vp, ctypes.c_int, vp, vp, u32, vp, i32, vp]
     L.arcle_set_flat_output_ex.argtypes = [vp, vp, i32, ctypes.c_int, ctypes.c_int]
     L.arcle_get_state_rows.argtypes = [vp, vp, i32, vp]
     L.arcle_set_state_rows.argtypes = [vp, vp, i32, vp, vp]
@@ -118,7 +120,6 @@ def lib():
     L.arcle_get_accounting.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                        ctypes.c_int, vp]
     L.arcle_last_error.argtypes = [vp]
-    L.arcle_debug_copy_order.argtypes = [vp, vp]
     L.arcle_last_error.restype = ctypes.c_char_p
     if L.arcle_abi_version() != ABI_VERSION:
         raise ArcleHipError("libarcle_hip.so ABI version mismatch — rebuild")

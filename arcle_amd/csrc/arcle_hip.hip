@@ -238,84 +238,16 @@ __device__ __forceinline__ int wave_of_launch(int waves_per_wg = WAVES_PER_WG, u
   return __builtin_amdgcn_readfirstlane((int)(vb * (uint32_t)waves_per_wg + (threadIdx.x >> 6)));
 }
 
-// ---- dispatch order of the NEXT step (ARCLE_STEPX_ORDERED launches of arcle_step_many) -------------------------------------
+// ---- dispatch order ---------------------------------------------------------------------------------------------------------------
 // A launch of one wave per env ends with its last object operation: the hardware starts the 8192 waves over ~2 us (every XCD works
 // through its workgroups in index order) and a Move / Rotate / Flip wave lives ~1.2 us longer than the others, so a launch whose late
-// slots hold object ops ends ~0.6 us after one whose EARLY slots hold them (tools/lptbench.py: 5.33 vs 4.71 us).  arcle_step_many
-// knows the next step's op array while a step runs (the caller handed over K steps of actions), so the first workgroup on every
-// XCD of launch t partitions that XCD's slot range for launch t+1: with L object ops among the rs slots, the object ops that sit
-// in slots >= L trade places with the other ops sitting in slots < L (k-th with k-th) — afterwards slots [0, L) hold the object ops.
-// The table maps slot -> env and is a permutation of the XCD's own env range (L2 affinity is kept).  It is scheduling only: whatever
-// the table holds, every env is stepped exactly once, and a caller that rewrites the next actions after this ran loses nothing
-// but the ordering.
+// slots hold object ops ends ~0.6 us after one whose EARLY slots hold them (tools/lptbench.py: 5.33 vs 4.71 us).  Rounds 3-4 sorted the
+// NEXT step's slots from a table written by the front workgroups of the previous launch (arcle_step_many, or single steps after
+// arcle_hint_next_ops: 4.93 us, but only for callers who know their ops one step ahead).  Round 5: the launch orders ITSELF inside groups
+// of ARCLE_GROUP_SIZE envs (the GROUPED block of arcle_step_kernel below: 4.90 us, no table, no hint) and the table form is gone.
 #ifndef ARCLE_GROUP_SIZE
 #define ARCLE_GROUP_SIZE 32  // envs (= dispatch strata) per group of a self-ordering launch
 #endif
-#define ARCLE_ORD_BLOCKS 8u    // one per XCD: workgroup b < 8 runs on XCD b
-#define ARCLE_ORD_MAX_SLOTS 1024u  // slots per XCD this pass handles (2 per thread of a 512-thread workgroup): N <= 8192
-__device__ __forceinline__ void order_next_step(const StepParams& p, uint32_t xcd, uint32_t rs) {
-  __shared__ uint32_t cnt[16];
-  __shared__ uint32_t long_before_L;
-  __shared__ uint16_t early_other[ARCLE_ORD_MAX_SLOTS], late_long[ARCLE_ORD_MAX_SLOTS], slot_of[ARCLE_ORD_MAX_SLOTS];
-  const uint32_t t = threadIdx.x, wave = t >> 6, base = xcd * rs;
-  const uint32_t s0 = t, s1 = t + 512u;
-  // With a step limit (ARCLE_STEP_TRUNCATE, the research env) the longest waves of the next launch are not its object operations but its
-  // auto-resets (new task from the table, augmentation, nine plane stores, the whole observation row): an env whose step counter reads
-  // limit - 1 now will be re-initialised by the next launch.  The counter is read while this launch's waves update it — a stale or
-  // fresh value only moves an env between the two classes (scheduling only).
-  const bool by_limit = (p.flags & ARCLE_STEP_TRUNCATE) != 0u && p.step_limit > 0;
-  bool lg0 = false, lg1 = false;
-  if (s0 < rs) {
-    const uint32_t o = (uint32_t)p.next_op[(size_t)(base + s0) * (size_t)p.next_op_stride];
-    lg0 = (p.long_mask >> (o < 63u ? o : 63u)) & 1ull;
-    if (by_limit) lg0 = lg0 || p.cnt[2 * (size_t)(base + s0)] == p.step_limit - 1;
-  }
-  if (s1 < rs) {
-    const uint32_t o = (uint32_t)p.next_op[(size_t)(base + s1) * (size_t)p.next_op_stride];
-    lg1 = (p.long_mask >> (o < 63u ? o : 63u)) & 1ull;
-    if (by_limit) lg1 = lg1 || p.cnt[2 * (size_t)(base + s1)] == p.step_limit - 1;
-  }
-  const unsigned long long b0 = __ballot(lg0), b1 = __ballot(lg1);
-  if ((t & 63u) == 0) {
-    cnt[wave] = (uint32_t)__popcll(b0);
-    cnt[8 + wave] = (uint32_t)__popcll(b1);
-  }
-  slot_of[s0] = (uint16_t)s0;
-  slot_of[s1] = (uint16_t)s1;
-  __syncthreads();
-  uint32_t before0 = 0, before1 = 0, L = 0;  // object ops in the slots before s0 / s1, and among all rs slots
-#pragma unroll
-  for (uint32_t c = 0; c < 16; c++) {
-    const uint32_t v = cnt[c];
-    if (c < wave) before0 += v;
-    if (c < 8 + wave) before1 += v;
-    L += v;
-  }
-  before0 += __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
-  before1 += __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
-  if (s0 == L) long_before_L = before0;
-  if (s1 == L) long_before_L = before1;
-  __syncthreads();
-  const uint32_t pl = L < rs ? long_before_L : L;  // object ops already inside [0, L)
-  const uint32_t n_swap = L - pl;                  // = object ops in [L, rs) = other ops in [0, L)
-  if (s0 < rs) {
-    if (s0 < L && !lg0) early_other[s0 - before0] = (uint16_t)s0;
-    if (s0 >= L && lg0) late_long[before0 - pl] = (uint16_t)s0;
-  }
-  if (s1 < rs) {
-    if (s1 < L && !lg1) early_other[s1 - before1] = (uint16_t)s1;
-    if (s1 >= L && lg1) late_long[before1 - pl] = (uint16_t)s1;
-  }
-  __syncthreads();
-  for (uint32_t k = t; k < n_swap; k += 512u) {
-    const uint16_t a = early_other[k], b = late_long[k];
-    slot_of[a] = b;
-    slot_of[b] = a;
-  }
-  __syncthreads();
-  if (s0 < rs) p.order_next[base + s0] = base + slot_of[s0];
-  if (s1 < rs) p.order_next[base + s1] = base + slot_of[s1];
-}
 
 // ING: selection ingress form; FW: arcle::FW_* grid-width class;
 // ACCT: 1 = add the step's algorithmic bytes to p.acct[env]; FEAT: 1 = carries the ARCLE_STEP_FEATURE_FLAGS code
@@ -325,8 +257,8 @@ template <int ING, int FW, int ACCT, int FEAT, int FL = -1, int WC = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(ARCLE_SGPR_CAP))) void arcle_step_kernel(
     const int8_t* rec, const int32_t* cnt, const int32_t* op, const void* sel, const uint32_t* order, int n_envs, int wpw_front, uint32_t nb8,
     const StepParams pa) {
-  // (wpw_front: waves per workgroup | front workgroups that do not step envs << 8 — ordered-dispatch launches only)
-  const int wpw = (FL >= 0 && (FL & ARCLE_STEPX_ORDERED)) ? (wpw_front & 0xff) : wpw_front;
+  // (wpw_front: waves per workgroup; self-ordering launches pass its log2)
+  const int wpw = wpw_front;
   StepParams p = pa;  // (a register-promoted copy: only the fields a path reads are ever fetched)
   if (WC == 30) {
     p.H = p.W = 30;
@@ -348,15 +280,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   // (at the FRONT of the grid: the copy waves start first and their PCIe round trips run under the whole launch — 6.9 us per step at
   // 8192 envs; placed at the end of the grid they start last and the launch waits for them: 8.1 us, profiles/round3_experiments.txt)
   const bool pf_role = ING == arcle::INGRESS_BBOX5_PF && blockIdx.x < ARCLE_PF_BLOCKS;
-  uint32_t pf_first = 0, pf_off = ING == arcle::INGRESS_BBOX5_PF ? ARCLE_PF_BLOCKS : 0u;
-  constexpr bool ORD = FL >= 0 && (FL & ARCLE_STEPX_ORDERED) != 0;
-  if (ORD) {  // (as above: at the front of the grid, one workgroup on every XCD; their number travels in a preloaded argument)
-    pf_off = (uint32_t)wpw_front >> 8;
-    if (blockIdx.x < pf_off) {
-      order_next_step(pa, blockIdx.x, nb8 * (uint32_t)wpw);
-      return;
-    }
-  }
+  const uint32_t pf_first = 0, pf_off = ING == arcle::INGRESS_BBOX5_PF ? ARCLE_PF_BLOCKS : 0u;
   if (pf_role) {
     // The first workgroups of the launch are a copy engine: they move the NEXT step's action records from pinned host memory into the
     // device staging buffer that step will read (arcle_step_many over host-resident records).  The PCIe round trips of these few
@@ -386,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     // An XCD starts the workgroups of its slot range in index order, so the range falls into GS = 32 strata of G = rs / 32 consecutive slots
     // that start one after the other.  Group g of the XCD = the 32 slots {g + j G, j = 0..31} (one per stratum) and the 32 CONTIGUOUS envs
     // xbase + 32 g .. + 31.  Every wave of the group loads the inputs of ALL 32 envs — records, counters, tuples, op indices: one request of
-    // the whole wave per array, 1.4 KB — ballots which ops are object operations (m, L = popc(m)) and applies order_next_step's rule inside
+    // the whole wave per array, 1.4 KB — ballots which ops are object operations (m, L = popc(m)) and applies one rule inside
     // the group: by default position j steps env j; the k-th object op found in a position >= L trades places with the k-th other op found
     // in a position < L.  All 32 waves compute the same permutation from the same 32 ops, so every env is stepped exactly once whatever the
     // ops are, and the slot's env is then picked out of the lanes with v_readlane: no table, no hint, no second round trip, no barrier.
@@ -409,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     arcle::Wave w(p, &tiles[threadIdx.x >> 6], nullptr, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0, false);
     static_assert(arcle::is_tuple(ING) && ING != arcle::INGRESS_BBOX5_PF, "grouped launches: bbox / point tuples and 5-tuple records");
     constexpr bool REC5 = ING == arcle::INGRESS_BBOX5;
-    constexpr bool BY_LIMIT = (FL & ARCLE_STEP_TRUNCATE) != 0;  // (the research step: an env about to be re-initialised counts as long, see order_next_step)
+    constexpr bool BY_LIMIT = (FL & ARCLE_STEP_TRUNCATE) != 0;  // (the research step: an env about to be re-initialised counts as long: its auto-reset is that kernel's longest wave)
     // the group's inputs: lanes 0-31 read the 32 op indices (the upper half repeats them); records (16 B per env), bbox tuples (16 B), point
     // tuples and counters (8 B) as ONE contiguous block per array spread over the 64 lanes — env e's item in lanes 2 e, 2 e + 1
     const uint32_t lane = threadIdx.x & 63u, e = lane & 31u;
@@ -478,9 +402,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
   arcle::Wave w(p, &tiles[threadIdx.x >> 6], nullptr, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0, false);  // (no expansion table: Wave::expand16)
   constexpr bool STREAM = FL >= 0 && (FL & ARCLE_STEPX_STREAM) != 0;
   w.store_nt = FL >= 0 && (FL & ARCLE_STEPX_STORE_NT) != 0;
-  // ordered dispatch: the slot's table entry is requested beside the inputs of the env in the same position — most slots keep it
-  uint32_t slot_env = (uint32_t)env;
-  if (ORD) slot_env = xl::uload1(arcle::at(order, 4u * (uint32_t)env));
   arcle::StepInputs in = arcle::load_inputs<ING>(w, env, rec, cnt, op, sel);  // in flight while the expansion table is built
   // streaming regime: the env's grid plane is requested NOW, beside the scalar inputs (its address needs nothing but the env index; the
   // plane's base travels in the preloaded `order` argument, which these launches do not use otherwise) — two of three steps of the O2ARC
@@ -493,10 +414,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     early = true;
   } else if (ARCLE_PACK_SPEC && FL >= 0 && (FL & ARCLE_STEP_PACK_OBS) && WC == 30) {
     // fused packed rows: EVERY wave needs the grid plane at its end (the row it packs), so the speculative request is never wasted —
-    // and the epilogue no longer waits for a read-back (a traded slot of an ordered launch drops it below: it belongs to another env)
+    // and the epilogue no longer waits for a read-back
     early_grid = xl::load16(pa.plane[ARCLE_PL_GRID], (uint32_t)env * (uint32_t)ARCLE_MAX_CELLS + 16u * (threadIdx.x & 63u));
     early = true;
-  } else if (WC == 0 && !ACCT && !FEAT && !ORD && ING != arcle::INGRESS_BBOX5_PF) {
+  } else if (WC == 0 && !ACCT && !FEAT && ING != arcle::INGRESS_BBOX5_PF) {
     // small batches of other grid shapes (at most a wave or two per SIMD: the launch is one wave's latency chain, nothing competes for
     // the memory pipes): the same speculative request, decided by the launcher (StepParams::spec_grid)
     if (pa.spec_grid) {
@@ -511,16 +432,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #if ARCLE_STOP_AT == 1
   return;
 #endif
-  int my_env = env;
-  if (ORD && slot_env != (uint32_t)env) {  // a traded slot: one more round trip for the other env's inputs
-    my_env = (int)slot_env;
-    in = arcle::load_inputs<ING>(w, my_env, rec, cnt, op, sel);
-    early = false;
-  }
 #ifdef ARCLE_TRACE_WAVES
-  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, t_entry, xl::clock());
+  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in, t_entry, xl::clock());
 #else
-  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, 0, 0, early, early_grid);
+  arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in, 0, 0, early, early_grid);
 #endif
 }
 
@@ -614,6 +529,12 @@ struct DeviceGuard {
   }
 };
 
+struct LaunchPlan {  // how a step launch runs (see plan_launch)
+  int policy;   // 0 | 'A' | 'B' | 'H' | 'J' (StepParams::spec_grid)
+  int wpw;      // waves per workgroup
+  int grouped;  // 1: a launch that orders itself (ARCLE_STEPX_GROUPED)
+};
+
 struct arcle_env {
   arcle_config cfg;
   arcle_buffers bufs;
@@ -633,25 +554,19 @@ struct arcle_env {
   int32_t* d_stage;           // int32 [2][n_envs][5]: staging of host-resident action records (arcle_step_many), allocated on first use
   const int32_t* pf_next;     // set by arcle_step_many around a launch: the next step's host records / the staging buffer to fill
   int32_t* pf_stage;
-  uint32_t* d_order;          // uint32 [3][n_envs]: dispatch-order tables of arcle_step_many (two alternating + the identity), first use
-  int order_enabled;          // arcle_set_dispatch_order (default 1)
-  const uint32_t* ord_cur;    // set by arcle_step_many around a launch: this step's table, the one to fill, the next step's ops
-  uint32_t* ord_next;
-  const int32_t* ord_next_op;
-  int32_t ord_next_stride;
-  // one-shot hint of single-step callers (arcle_hint_next_ops): the NEXT step's op indices, consumed by the next arcle_step_* launch,
-  // whose front workgroups then write table [ord_parity ^ 1]; ord_have: table [ord_parity] was written for the step about to be launched
-  const int32_t* hint_op;
-  int32_t hint_stride;
-  int ord_have, ord_parity;
-  int in_many;                // inside arcle_step_many's loop (it manages the tables itself)
+  int pf_active;              // ... inside such a call (its first and last launches read records no front workgroup staged)
+  int order_enabled;          // arcle_set_dispatch_order (default 1): launches of the standard batch order themselves (see the kernel)
   int stream_min;             // batches of at least this many envs take the streaming instantiations (ARCLE_STREAM_MIN_ENVS / env override)
   int spec_small_max;         // batches of at most this many envs request the grid plane speculatively (ARCLE_SPEC_SMALL_MAX env override)
   int stream_policy_override; // tuning runs: ARCLE_STREAM_POLICY = 0 | A | B | H | J for every batch size
-  int group_enabled;          // launches of plain single-step calls order themselves (ARCLE_GROUPED = 0 | 1 overrides; default 1)
+  int group_enabled;          // tuning runs: ARCLE_GROUPED = 0 switches the self-ordering launches off for handles created under it
   int group_min, group_max;   // ... for batches of group_min .. group_max envs (ARCLE_GROUP_MIN / ARCLE_GROUP_MAX)
   int group_wpw;              // ... in workgroups of this many waves (ARCLE_GROUP_WPW)
-  int group_over_order;       // ... also where the caller hinted the next ops / arcle_step_many could sort them (ARCLE_GROUP_OVER_ORDER, default 1)
+  const LaunchPlan* forced;   // arcle_autotune timing a candidate
+  int tuned_valid, tuned_ingress;   // arcle_autotune's choice for (ingress, flags) launches of this handle
+  uint32_t tuned_flags;
+  LaunchPlan tuned;
+  int dense_cache_live;       // the dense-pair cache may hold pairs: 1 a dense step ran since it was last dropped, 2 always assume so (a captured dense step)
   int wpw_override;           // tuning runs: waves per workgroup of the step launches (ARCLE_WPW = 1, 2, 4 or 8), 0 = the library's choice
   int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
   uint32_t* d_acct;
@@ -698,10 +613,8 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   }
   e->group_enabled = 1;
   e->group_min = 2049;
-  e->group_max = 32768;
+  e->group_max = 12288;
   e->group_wpw = 4;
-  e->group_over_order = 0;
-  if (const char* gs = getenv("ARCLE_GROUP_OVER_ORDER")) e->group_over_order = atoi(gs) != 0;
   if (const char* gs = getenv("ARCLE_GROUPED")) e->group_enabled = atoi(gs) != 0;
   if (const char* gs = getenv("ARCLE_GROUP_MIN")) e->group_min = atoi(gs);
   if (const char* gs = getenv("ARCLE_GROUP_MAX")) e->group_max = atoi(gs);
@@ -807,7 +720,6 @@ extern "C" int arcle_destroy(arcle_env* e) {
   for (int i = 0; i < e->n_retired; i++) (void)hipFree(e->retired_ops[i]);
   if (e->d_dense_cache) (void)hipFree(e->d_dense_cache);
   if (e->d_stage) (void)hipFree(e->d_stage);
-  if (e->d_order) (void)hipFree(e->d_order);
   if (e->d_acct) (void)hipFree(e->d_acct);
   delete e;
   return ARCLE_OK;
@@ -864,7 +776,7 @@ extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n
     e->base.d_ops = fresh;
   }
   e->base.n_ops = n_ops;
-  e->base.long_mask = 0;  // the operations whose waves run longest (ordered dispatch of arcle_step_many)
+  e->base.long_mask = 0;  // the operations whose waves run longest (self-ordering launches deal them to the slots that start first)
   for (int i = 0; i < n_ops && i < 63; i++) {
     const uint32_t k = ARCLE_OP_KIND(descs[i]);
     if (k == ARCLE_OP_MOVE || k == ARCLE_OP_ROTATE || k == ARCLE_OP_FLIP) e->base.long_mask |= 1ull << i;
@@ -878,6 +790,10 @@ extern "C" int arcle_set_task_table(arcle_env* e, const int8_t* in_planes, const
   if (n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "empty task table");
   if ((reinterpret_cast<uintptr_t>(in_planes) & 15) || (reinterpret_cast<uintptr_t>(ans_planes) & 15))
     return fail(e, ARCLE_ERR_ARG, "task table planes must be 16-byte aligned");
+  // (an entry's two dims are read with ONE aligned scalar dword load, arcle::load_task: the dims arrays start on a 4-byte boundary and their
+  // allocation covers 2 * n_tasks rounded up to a multiple of 4 bytes)
+  if ((reinterpret_cast<uintptr_t>(in_dims) & 3) || (reinterpret_cast<uintptr_t>(ans_dims) & 3))
+    return fail(e, ARCLE_ERR_ARG, "task table dims arrays must be 4-byte aligned (and allocated in whole dwords)");
   // (the table stays caller-owned and must outlive its last use; what CAN be checked here: all four are device-accessible memory)
   for (const void* ptr : {(const void*)in_planes, (const void*)in_dims, (const void*)ans_planes, (const void*)ans_dims}) {
     hipPointerAttribute_t attr;
@@ -938,7 +854,7 @@ static int width_class(const StepParams& p) {
   if (p.W < 16 || p.W > 32) return arcle::FW_GENERIC;
   return p.PS == ARCLE_MAX_CELLS ? arcle::FW_FULL : arcle::FW_FAST;
 }
-#define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw, g.x >> 3, p
+#define STEP_ARGS (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, (const uint32_t*)nullptr, p.n_envs, p.wpw, g.x >> 3, p
 #define STEP_LDS(b) ((size_t)((b).x / 64u) * sizeof(arcle::WaveLDS))
 #define LAUNCH_STEP(...) hipLaunchKernelGGL((arcle_step_kernel<__VA_ARGS__>), g, b, STEP_LDS(b), st, STEP_ARGS)
 // a launch that orders itself: the preloaded `order` argument carries the object-op mask, `n_envs` the reciprocal of the group count
@@ -959,8 +875,7 @@ static constexpr int RESEARCH_INC_FL = RESEARCH_FL | ARCLE_STEP_ROWS_INCREMENTAL
 static bool research_shape(const StepParams& p, uint32_t extra = 0) {
   return p.flags == ((uint32_t)RESEARCH_FLAGS | extra) && p.flat_filter == 1 && p.flat_tail == 0 && p.flat_stride == ARCLE_ROW30_FILTERED_STRIDE;
 }
-#ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiations exist (seconds instead of a minute)
-static bool ordered_instantiation(int ingress, const StepParams& p) { return ingress == arcle::INGRESS_BBOX && p.flags == (uint32_t)HOT_FLAGS; }
+#ifdef ARCLE_FAST_BUILD  // development builds: only the benchmark's instantiations exist (seconds instead of minutes)
 template <int ING>
 static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if (ING != arcle::INGRESS_BBOX || width_class(p) != arcle::FW_FULL || p.H != 30 || p.W != 30) return ARCLE_ERR_CONFIG;
@@ -970,10 +885,6 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
     else LAUNCH_STEP(arcle::INGRESS_BBOX, arcle::FW_FULL, 1, 1);
   } else if (p.flags == (uint32_t)HOT_FLAGS && p.group_magic) {
     LAUNCH_GROUPED(arcle::INGRESS_BBOX, arcle::FW_FULL, HOT_FLAGS, 0);
-  } else if (p.flags == (uint32_t)HOT_FLAGS && p.order && p.wpw == WAVES_PER_WG) {
-    const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));
-    hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_ORDERED, 30>), go, b, STEP_LDS(b), st,
-                       (const int8_t*)p.rec, (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);
   } else if (p.flags == (uint32_t)HOT_FLAGS && p.spec_grid) {
 #define LAUNCH_STREAM(BITS)                                                                                                                    \
   hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX, arcle::FW_FULL, 0, 0, HOT_FLAGS | ARCLE_STEPX_STREAM | (BITS), 30>), g, b, STEP_LDS(b), st, (const int8_t*)p.rec, \
@@ -990,13 +901,6 @@ static int launch_step_ing(int, bool acct, bool feat, dim3 g, dim3 b, hipStream_
   return ARCLE_OK;
 }
 #else
-// which (ingress, flag set) combinations have an ordered-dispatch instantiation (30 x 30, FW_FULL, no accounting, 8-wave workgroups)
-static bool ordered_instantiation(int ingress, const StepParams& p) {
-  const bool tuple5 = ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5;
-  if (p.flags == (uint32_t)HOT_FLAGS) return tuple5 || ingress == arcle::INGRESS_POINT;
-  if (p.flags == (uint32_t)HOT_PACK_FLAGS) return tuple5;
-  return tuple5 && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL);
-}
 template <int ING, int FW>
 static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   if constexpr (FW == arcle::FW_FULL) {  // the standard 30 x 30 grid: lean instantiations with the dimensions as compile-time constants
@@ -1005,29 +909,10 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
         if (p.flags == (uint32_t)HOT_FLAGS && p.next_sel && p.wpw == WAVES_PER_WG) {  // records prefetched by the launch's front workgroups
           const dim3 gp(g.x + ARCLE_PF_BLOCKS);
           hipLaunchKernelGGL((arcle_step_kernel<arcle::INGRESS_BBOX5_PF, FW, 0, 0, HOT_FLAGS, 30>), gp, b, STEP_LDS(b), st, (const int8_t*)p.rec,
-                             (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw, g.x >> 3, p);
+                             (const int32_t*)p.cnt, p.op, p.sel, (const uint32_t*)nullptr, p.n_envs, p.wpw, g.x >> 3, p);
           return;
         }
       }
-      // ordered dispatch (arcle_step_many, or a single step after arcle_hint_next_ops): waves take their env from the order table, the
-      // launch's front workgroups (one per XCD, present iff there is a next step to sort) write the next table
-#define LAUNCH_ORDERED(FLSET, FEATV)                                                                                                  \
-  do {                                                                                                                                \
-    const dim3 go(g.x + (p.order_next ? ARCLE_ORD_BLOCKS : 0u));                                                                     \
-    hipLaunchKernelGGL((arcle_step_kernel<ING, FW, 0, FEATV, (FLSET) | ARCLE_STEPX_ORDERED, 30>), go, b, STEP_LDS(b), st, (const int8_t*)p.rec, \
-                       (const int32_t*)p.cnt, p.op, p.sel, p.order, p.n_envs, p.wpw | (int)((go.x - g.x) << 8), g.x >> 3, p);         \
-    return;                                                                                                                           \
-  } while (0)
-      if (p.order && p.wpw == WAVES_PER_WG) {
-        if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5 || ING == arcle::INGRESS_POINT) {
-          if (p.flags == (uint32_t)HOT_FLAGS) LAUNCH_ORDERED(HOT_FLAGS, 0);
-        }
-        if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
-          if (p.flags == (uint32_t)HOT_PACK_FLAGS) LAUNCH_ORDERED(HOT_PACK_FLAGS, 0);
-          if (research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) LAUNCH_ORDERED(RESEARCH_INC_FL, 1);
-        }
-      }
-#undef LAUNCH_ORDERED
       if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5 || ING == arcle::INGRESS_POINT) {
         if (p.group_magic && p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_FLAGS, 0); return; }
       }
@@ -1073,8 +958,6 @@ static int launch_step_ing(int fw, bool acct, bool feat, dim3 g, dim3 b, hipStre
 }
 #endif
 
-static bool ensure_order_tables(arcle_env* e);
-
 // which (ingress, flag set) combinations have a self-ordering instantiation (30 x 30, FW_FULL, no accounting)
 static bool grouped_instantiation(int ingress, const StepParams& p) {
 #ifdef ARCLE_FAST_BUILD
@@ -1087,11 +970,19 @@ static bool grouped_instantiation(int ingress, const StepParams& p) {
 #endif
 }
 
-// ... and whether a launch of this handle with these parameters (flags, row shape already filled in) takes it
+// ... and whether a launch of this handle with these parameters (flags, row shape already filled in) CAN take it (whether it does: plan_launch)
 static bool grouped_applies(const arcle_env* e, int ingress, const StepParams& p) {
   return e->group_enabled && e->order_enabled && p.H == 30 && p.W == 30 && p.PS == ARCLE_MAX_CELLS && !e->d_acct && e->base.long_mask != 0 &&
-         (p.n_envs % (8 * ARCLE_GROUP_SIZE)) == 0 && p.n_envs >= 16 * ARCLE_GROUP_SIZE && p.n_envs >= e->group_min && p.n_envs <= e->group_max &&
-         grouped_instantiation(ingress, p);
+         (p.n_envs % (8 * ARCLE_GROUP_SIZE)) == 0 && p.n_envs >= 16 * ARCLE_GROUP_SIZE && grouped_instantiation(ingress, p);
+}
+
+// A self-ordering launch reads the actions of 32 envs per wave: fine from device memory (one wave's request serves the whole group out of
+// L2), 32 x the PCIe traffic for a payload in pinned host memory (ARCVecEnv.step_bbox5 accepts one) — those keep the scalar per-env loads
+static bool on_device(const void* ptr) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, ptr) == hipSuccess) return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  (void)hipGetLastError();
+  return false;
 }
 
 // Which batches request the grid plane speculatively, and with which cache policies (profiles/round4_experiments.txt; sweeps in
@@ -1124,6 +1015,40 @@ static int launch_wpw(const arcle_env* e) {
   return (e->cfg.n_envs >= 65536 || e->cfg.n_envs <= e->spec_small_max) ? 4 : WAVES_PER_WG;
 }
 
+// How a step launch of this handle runs: cache policy of the speculative grid request, workgroup size, self-ordering or not.  The library's
+// tables (stream_policy, launch_wpw, the grouping window) were measured on one box with one action-stream regime; arcle_autotune replaces
+// them, per handle, by what it measured on THIS handle's size, box and action residency.
+// p: the launch's parameters with flags and row shape filled in; device_payload: the actions live in device memory
+static LaunchPlan plan_launch(const arcle_env* e, int ingress, const StepParams& p, bool device_payload) {
+  const uint32_t flags = p.flags;
+  const bool std30 = p.H == 30 && p.W == 30 && p.PS == ARCLE_MAX_CELLS;
+  const bool tuple5 = ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5;
+  // which choices exist for this launch at all
+  const bool can_group = device_payload && !e->pf_active && grouped_applies(e, ingress, p);
+  const bool any_policy = std30 && flags == (uint32_t)HOT_FLAGS && tuple5;                      // the lean streaming instantiations
+  const bool policy_a = !std30 && !(flags & ARCLE_STEP_FEATURE_FLAGS) && ingress != arcle::INGRESS_MASK;  // other shapes: the run-time request
+  LaunchPlan pl;
+  if (e->forced) {  // (arcle_autotune timing a candidate)
+    pl = *e->forced;
+  } else if (e->tuned_valid && e->tuned_ingress == ingress && e->tuned_flags == flags) {
+    pl = e->tuned;
+  } else {
+    pl.policy = stream_policy(e, p.n_envs);
+    pl.wpw = launch_wpw(e);
+    // ... and for a batch of at most one occupancy round whose launch has no front workgroups to carry (no records to prefetch): 5.40 -> 5.35 us
+    // at 8192 envs, 4.28 -> 4.25 at 4096; from 16384 envs on 8 waves are the better shape (profiles/round4_experiments.txt §9)
+    if (!e->wpw_override && pl.wpw == WAVES_PER_WG && p.n_envs <= 8192 && !e->pf_next) pl.wpw = 4;
+    // self-ordering launches inside the window they were measured to win in with a cache-resident action stream (profiles/round5_experiments.txt)
+    pl.grouped = p.n_envs >= e->group_min && p.n_envs <= e->group_max;
+    if (pl.grouped && can_group && !e->wpw_override) pl.wpw = e->group_wpw;
+  }
+  if (!can_group) pl.grouped = 0;
+  if (pl.grouped) pl.policy = 0;
+  else if (!(any_policy || (policy_a && pl.policy == 'A'))) pl.policy = 0;
+  if (e->pf_next && pl.wpw != WAVES_PER_WG) pl.wpw = WAVES_PER_WG;  // (the record-prefetching launch is written for 8-wave workgroups)
+  return pl;
+}
+
 static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t* op, int32_t* reward, uint8_t* term,
                        uint32_t flags, void* stream) {
   if (!e || !sel || (!op && ingress != arcle::INGRESS_BBOX5) || !reward || !term) return ARCLE_ERR_ARG;
@@ -1136,9 +1061,19 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if (flags & ~0x3ffu) return fail(e, ARCLE_ERR_ARG, "unknown step flag");
   if ((flags & ARCLE_STEP_ROWS_INCREMENTAL) && !(flags & ARCLE_STEP_FLAT_OBS)) return fail(e, ARCLE_ERR_ARG, "ARCLE_STEP_ROWS_INCREMENTAL without ARCLE_STEP_FLAT_OBS");
   DeviceGuard guard(e->device);
-  // A step without ARCLE_STEP_DENSE on a handle that keeps dense pairs may move grids the cache still describes: drop the entries
-  // first (stream-ordered; handles that always step with the flag — ARCVecEnv(dense_reward) — never take this branch)
-  if (e->d_dense_cache && !(flags & ARCLE_STEP_DENSE)) HIP_TRY(e, hipMemsetAsync(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8, (hipStream_t)stream));
+  // A step without ARCLE_STEP_DENSE on a handle that keeps dense pairs may move grids the cache still describes: drop the entries first
+  // (stream-ordered; handles that always step with the flag never get here).  Only needed while the cache may hold pairs: a host flag,
+  // set by dense steps — and stuck at "always" once a dense step was captured into a hipGraph, whose replays fill the cache unseen.
+  if (e->d_dense_cache) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (flags & ARCLE_STEP_DENSE) {
+      e->dense_cache_live = capturing ? 2 : (e->dense_cache_live == 2 ? 2 : 1);
+    } else if (capturing || e->dense_cache_live) {
+      HIP_TRY(e, hipMemsetAsync(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8, (hipStream_t)stream));
+      if (!capturing && e->dense_cache_live == 1) e->dense_cache_live = 0;
+    }
+  }
   // env kinds without a `selected` plane (ARCEnv, RawARCEnv: no table of theirs can hold a reset_sel-wrapped op — arcle_set_op_table
   // rejects it): the zero-fill elision is vacuous there, so an auto-resetting step of such a handle takes the same lean instantiations
   // as the O2ARC batch (ARCVecEnv's flag set) instead of the runtime-flag kernel
@@ -1155,21 +1090,6 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.rmask = nullptr;
   p.next_sel = e->pf_next;
   p.stage_out = e->pf_stage;
-  p.order = e->ord_cur;
-  p.order_next = e->ord_next;
-  p.next_op = e->ord_next_op;
-  p.next_op_stride = e->ord_next_stride;
-  // Speculative grid request / store policy by batch size (StepParams::spec_grid: 0 none, else the policy letter):
-  const bool std30 = p.H == 30 && p.W == 30 && p.PS == ARCLE_MAX_CELLS;
-  const int policy = stream_policy(e, p.n_envs);
-  if (std30) p.spec_grid = (policy && flags == (uint32_t)HOT_FLAGS && (ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5)) ? policy : 0;
-  else p.spec_grid = (policy == 'A' && !(flags & ARCLE_STEP_FEATURE_FLAGS) && ingress != arcle::INGRESS_MASK) ? policy : 0;
-  int wpw = launch_wpw(e);
-  // ... and for a batch of at most one occupancy round whose launch has no front workgroups to carry (no dispatch order to read or
-  // write, no records to prefetch): 5.40 -> 5.35 us at 8192 envs, 4.28 -> 4.25 at 4096; from 16384 envs on 8 waves are the better shape
-  // (profiles/round4_experiments.txt §9)
-  if (!e->wpw_override && wpw == WAVES_PER_WG && p.n_envs <= 8192 && !e->ord_cur && !e->pf_next && !(!e->in_many && (e->hint_op || e->ord_have))) wpw = 4;
-  p.wpw = wpw;
   if (flags & ARCLE_STEP_FLAT_OBS) {
     if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
     p.flat_out = e->flat_out;
@@ -1181,47 +1101,17 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     if (!e->pack_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output");
     p.pack_out = e->pack_out;
   }
-  // A launch that orders itself (round 5): the standard 30 x 30 batch whose op table has object operations, stepped with one of the front-ends'
-  // flag sets; every dispatch slot must hold an env and an XCD's slot range must split into ARCLE_GROUP_SIZE strata.  With group_over_order
-  // (default) it also replaces the table form: hints are accepted and ignored, arcle_step_many launches plain self-ordering steps.
-  p.group_magic = 0;
-  if (grouped_applies(e, ingress, p) && !e->ord_cur && !e->pf_next && (e->group_over_order || !(!e->in_many && (e->hint_op || e->ord_have)))) {
-    p.group_magic = (uint32_t)(0x100000000ull / (uint64_t)(p.n_envs / (8 * ARCLE_GROUP_SIZE))) + 1u;  // (G = groups per XCD >= 2)
-    p.spec_grid = 0;
-    p.wpw = wpw = e->wpw_override ? e->wpw_override : e->group_wpw;
-    if (!e->in_many) e->hint_op = nullptr, e->ord_have = 0;
-  }
-  const dim3 g = grid_for(p.n_envs, wpw), b(64 * wpw);
+  // (a self-ordering launch reads the actions of 32 envs per wave: only from device memory, see on_device)
+  const bool dev_payload = grouped_applies(e, ingress, p) && on_device(sel) && (ingress == arcle::INGRESS_BBOX5 || on_device(op));
+  const LaunchPlan pl = plan_launch(e, ingress, p, dev_payload);
+  p.spec_grid = pl.policy;
+  p.wpw = pl.wpw;
+  p.group_magic = pl.grouped ? (uint32_t)(0x100000000ull / (uint64_t)(p.n_envs / (8 * ARCLE_GROUP_SIZE))) + 1u : 0u;  // (G = groups per XCD >= 2)
+  const dim3 g = grid_for(p.n_envs, pl.wpw), b(64 * pl.wpw);
   hipStream_t st = (hipStream_t)stream;
   const int fw = width_class(p);
   const bool acct = e->d_acct != nullptr;
   const bool feat = (flags & ARCLE_STEP_FEATURE_FLAGS) != 0;
-  // Ordered dispatch for single-step callers: arcle_hint_next_ops left the NEXT step's op indices (one-shot), and / or the previous
-  // hinted launch left the table for THIS step.  Scheduling only — whatever a table holds is a permutation of every XCD's env range.
-  bool hinted = false;
-  if (!p.group_magic && !e->in_many && (e->hint_op || e->ord_have)) {
-    const size_t n = (size_t)p.n_envs;
-    const uint32_t slots = g.x * (uint32_t)wpw;
-    bool ok = e->order_enabled && fw == arcle::FW_FULL && p.H == 30 && p.W == 30 && !acct && wpw == WAVES_PER_WG && (size_t)slots == n &&
-              slots / 8u <= ARCLE_ORD_MAX_SLOTS && ordered_instantiation(ingress, p);
-    if (ok && !e->d_order) {  // (allocated by the first such call outside a stream capture, or by arcle_set_dispatch_order(env, 1))
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        ok = false;
-      } else {
-        ok = ensure_order_tables(e);
-      }
-    }
-    if (ok) {
-      p.order = e->ord_have ? e->d_order + (size_t)e->ord_parity * n : e->d_order + 2 * n;
-      p.order_next = e->hint_op ? e->d_order + (size_t)(e->ord_parity ^ 1) * n : nullptr;
-      p.next_op = e->hint_op;
-      p.next_op_stride = e->hint_stride;
-      p.spec_grid = 0;
-      hinted = true;
-    }
-  }
   int rc;
   switch (ingress) {
     case arcle::INGRESS_BBOX: rc = launch_step_ing<arcle::INGRESS_BBOX>(fw, acct, feat, g, b, st, p); break;
@@ -1231,19 +1121,129 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     case arcle::INGRESS_BITS: rc = launch_step_ing<arcle::INGRESS_BITS>(fw, acct, feat, g, b, st, p); break;
     default: return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
   }
-  if (!e->in_many) {  // the hint is consumed by this launch, sorted or not; the table it wrote (if any) serves the next step only
-    if (hinted && e->hint_op) {
-      e->ord_parity ^= 1;
-      e->ord_have = 1;
-    } else {
-      e->ord_have = 0;
-    }
-    e->hint_op = nullptr;
-  }
   if (rc != ARCLE_OK) return fail(e, rc, "this build of libarcle_hip has no kernel for the configuration");
   HIP_TRY(e, hipGetLastError());
   if (e->d_acct) e->acct_steps += (uint64_t)p.n_envs;
   return ARCLE_OK;
+}
+
+extern "C" int arcle_launch_info(arcle_env* e, int ingress, uint32_t flags, int32_t* out4) {
+  if (!e || !out4) return ARCLE_ERR_ARG;
+  if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  StepParams p = e->base;
+  p.flags = flags;
+  p.flat_stride = e->flat_stride;
+  p.flat_filter = e->flat_filtered ? 1 : 0;
+  p.flat_tail = e->flat_tail ? 1 : 0;
+  const LaunchPlan pl = plan_launch(e, ingress, p, true);
+  out4[0] = pl.grouped;
+  out4[1] = pl.policy;
+  out4[2] = pl.wpw;
+  out4[3] = (e->tuned_valid && e->tuned_ingress == ingress && e->tuned_flags == flags) ? 1 : 0;
+  return ARCLE_OK;
+}
+
+// Times the candidate launch plans of THIS handle — its batch size, this box, the caller's own action arrays where they live — and keeps the
+// fastest for later launches with the same ingress form and flags.  The env state is saved first and restored before every candidate and at
+// the end, so the call leaves the handle exactly as it found it (only stream order: no host synchronisation is left pending).
+extern "C" int arcle_autotune(arcle_env* e, int ingress, const void* sel, const int32_t* op, uint32_t flags, int32_t* report, int32_t report_rows,
+                              void* stream) {
+  if (!e || !sel || (!op && ingress != arcle::INGRESS_BBOX5)) return ARCLE_ERR_ARG;
+  if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  if (flags & ~(uint32_t)(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_PACK_OBS))
+    return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS only (other flags keep per-env side state it does not save)");
+  if (e->d_acct) return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: not with byte accounting enabled");
+  hipStream_t st = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: not inside a stream capture");
+  }
+  DeviceGuard guard(e->device);
+  const size_t n = (size_t)e->cfg.n_envs, pbytes = n * (size_t)e->base.PS;
+  // scratch: a copy of every plane, the records, the counters; outputs of the timed launches
+  int8_t* save_plane[ARCLE_N_PLANES] = {nullptr};
+  int8_t* save_rec = nullptr;
+  int32_t *save_cnt = nullptr, *t_reward = nullptr;
+  uint8_t* t_term = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ok = hipMalloc((void**)&save_rec, n * ARCLE_REC_BYTES) == hipSuccess && hipMalloc((void**)&save_cnt, n * 8) == hipSuccess &&
+            hipMalloc((void**)&t_reward, n * 4) == hipSuccess && hipMalloc((void**)&t_term, n) == hipSuccess &&
+            hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess;
+  for (int i = 0; ok && i < ARCLE_N_PLANES; i++)
+    if (e->bufs.plane[i]) ok = hipMalloc((void**)&save_plane[i], pbytes) == hipSuccess;
+  auto copy_state = [&](bool save) -> bool {
+    bool r = true;
+    for (int i = 0; r && i < ARCLE_N_PLANES; i++)
+      if (e->bufs.plane[i])
+        r = hipMemcpyAsync(save ? save_plane[i] : e->bufs.plane[i], save ? e->bufs.plane[i] : save_plane[i], pbytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    r = r && hipMemcpyAsync(save ? save_rec : e->bufs.rec, save ? e->bufs.rec : save_rec, n * ARCLE_REC_BYTES, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    r = r && hipMemcpyAsync(save ? (void*)save_cnt : (void*)e->bufs.cnt, save ? (void*)e->bufs.cnt : (void*)save_cnt, n * 8, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    return r;
+  };
+  int rc = ARCLE_OK;
+  LaunchPlan best = {0, WAVES_PER_WG, 0};
+  float best_ms = -1.f;
+  int rows = 0;
+  if (ok) ok = copy_state(true);
+  if (ok) {
+    e->tuned_valid = 0;
+    const int policies[] = {0, 'A', 'B', 'H', 'J'};
+    for (int grouped = 0; grouped <= 1 && rc == ARCLE_OK; grouped++)
+      for (int pi = 0; pi < (grouped ? 1 : 5) && rc == ARCLE_OK; pi++)
+        for (int wpw = 4; wpw <= 8 && rc == ARCLE_OK; wpw += 4) {
+          LaunchPlan cand = {policies[pi], wpw, grouped};
+          // does the candidate survive planning unchanged?  (a policy / the grouping the launch cannot take is not a candidate)
+          StepParams probe = e->base;
+          probe.flags = flags;
+          e->forced = &cand;
+          const bool dev_payload = on_device(sel) && (ingress == arcle::INGRESS_BBOX5 || on_device(op));
+          const LaunchPlan got = plan_launch(e, ingress, probe, dev_payload);
+          if (got.policy == cand.policy && got.wpw == cand.wpw && got.grouped == cand.grouped) {
+            float ms = 0.f;
+            bool r = copy_state(false);
+            for (int it = 0; r && it < 3 + 10; it++) {
+              if (it == 3) r = hipEventRecord(ev0, st) == hipSuccess;
+              if (r) rc = launch_step(e, ingress, sel, op, t_reward, (uint8_t*)t_term, flags, stream);
+              r = r && rc == ARCLE_OK;
+            }
+            r = r && hipEventRecord(ev1, st) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess;
+            if (!r && rc == ARCLE_OK) rc = ARCLE_ERR_HIP;
+            if (r) {
+              if (best_ms < 0.f || ms < best_ms) best_ms = ms, best = cand;
+              if (report && rows < report_rows) {
+                report[4 * rows + 0] = cand.grouped, report[4 * rows + 1] = cand.policy, report[4 * rows + 2] = cand.wpw;
+                report[4 * rows + 3] = (int32_t)(ms * 1e5f);  // ns per launch (10 launches)
+                rows++;
+              }
+            }
+          }
+          e->forced = nullptr;
+        }
+    if (!copy_state(false) || hipStreamSynchronize(st) != hipSuccess) rc = rc == ARCLE_OK ? ARCLE_ERR_HIP : rc;
+  } else {
+    rc = ARCLE_ERR_HIP;
+  }
+  for (int i = 0; i < ARCLE_N_PLANES; i++)
+    if (save_plane[i]) (void)hipFree(save_plane[i]);
+  if (save_rec) (void)hipFree(save_rec);
+  if (save_cnt) (void)hipFree(save_cnt);
+  if (t_reward) (void)hipFree(t_reward);
+  if (t_term) (void)hipFree(t_term);
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
+  if (rc != ARCLE_OK) {
+    (void)hipGetLastError();
+    if (rc == ARCLE_ERR_HIP) snprintf(e->err, sizeof(e->err), "arcle_autotune: a HIP call failed (out of memory for the state copy?)");
+    return rc;
+  }
+  if (best_ms >= 0.f) {
+    e->tuned = best;
+    e->tuned_ingress = ingress;
+    e->tuned_flags = flags;
+    e->tuned_valid = 1;
+  }
+  return rows;
 }
 
 extern "C" int arcle_step_mask(arcle_env* e, const int8_t* sel, const int32_t* op, int32_t* reward, uint8_t* term,
@@ -1278,34 +1278,12 @@ static size_t payload_bytes(const arcle_env* e, int ingress) {
   }
 }
 
-// the three dispatch-order tables of arcle_step_many (two alternating by step parity + the identity step 0 runs with)
-static bool ensure_order_tables(arcle_env* e) {
-  if (e->d_order) return true;
-  DeviceGuard guard(e->device);
-  const size_t n = (size_t)e->cfg.n_envs;
-  uint32_t* ident = new (std::nothrow) uint32_t[n];
-  bool ok = ident && hipMalloc((void**)&e->d_order, 3 * n * sizeof(uint32_t)) == hipSuccess;
-  if (ok) {
-    for (size_t i = 0; i < n; i++) ident[i] = (uint32_t)i;
-    // (all three start as the identity: whatever a launch finds in a table — also one nobody wrote for THIS step — is a permutation)
-    for (int k = 0; k < 3 && ok; k++) ok = hipMemcpy(e->d_order + (size_t)k * n, ident, n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) (void)hipFree(e->d_order);
-  }
-  if (!ok) {
-    (void)hipGetLastError();
-    e->d_order = nullptr;
-  }
-  delete[] ident;
-  return ok;
-}
-
 extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
                                uint8_t* term, uint32_t flags, void* stream) {
   if (!e) return ARCLE_ERR_ARG;
   if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
-  if (n_steps == 1)  // one step is a single-step call (a pending arcle_hint_next_ops applies to it)
-    return launch_step(e, ingress, sel, op, reward, term, flags, stream);
+  if (n_steps == 1) return launch_step(e, ingress, sel, op, reward, term, flags, stream);
   const size_t n = (size_t)e->cfg.n_envs, pb = payload_bytes(e, ingress);
   // Host-resident 5-tuple records (a policy on the CPU): step t reads its records from a device staging buffer that the FRONT
   // workgroups of launch t-1 filled from pinned host memory while that launch ran; only step 0 reads across PCIe itself.
@@ -1333,80 +1311,36 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
       }
     }
   }
-  // Ordered dispatch (device-resident bbox + op arrays or 5-tuple records, the lean 30 x 30 instantiation): launch t's front workgroups
-  // sort step t+1's slots — object operations first — from that step's op array; see order_next_step.
-  const uint32_t slots = grid_for((int)n, WAVES_PER_WG).x * (uint32_t)WAVES_PER_WG;
-  StepParams probe = e->base;  // (the flag sets that have an ordered instantiation: ARCVecEnv's, + the packed row, + the research step)
-  probe.flags = flags;
-  probe.flat_filter = e->flat_filtered ? 1 : 0;
-  probe.flat_tail = e->flat_tail ? 1 : 0;
-  probe.flat_stride = e->flat_stride;
-  const bool ord_kernel = width_class(e->base) == arcle::FW_FULL && e->base.H == 30 && e->base.W == 30 && !e->d_acct && launch_wpw(e) == WAVES_PER_WG &&
-                          ordered_instantiation(ingress, probe);
-  const bool grouped = e->group_over_order && !prefetch && grouped_applies(e, ingress, probe);  // (the launches order themselves: no tables)
-  bool ordered = e->order_enabled && ord_kernel && !grouped && !prefetch && n_steps > 1 && sel && (size_t)slots == n && slots / 8u <= ARCLE_ORD_MAX_SLOTS &&
-                 (((ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_POINT) && op) || ingress == arcle::INGRESS_BBOX5);
-  if (ordered && ingress == arcle::INGRESS_BBOX5) {  // (host-resident records take the prefetch path above, or none)
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, sel) != hipSuccess || attr.type != hipMemoryTypeDevice) ordered = false;
-    (void)hipGetLastError();
-  }
-  if (ordered && !e->d_order) {  // (allocated like the staging buffer: by the first call outside a stream capture, or by arcle_set_dispatch_order)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      ordered = false;
-    } else if (!ensure_order_tables(e)) {
-      ordered = false;
-    }
-  }
+  // (device-resident payloads need nothing here: the launches of the standard batch order themselves, see launch_step)
   int rc = ARCLE_OK;
-  e->in_many = 1;
-  e->hint_op = nullptr;  // (a pending single-step hint does not survive a multi-step call: the tables are this call's now)
-  e->ord_have = 0;
   for (int32_t t = 0; t < n_steps && rc == ARCLE_OK; t++) {
-    if (ordered) {
-      e->ord_cur = t == 0 ? e->d_order + 2 * n : e->d_order + (size_t)(t & 1) * n;  // (step 0: the identity; nobody looked ahead for it)
-      e->ord_next = t + 1 < n_steps ? e->d_order + (size_t)((t + 1) & 1) * n : nullptr;
-      if (ingress == arcle::INGRESS_BBOX5) {
-        e->ord_next_op = (const int32_t*)((const char*)sel + (size_t)(t + 1) * pb) + 4;
-        e->ord_next_stride = 5;
-      } else {
-        e->ord_next_op = op + (size_t)(t + 1) * n;
-        e->ord_next_stride = 1;
-      }
-    }
     const void* src = (const char*)sel + (size_t)t * pb;
     if (prefetch) {
       if (t > 0) src = e->d_stage + (size_t)(t & 1) * n * 5;
       e->pf_next = t + 1 < n_steps ? (const int32_t*)((const char*)sel + (size_t)(t + 1) * pb) : nullptr;
       e->pf_stage = e->d_stage + (size_t)((t + 1) & 1) * n * 5;
+      e->pf_active = 1;
     }
     rc = launch_step(e, ingress, src, op ? op + (size_t)t * n : nullptr, reward ? reward + (size_t)t * n : nullptr,
                      term ? term + (size_t)t * n : nullptr, flags, stream);
   }
   e->pf_next = nullptr;
   e->pf_stage = nullptr;
-  e->ord_cur = nullptr;
-  e->ord_next = nullptr;
-  e->ord_next_op = nullptr;
-  e->in_many = 0;
+  e->pf_active = 0;
   return rc;
 }
 
+// Since ABI 5 a launch orders ITSELF from the operations it is about to execute (see arcle_step_kernel): nobody has to know the next step's
+// operations, so the round-4 hint has nothing left to do.  Kept, validated and ignored, for callers written against ABI 4.
 extern "C" int arcle_hint_next_ops(arcle_env* e, const int32_t* next_op, int32_t stride) {
   if (!e) return ARCLE_ERR_ARG;
   if (next_op && stride <= 0) return fail(e, ARCLE_ERR_ARG, "arcle_hint_next_ops: stride must be positive (1 for op arrays, 5 for BBoxWrapper records)");
-  e->hint_op = next_op;
-  e->hint_stride = stride;
   return ARCLE_OK;
 }
 
 extern "C" int arcle_set_dispatch_order(arcle_env* e, int enable) {
   if (!e) return ARCLE_ERR_ARG;
   e->order_enabled = enable ? 1 : 0;
-  // (enabling allocates the tables now: a later arcle_step_many inside a stream capture cannot)
-  if (enable && !ensure_order_tables(e)) return fail(e, ARCLE_ERR_HIP, "could not allocate the dispatch-order tables");
   return ARCLE_OK;
 }
 
@@ -1767,17 +1701,6 @@ extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
     HIP_TRY(e, hipFree(e->d_acct));
     e->d_acct = nullptr;
   }
-  return ARCLE_OK;
-}
-
-// (test hook, declared in include/arcle_hip.h's last section: the dispatch-order tables arcle_step_many last wrote — [0], [1] alternate
-// by step parity, [2] is the identity — so that tests can check them against the op arrays)
-extern "C" int arcle_debug_copy_order(arcle_env* e, uint32_t* host_out) {
-  if (!e || !host_out) return ARCLE_ERR_ARG;
-  if (!e->d_order) return fail(e, ARCLE_ERR_CONFIG, "no dispatch-order tables (no ordered arcle_step_many call yet)");
-  DeviceGuard guard(e->device);
-  HIP_TRY(e, hipDeviceSynchronize());
-  HIP_TRY(e, hipMemcpy(host_out, e->d_order, 3 * (size_t)e->cfg.n_envs * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return ARCLE_OK;
 }
 

@@ -45,8 +45,7 @@ enum { INGRESS_MASK = 0,    // int8 [N][P] selection masks as given (action['sel
 #define ARCLE_BITS_STRIDE (ARCLE_MAX_CELLS / 8)
 // launcher-internal bit of a compile-time flag set (FL template parameter): the fused flat rows are the FilterO2ARC subset
 #define ARCLE_STEPX_FLAT_FILTERED 0x10000
-// ... and that its waves take their env from a dispatch-order table (arcle_step_many: longest operations first, see the kernel)
-#define ARCLE_STEPX_ORDERED 0x20000
+// (0x20000: the round-3/4 table form of ordered dispatch, retired in round 5)
 // ... the grid plane is requested speculatively beside the per-env scalar loads — one memory round trip per wave instead of two dependent
 // ones.  Pays where a launch is made of memory latency: the streaming regime (state beyond the 256 MiB Infinity Cache, 16+ occupancy rounds
 // of waves that each wait on HBM) and batches of at most a wave or two per SIMD (the launch IS one wave's latency chain); at 8192 envs —
@@ -119,11 +118,7 @@ struct StepParams {
   int32_t* dense_cache;    // library-owned int32 [N][2]: the dense pair of the env's CURRENT grid, (0, 0) = unknown (see step_core)
   const int32_t* next_sel; // INGRESS_BBOX5_PF: the NEXT step's records (pinned host memory, int32 [N][5]) ...
   int32_t* stage_out;      // ... and the device staging buffer the front workgroups copy them into while this step runs
-  // ---- ordered dispatch (ARCLE_STEPX_ORDERED instantiations, arcle_step_many) ----
-  const uint32_t* order;   // uint32 [N]: the env the wave in dispatch slot s steps (a permutation inside every XCD's slot range)
-  uint32_t* order_next;    // table the launch's front workgroups fill for the NEXT step (NULL: last step)
-  const int32_t* next_op;  // the next step's op indices: element s at next_op[s * next_op_stride]
-  int32_t next_op_stride;  // 1 (op arrays) / 5 (the op field of BBoxWrapper records)
+  // ---- dispatch order (ARCLE_STEPX_GROUPED instantiations: launches that order themselves) ----
   uint64_t long_mask;      // bit i: op table slot i is an object operation (Move / Rotate / Flip: the longest-running waves)
   uint32_t group_magic;    // != 0: the launch orders itself (ARCLE_STEPX_GROUPED instantiations): floor(2^32 / (n_envs / 128)) + 1
   int32_t spec_grid;       // 1: the launch's lean twin loads the grid plane speculatively (ARCLE_STEPX_STREAM); the accounting instantiation

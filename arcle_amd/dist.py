@@ -149,13 +149,11 @@ class ShardedVecEnv:
         return out
 
     def step_bbox(self, bbox, op, group=0, next_operation=None):
-        """next_operation: this rank's slice of the FOLLOWING step's operations, when known (ordered dispatch, see ARCVecEnv.step_bbox)."""
-        kw = {} if next_operation is None else {"next_operation": next_operation}
-        return self._step("step_bbox", group, bbox, op, **kw)
+        """(next_operation: round 4's hint, accepted and ignored — launches order themselves, see ARCVecEnv.step_bbox)"""
+        return self._step("step_bbox", group, bbox, op)
 
     def step_point(self, xy, op, group=0, next_operation=None):
-        kw = {} if next_operation is None else {"next_operation": next_operation}
-        return self._step("step_point", group, xy, op, **kw)
+        return self._step("step_point", group, xy, op)
 
     def step(self, action, group=0):
         return self._step("step", group, action)
@@ -249,15 +247,12 @@ class ShardedVecEnv:
         packed = torch.zeros((K, nm, R), dtype=torch.uint8, device=self.device)
         full = torch.zeros((K, self.world * nm, R), dtype=torch.uint8, device=self.device) if self._collective else None
         reward, term, trunc, dense = env._many_buffers(K)
-        b.prepare_dispatch_order()  # (the dispatch-order tables cannot be allocated inside the capture)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
             for i in range(K):
                 b.set_packed_output(packed[i][:grp.n])
-                if i + 1 < K and form in ("bbox", "point", "bbox5"):  # (step i sorts step i+1's dispatch slots while it runs)
-                    b.hint_next_ops(payload[i + 1] if form == "bbox5" else operation[i + 1])
                 env._enqueue_steps(form, payload[i:i + 1], None if operation is None else operation[i:i + 1], reward[i:i + 1],
                                    term[i:i + 1], None if trunc is None else trunc[i:i + 1], None if dense is None else dense[i:i + 1])
                 if self._collective:

@@ -323,35 +323,37 @@ class EnvBatch:
         return reward, term
 
     def set_dispatch_order(self, enable=True):
-        """arcle_step_many's ordered dispatch (object operations handed to the waves that start first; scheduling only) on / off."""
+        """Dispatch order on / off for this handle (arcle_set_dispatch_order).  On (default): launches of the standard 30 x 30 batch
+        hand the object operations (Move / Rotate / Flip, the longest waves) to the waves that start first — every launch derives that
+        from the operations it is about to execute, inside groups of 32 envs; scheduling only, results never depend on it."""
         self._check(self.L.arcle_set_dispatch_order(self._h, 1 if enable else 0), "arcle_set_dispatch_order")
-        self._order_enabled = bool(enable)
+
+    def launch_info(self, form, flags):
+        """The plan a step launch with this ingress form and these flags takes (arcle_launch_info): dict(orders_itself, policy ('' or the
+        letter A / B / H / J), waves_per_workgroup, autotuned)."""
+        import numpy as np
+        out = np.zeros(4, np.int32)
+        self._check(self.L.arcle_launch_info(self._h, _lib.INGRESS[form], int(flags), out.ctypes.data), "arcle_launch_info")
+        return {"orders_itself": bool(out[0]), "policy": chr(out[1]) if out[1] else "", "waves_per_workgroup": int(out[2]), "autotuned": bool(out[3])}
+
+    def orders_itself(self, form, flags):
+        return self.launch_info(form, flags)["orders_itself"]
+
+    def autotune(self, form, payload, op, flags):
+        """Times every launch plan this handle can take on the caller's own action tensors (arcle_autotune: state saved and restored, stream
+        synchronised) and keeps the fastest for later (form, flags) launches.  Returns the candidates as a list of dicts sorted by time."""
+        import numpy as np
+        rep = np.zeros((16, 4), np.int32)
+        rc = self.L.arcle_autotune(self._h, _lib.INGRESS[form], _ptr(payload), _ptr(op), int(flags), rep.ctypes.data, 16, self._stream())
+        if rc < 0:
+            self._check(rc, "arcle_autotune")
+        rows = [{"orders_itself": bool(r[0]), "policy": chr(r[1]) if r[1] else "", "waves_per_workgroup": int(r[2]), "us_per_launch": r[3] / 1e3} for r in rep[:rc]]
+        return sorted(rows, key=lambda r: r["us_per_launch"])
 
     def hint_next_ops(self, next_op, stride=1):
-        """One-shot hint for single-step callers (arcle_hint_next_ops): `next_op` = the operations of the step AFTER the next step_*
-        call — an int32 [N] device tensor (stride 1), an int32 [N, 5] record tensor (its op column is used, stride 5), or a raw device
-        address with `stride`.  The next step launch then sorts the following launch's dispatch slots (object operations first) while
-        it runs; scheduling only, results never depend on it.  None withdraws a pending hint."""
-        if next_op is None:
-            ptr, stride = 0, 1
-        elif isinstance(next_op, int):
-            ptr = next_op
-        else:
-            assert next_op.dtype == torch.int32 and next_op.is_contiguous() and next_op.shape[0] == self.N
-            if next_op.dim() == 2:
-                assert next_op.shape[1] == 5, "records are int32 [N, 5] = (x1, y1, x2, y2, operation)"
-                ptr, stride = next_op.data_ptr() + 16, 5
-            else:
-                ptr = next_op.data_ptr()
-        rc = self.L.arcle_hint_next_ops(self._h, ptr, int(stride))
-        if rc != 0:
-            self._check(rc, "arcle_hint_next_ops")
-
-    def prepare_dispatch_order(self):
-        """Before capturing step_many into a hipGraph: allocate the dispatch-order tables (a capture cannot) — but only if ordered
-        dispatch is on; a caller's set_dispatch_order(False) stays in force."""
-        if getattr(self, "_order_enabled", True):
-            self.set_dispatch_order(True)
+        """ABI 4's one-shot hint of the NEXT step's operations.  Launches order themselves since ABI 5, so this does nothing; kept so
+        that callers written against it keep running."""
+        return None
 
     def step_bbox_ptr(self, bbox_ptr, op_ptr, flags=0, stream=0):
         """Lowest-overhead launch for rollout loops: raw device addresses (ints) of an int32 [N,4] bbox array

@@ -398,12 +398,9 @@ class ARCVecEnv:
         return packed
 
     def step_bbox(self, bbox, operation, next_operation=None):
-        """next_operation: int32 [N] device tensor, the operations of the FOLLOWING step when the caller already knows them (action
-        chunks, scripted policies, an actor one step behind its learner): this launch then sorts the next launch's dispatch slots —
-        object operations to the waves that start first — exactly as `step_many` / `capture` do between their own launches.
-        Scheduling only: results never depend on it."""
-        if next_operation is not None:
-            self.batch.hint_next_ops(next_operation)
+        """bbox int32 [N, 4], operation int32 [N] (device).  next_operation: round 4's hint of the FOLLOWING step's operations — launches
+        order themselves since round 5 (the object operations go to the waves that start first, derived from THIS step's operations), so
+        it is accepted and ignored."""
 
         def action_of(n):  # BBoxWrapper.action (bbox.py:22-30) for one env, only needed by host-applied ops
             x1, y1, x2, y2 = (int(v) for v in bbox[n].tolist())
@@ -413,10 +410,7 @@ class ARCVecEnv:
         skip = self._host_skip()
         return self._ret(*self.batch.step_bbox(bbox, operation, self.flags), operation, action_of, skip)
 
-    def step_point(self, xy, operation, next_operation=None):
-        if next_operation is not None:
-            self.batch.hint_next_ops(next_operation)
-
+    def step_point(self, xy, operation, next_operation=None):  # (next_operation: accepted and ignored, see step_bbox)
         def action_of(n):
             sel = np.zeros((self.H, self.W), np.int8)
             sel[int(xy[n, 0]), int(xy[n, 1])] = 1
@@ -432,12 +426,10 @@ class ARCVecEnv:
 
     def step_bbox5(self, act5, next_act5=None):
         """The BBoxWrapper action as it is sampled (examples/example_bbox.py:13-15): int32 [N, 5] = (x1, y1, x2, y2, operation), ONE
-        array (device, or pinned host memory — the kernel then reads it across PCIe, no copy in front of the step).  next_act5: the
-        FOLLOWING step's records, when known (device tensor; see step_bbox's next_operation)."""
+        array (device, or pinned host memory — the kernel then reads it across PCIe, no copy in front of the step).  next_act5: accepted
+        and ignored (see step_bbox's next_operation)."""
         if self._host_slots:
             return self.step_bbox(act5[:, :4].contiguous(), act5[:, 4].contiguous())
-        if next_act5 is not None:
-            self.batch.hint_next_ops(next_act5)
         return self._ret(*self.batch.step_bbox5(act5, self.flags))
 
     def step_bits(self, bits, operation):
@@ -479,8 +471,6 @@ class ARCVecEnv:
         st = b._stream()
         for i in range(K):
             self._redirect(i, trunc, dense)
-            if i + 1 < K and form in ("bbox", "point", "bbox5"):  # the library sorts step i+1's dispatch slots while step i runs
-                b.hint_next_ops(payload[i + 1] if form == "bbox5" else operation[i + 1])
             if form == "bbox5":
                 rc = b.L.arcle_step_bbox5(b._h, payload[i].data_ptr(), reward[i].data_ptr(), term[i].data_ptr(), self.flags, st)
             else:
@@ -530,7 +520,6 @@ class ARCVecEnv:
         self._check_many(form, payload, operation)
         K = int(payload.shape[0])
         reward, term, trunc, dense = self._many_buffers(K)
-        self.batch.prepare_dispatch_order()  # (allocates the dispatch-order tables now — inside the capture the library cannot — unless the caller turned ordered dispatch off)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         g = torch.cuda.CUDAGraph()

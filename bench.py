@@ -10,12 +10,13 @@ A "step" is ONE pass of the hot path over one batch: a single launch of the step
 operation) action to every env of this GPU.  Tasks, state and the whole action stream are resident in HBM before the
 timed region starts.  HEADLINE (`value`, `ms_per_step`, `roofline`) = the step()-per-call form: a region's K launches are K
 `arcle_step_bbox` calls, none of which sees the next step's actions (the loop a(t+1) = policy(obs(t)) of the reference's
-examples/example_bbox.py:13-15).  c3 times beside it — same run, same event clock, top-level `ordered` block — the same K launches
-enqueued by ONE `arcle_step_many` call (what `ARCVecEnv.capture` records): the library then knows the next step's op array while a
-step runs, and every launch's eight front workgroups sort the next launch's dispatch slots — Move / Rotate / Flip to the waves that
-start first — which shortens the launch's tail (scheduling only: the same K launches with the same results; `--no-ordered` skips that
+examples/example_bbox.py:13-15).  Since round 5 every such launch orders ITSELF (object operations to the waves that start first,
+derived inside groups of 32 envs from the operations the launch is about to execute; scheduling only).  c3 times beside the headline —
+same run, same event clock, top-level `forms` block — the same K launches enqueued by ONE `arcle_step_many` call (what
+`ARCVecEnv.capture` records) and the K single-step calls with the dispatch order switched off (the plain instantiation: every wave steps
+the env of its own slot) — the in-run A/B of the ordering (`--no-forms` skips that
 leg).  Envs are independent, so N GPUs = N shards, no data-path collective (weak scaling).
-OUTPUT: rank 0 prints ONE compact JSON line on stdout (< 3 KB, the LAST line; the contract fields + `ordered`, `roofline`,
+OUTPUT: rank 0 prints ONE compact JSON line on stdout (< 3 KB, the LAST line; the contract fields + `forms`, `roofline`,
 `cpu_baseline`, `sustained`, `legs_us_per_step`, `collective` for N > 1); the full record (every leg with its own roofline block,
 per-region times) goes to stderr as one `BENCH_FULL {...}` line and to gpurun_out/bench_full_<config>_n<N>_k<K>.json.
 Workloads (`config.workload` names the one that ran):
@@ -42,7 +43,7 @@ batches on an evolving state.)  Besides the contract fields the line carries
                 (ARCVecEnv: Python loop / step_many / capture + replay), research_env (the paper's training step, rows rewritten in
                 full / incrementally), mask_ingress (int8 / bit-packed masks), host_actions (records of a host-resident policy:
                 zero-copy / one copy node / two), single_env (Gym class: step and transition latency), transition_rows (stateless
-                batched transition), rollout, batch_sweep (32 768 and 131 072 envs: the out-of-cache fraction), other_configs
+                batched transition), rollout, batch_sweep (32 768 / 65 536 / 131 072 envs: the out-of-cache fraction, library tables vs arcle_autotune), other_configs
                 (c2 / c4 on one rank / c5 with their real bounds);
   cpu_baseline  (N=1) on this box's host, bounded samples of the same workload: the oracle's C restatement (1 thread /
                 ALL host cores) and `numpy_step` = a plain-NumPy one-env-at-a-time step() loop with the reference's call
@@ -366,17 +367,16 @@ def emit(out, a):
     c["timing"] = {"regions": t["regions"], "stat": "median region, max over ranks", "clock": "hip_events" if t["clock"].startswith("HIP") else "host",
                    "launch": "hipGraph of K arcle_step_bbox calls" if t["launch"] != "eager" else "eager",
                    "host_region_ms_median": _r(float(np.median(t["host_region_ms"])))}
-    if out.get("ordered"):
-        o = out["ordered"]
-        c["ordered"] = {"value": _r(o["value"], 6), "ms_per_step": _r(o["ms_per_step"], 6), "avg_launch_us": _r(o["avg_launch_us"]),
-                        "frac": _r(o.get("frac")), "form": "one arcle_step_many call (ordered dispatch), same clock"}
-        if o.get("per_step_calls_hinted"):
-            c["ordered"]["per_step_calls_hinted_us"] = _r(o["per_step_calls_hinted"]["avg_launch_us"])
+    if out.get("forms"):
+        c["forms"] = {k: {"value": _r(v["value"], 6), "avg_launch_us": _r(v["avg_launch_us"]), "frac": _r(v.get("frac"))} for k, v in out["forms"].items()}
+        c["forms"]["note"] = "same run, same clock: one arcle_step_many call / single-step calls with arcle_set_dispatch_order(env, 0)"
     rl = out.get("roofline")
     if rl:
         c["roofline"] = {k: _r(rl[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_by_traffic", "kernel", "avg_launch_us",
                                                  "algorithmic_bytes_per_launch", "algorithmic_bytes_per_env_step") if k in rl}
         c["roofline"]["kernel"] = str(rl["kernel"])[:70]
+        if rl.get("plan"):
+            c["roofline"]["plan"] = rl["plan"]
         c["roofline"]["traffic_source"] = "kernel-counted issued bytes, this run"
         c["roofline"]["fits_infinity_cache"] = rl["note_cache"]["fits_infinity_cache"]
         if rl.get("pmc_crosscheck"):
@@ -384,8 +384,11 @@ def emit(out, a):
     ex = out.get("extras") or {}
     sweep = ex.get("batch_sweep")
     if isinstance(sweep, list) and rl:
+        def plan_str(pl):
+            return ("grouped" if pl["orders_itself"] else (pl["policy"] or "plain")) + f"/{pl['waves_per_workgroup']}w" + ("*" if pl["autotuned"] else "")
         c["roofline"]["frac_out_of_cache"] = {str(e["envs"]): {"frac": _r(e["roofline"]["frac"]), "frac_by_traffic": _r(e["roofline"]["frac_by_traffic"]),
-                                                              "us": _r(e["us_per_step_batch"])} for e in sweep}
+                                                              "us": _r(e["us_per_step_batch"]), "plan": plan_str(e["roofline"]["plan"]),
+                                                              "table_plan_us": _r(e["table_plan"]["us_per_step_batch"])} for e in sweep}
     if ex:
         def us(*path):
             d = ex
@@ -463,7 +466,7 @@ def counted_bytes(batch, enqueue, K, dev):
     return alg / K, issued / K, alg / max(steps, 1)
 
 
-def roofline_block(kernel, sec, alg, issued, n, PS=1024, planes=8, note=None):
+def roofline_block(kernel, sec, alg, issued, n, PS=1024, planes=8, note=None, plan=None):
     """The JSON block of one kernel: achieved = algorithmic bytes / launch duration against the 8 TB/s HBM3E peak; `traffic` = the
     bytes of the accesses the kernel itself counted as issued (kernel-counted, this run)."""
     state = planes * n * PS + 24 * n
@@ -479,6 +482,8 @@ def roofline_block(kernel, sec, alg, issued, n, PS=1024, planes=8, note=None):
                                      "HBM: frac is then a fabric-level figure; extras.batch_sweep holds the out-of-cache fractions"}}
     if note:
         blk["note"] = note
+    if plan is not None:  # how the launches ran: arcle_launch_info (self-ordering, cache policy of the speculative grid request, workgroup size)
+        blk["plan"] = plan
     return blk
 
 
@@ -603,16 +608,6 @@ def research_env_leg(dev, n, bbox, op, K=200):
         alg, issued, _ = counted_bytes(b, enqueue, K, dev)
         v._refresh_rows()  # (the byte count replayed the steps and restored the state: bring the mirrored rows back in line)
         sec, _ = graph_time(dev, enqueue, K)
-        if name == "rows_incremental":  # ... and with every step hinting the next step's operations (what ARCVecEnv.step_many / capture do)
-            b.set_dispatch_order(True)
-
-            def enqueue_hinted(sh, FL=FL):
-                for i in range(K):
-                    b.hint_next_ops(op[(i + 1) % K].data_ptr())
-                    b.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, sh)
-            sec_h, _ = graph_time(dev, enqueue_hinted, K)
-            v._refresh_rows()
-            out["rows_incremental_hinted_us"] = sec_h * 1e6
         out[name] = {"value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6,
                      "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 1, research flags, 30>", sec, alg, issued, n,
                                                 note="algorithmic = the step's planes + 56 B, + the dense reward's answer read when the grid moved, "
@@ -800,9 +795,10 @@ def transition_leg(dev, n, bbox, op, K=32):
                                  "writes the WHOLE 6314-byte state: it has no resident copy to leave untouched planes in)"}}
 
 
-def batch_sweep_leg(dev, bbox, op, sizes=(32768, 131072), K=24):
+def batch_sweep_leg(dev, bbox, op, sizes=(32768, 65536, 131072), K=24):
     """The headline kernel on batches whose state (8 planes x N x 1024 B) exceeds the 256 MiB Infinity Cache: the out-of-cache
-    HBM fraction, timed in this run."""
+    HBM fraction, timed in this run — with the launch plan of the library's tables, and after `arcle_autotune` picked the plan on this
+    handle, this box and these action arrays (the in-box A/B of the policy choice: `autotune.candidates` lists every plan it timed)."""
     out = []
     for N in sizes:
         rep = (N + bbox.shape[1] - 1) // bbox.shape[1]
@@ -815,9 +811,19 @@ def batch_sweep_leg(dev, bbox, op, sizes=(32768, 131072), K=24):
             for i in range(K):
                 batch.step_bbox_ptr(bb[i].data_ptr(), oo[i].data_ptr(), FL, sh)
         alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
-        sec, _ = graph_time(dev, enqueue, K, reps=7, warm=8)  # (1 GB of freshly allocated state: let TLBs and clocks settle)
-        out.append({"envs": N, "us_per_step_batch": sec * 1e6, "value": N / sec, "unit": "env-steps/s",
-                    "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, N)})
+        plan0 = batch.launch_info("bbox", FL)
+        sec0, _ = graph_time(dev, enqueue, K, reps=7, warm=8)  # (1 GB of freshly allocated state: let TLBs and clocks settle)
+        cands = batch.autotune("bbox", bb[0], oo[0], FL)
+        plan1 = batch.launch_info("bbox", FL)
+        sec1, _ = graph_time(dev, enqueue, K, reps=7, warm=4)
+        sec, plan = (sec1, plan1) if sec1 <= sec0 else (sec0, plan0)
+        leg = {"envs": N, "us_per_step_batch": sec * 1e6, "value": N / sec, "unit": "env-steps/s",
+               "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, N, plan=plan),
+               "table_plan": {"plan": plan0, "us_per_step_batch": sec0 * 1e6}, "autotuned_plan": {"plan": plan1, "us_per_step_batch": sec1 * 1e6},
+               "autotune": {"candidates": [f"{'grouped' if r['orders_itself'] else (r['policy'] or 'plain')}/{r['waves_per_workgroup']}w {r['us_per_launch']:.2f}us" for r in cands],
+                            "note": "arcle_autotune: 10 launches of one action batch per candidate on the saved state; the leg's own graph of "
+                                    "K distinct batches is then timed with the table's plan and with the tuned plan, the faster one is the leg's figure"}}
+        out.append(leg)
         del batch, bb, oo
         torch.cuda.empty_cache()
     return out
@@ -856,15 +862,11 @@ def other_configs_leg(dev, K=100):
         alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
         sec, _ = graph_time(dev, enqueue, K)
         leg = {"workload": cfg["name"], "envs": n, "us_per_step_batch": sec * 1e6, "value": n / sec, "unit": "env-steps/s"}
-        if name == "c4":  # the same single-step calls with the next step's ops hinted (ordered dispatch of the packed-row instantiation)
+        if name == "c4":  # the same single-step calls with the dispatch order off (the plain packed-row instantiation): the in-run A/B
+            batch.set_dispatch_order(False)
+            sec_p, _ = graph_time(dev, enqueue, K)
             batch.set_dispatch_order(True)
-
-            def enqueue_hinted(sh, batch=batch, bbd=bbd, ood=ood, FL=FL):
-                for i in range(K):
-                    batch.hint_next_ops(ood[(i + 1) % K].data_ptr())
-                    batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), FL, sh)
-            sec_h, _ = graph_time(dev, enqueue_hinted, K)
-            leg["hinted_us_per_step_batch"] = sec_h * 1e6
+            leg["dispatch_order_off_us_per_step_batch"] = sec_p * 1e6
         rl = roofline_block("arcle_step_kernel", sec, alg, issued, n, PS=batch.PS, planes=len(batch.planes))
         if name == "c2":
             rl.update({"bound": "launch-floor", "launch_floor_us": 2.5,
@@ -913,8 +915,8 @@ def main():
                     "through them; a small number keeps the action stream cache-resident — a policy that writes one batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-headline legs (kernel A/B runs)")
-    ap.add_argument("--no-ordered", action="store_true", help="skip the `ordered` leg (the region's K launches as ONE arcle_step_many call, "
-                    "whose launches sort the next step's dispatch slots, object operations first)")
+    ap.add_argument("--no-forms", "--no-ordered", dest="no_ordered", action="store_true", help="skip the `forms` leg (the region's K launches as ONE arcle_step_many call, "
+                    "and the K single-step calls with the dispatch order off)")
     ap.add_argument("--no-graph", action="store_true", help="launch the K steps of a region eagerly instead of as one hipGraph")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp launches (counter-collection runs)")
     a = ap.parse_args()
@@ -1048,12 +1050,11 @@ def main():
     # and replayed per region: a launch-bound inner loop belongs in a graph, and the host then issues one call per region instead
     # of K.  (With more than one rank c4 keeps eager launches when ranks share a GPU: its collective goes through the host.)
     # HEADLINE = the step()-per-call form: K arcle_step_bbox calls, none of which knows the next step's actions (the loop
-    # a(t+1) = policy(obs(t)) of examples/example_bbox.py:13-15).  c3 also times, beside it and with the same clock, the same K
-    # launches enqueued by ONE arcle_step_many call (what ARCVecEnv.capture records): the library then holds the next step's op
-    # array while a step runs and every launch's front workgroups sort the NEXT launch's dispatch slots — object operations to
-    # the waves that start first (scheduling only: same launches, same results) -> the top-level `ordered` block.
+    # a(t+1) = policy(obs(t)) of examples/example_bbox.py:13-15); every launch orders itself.  c3 also times, beside it
+    # and with the same clock, the same K launches enqueued by ONE arcle_step_many call (what ARCVecEnv.capture records) and the K
+    # single-step calls with the dispatch order off (the plain instantiation) -> the top-level `forms` block.
     graph = None
-    graph_ordered = graph_hinted = None
+    graph_many = graph_plain = None
     many = a.config == "c3" and gather is None and not a.no_ordered and K > 1
     many_out = (torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)) if many else None
     if not a.no_graph and not (gather is not None and shared_gpu):
@@ -1071,21 +1072,21 @@ def main():
             if gather is not None:
                 done[0] = done[1] = None
             if many:
-                batch.set_dispatch_order(True)  # (allocates the order tables: inside a capture the library cannot)
-                graph_ordered = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_ordered, stream=cap):
+                graph_many = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_many, stream=cap):
                     batch.step_many("bbox", bbox[Wm:Wm + K], op[Wm:Wm + K], FL, many_out[0], many_out[1])
-                # ... and the single-step calls again, each preceded by the one-shot hint arcle_hint_next_ops(next step's ops): what a
-                # caller of step() gets who knows its operations one step ahead (the last step hints the region's first: replays chain)
-                graph_hinted = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_hinted, stream=cap):
+                # ... and the single-step calls again with the dispatch order off (launch parameters are baked in at capture)
+                batch.set_dispatch_order(False)
+                graph_plain = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_plain, stream=cap):
                     cs = torch.cuda.current_stream(dev)
                     for i in range(Wm, Wm + K):
-                        batch.hint_next_ops(optr[(i + 1) % S if i + 1 < Wm + K else Wm % S])
                         step(i, cs.cuda_stream, cs)
+                batch.set_dispatch_order(True)
         except Exception as exc:  # capture unsupported: eager launches
             print(f"bench: hipGraph capture failed ({exc}); eager launches", file=sys.stderr)
-            graph = graph_ordered = graph_hinted = None
+            graph = graph_many = graph_plain = None
+            batch.set_dispatch_order(True)
             if gather is not None:
                 done[0] = done[1] = None
 
@@ -1146,17 +1147,14 @@ def main():
             wait_gpu(ev1)
             ts.append(ev0.elapsed_time(ev1) * 1e-3)
         return float(np.median(ts))
-    ordered = None
-    if graph_ordered is not None:  # the same K launches as ONE arcle_step_many call (ordered dispatch); same event clock, this rank
-        t_ord = time_graph(graph_ordered)
-        ordered = {"value": K * n * world / t_ord, "unit": "env-steps/s", "ms_per_step": t_ord / K * 1e3, "avg_launch_us": t_ord / K * 1e6,
-                   "kernel": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|ordered, 30>",
-                   "form": "ONE arcle_step_many call for the K steps (ARCVecEnv.capture): launch t sorts step t+1's dispatch slots, object ops first; "
-                           "scheduling only; timed on this rank with the same event clock, N x this for the node"}
-        if graph_hinted is not None:
-            t_h = time_graph(graph_hinted)
-            ordered["per_step_calls_hinted"] = {"value": K * n * world / t_h, "ms_per_step": t_h / K * 1e3, "avg_launch_us": t_h / K * 1e6,
-                                                "form": "K arcle_step_bbox calls, each preceded by arcle_hint_next_ops(next step's ops)"}
+    forms = None
+    if graph_many is not None:  # same event clock, this rank (N x this for the node)
+        forms = {}
+        for key, g_, what in (("step_many", graph_many, "ONE arcle_step_many call for the K steps (what ARCVecEnv.capture records)"),
+                              ("dispatch_order_off", graph_plain, "K arcle_step_bbox calls after arcle_set_dispatch_order(env, 0): the plain instantiation, "
+                                                                  "every wave steps the env of its own dispatch slot")):
+            t_ = time_graph(g_)
+            forms[key] = {"value": K * n * world / t_, "unit": "env-steps/s", "ms_per_step": t_ / K * 1e3, "avg_launch_us": t_ / K * 1e6, "form": what}
     wall_t = torch.tensor(devt if device_clock else wall, dtype=torch.float64)
     ranks_seen = world
     if dist is not None:  # max over ranks, per region
@@ -1166,7 +1164,11 @@ def main():
         one = torch.ones(1, dtype=torch.float64) if shared_gpu else torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(one)  # every rank of the group adds 1: what the collective itself saw
         ranks_seen = int(one.item())
-        print(f"bench: rank {rank}/{dist.get_world_size()} backend={dist.get_backend()} device={dev} ({torch.cuda.get_device_name(dev)}) "
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = "?"
+        print(f"bench: rank {rank}/{dist.get_world_size()} backend={dist.get_backend()} RCCL {rccl} device={dev} ({torch.cuda.get_device_name(dev)}) "
               f"envs [{rank * n}, {(rank + 1) * n}) median region {float(np.median(devt if device_clock else wall)) * 1e3:.4f} ms", file=sys.stderr, flush=True)
     elapsed = float(wall_t.median())
     kernel_avg_s = float(np.median(kern))
@@ -1186,9 +1188,11 @@ def main():
             for i in range(Wm, Wm + K):
                 batch.step_bbox_ptr(bptr[i % S], optr[i % S], FL, sh_)
         per_launch_bytes, issued_bytes, _ = counted_bytes(batch, replay_region0, K, dev)
-        kname = {"c3": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>",
-                 "c4": "arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|pack, 30> (fused packed-row epilogue; a multi-rank run has the all-gather inside the event pair)"}.get(a.config, "arcle_step_kernel")
+        grp = "|grouped" if batch.orders_itself("bbox", FL) else ""
+        kname = {"c3": f"arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide{grp}, 30>",
+                 "c4": f"arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|pack{grp}, 30> (fused packed-row epilogue; a multi-rank run has the all-gather inside the event pair)"}.get(a.config, "arcle_step_kernel")
         roofline = roofline_block(kname, kernel_avg_s, per_launch_bytes, issued_bytes, n, PS=batch.PS, planes=len(batch.planes),
+                                  plan=batch.launch_info("bbox", FL),
                                   note="algorithmic bytes follow SURVEY.md 8d and include the reset_sel zero-fills of `selected` that "
                                        "ARCLE_STEP_ELIDE_SELECTED never writes (about 14 % of the figure on this mix); `traffic` does not")
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -1200,8 +1204,8 @@ def main():
             roofline.update({"bound": "launch-floor", "launch_floor_us": 2.5})
         if a.config == "c5":
             roofline.update({"bound": "iteration (dependent flood-fill passes)"})
-        if ordered is not None:
-            ordered["frac"] = per_launch_bytes / (ordered["avg_launch_us"] * 1e-6) / HBM_PEAK
+        for f_ in (forms or {}).values():
+            f_["frac"] = per_launch_bytes / (f_["avg_launch_us"] * 1e-6) / HBM_PEAK
 
     if rank == 0:
         out = {
@@ -1215,13 +1219,13 @@ def main():
                        "parallelism": f"env-shard x{world} (no data-path collective)" if gather is None
                        else (f"env-shard x{world} + one packed all-gather per step ({'gloo, shared GPU' if shared_gpu else 'RCCL on a side stream, double-buffered rows, overlapping the next step'})"
                              if dist is not None else "one rank: step with the fused packed-row epilogue, nothing to gather")},
-            "headline_form": "per_step_calls: K arcle_step_* calls, one launch each, none sees the next step's actions",
+            "headline_form": "per_step_calls: K arcle_step_* calls, one launch each, none sees the next step's actions (every launch orders itself)",
             "timing": {"regions": R, "stat": "median region, max over ranks per region",
                        "clock": "HIP events on the launch stream, recorded between the region's two synchronisations" if device_clock else "host perf_counter between the region's two synchronisations",
                        "host_region_ms": [round(x * 1e3, 4) for x in wall][:12],
                        "launch": "hipGraph of the K step launches (K arcle_step_bbox calls), one replay per region" if graph is not None else "eager",
                        "region_ms": [round(float(x) * 1e3, 4) for x in wall_t.tolist()][:12]},
-            "ordered": ordered,
+            "forms": forms,
             "roofline": roofline,
         }
         if dist is not None:

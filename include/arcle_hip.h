@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ARCLE_ABI_VERSION 4
+#define ARCLE_ABI_VERSION 5
 #define ARCLE_MAX_OPS 64
 #define ARCLE_MAX_CELLS 1024 /* H*W <= 1024 (one 64-lane wavefront x 16 cells) */
 /* default per-env plane stride: H*W rounded up to a whole number of 128-byte lines (30x30 -> 1024 B), so that no two
@@ -219,7 +219,8 @@ int arcle_reset(arcle_env* env, const uint8_t* mask, void* stream);
 /* Device task table: n_tasks (input, answer) pairs, already zero-padded to the plane stride PS = H*W rounded up
  * (arcle_config.plane_stride): in_planes / ans_planes int8 [n_tasks][PS], in_dims / ans_dims int8 [n_tasks][2] (device pointers, owned
  * by the caller, must stay alive).  It is the packed form of what Loader.parse yields (loader.py:89-113), one entry
- * per (task, pair). */
+ * per (task, pair).  Alignment (ABI 5): the planes 16 bytes; the dims arrays 4 bytes, their allocation covering 2 * n_tasks rounded up
+ * to a multiple of 4 bytes (an entry's two dims are read with one aligned dword load) — misaligned arrays are rejected. */
 int arcle_set_task_table(arcle_env* env, const int8_t* in_planes, const int8_t* in_dims, const int8_t* ans_planes,
                          const int8_t* ans_dims, int32_t n_tasks);
 /* reset() with the task choice made by the caller (base.py:95-108): for every env with mask[env] != 0 (mask NULL =
@@ -266,29 +267,38 @@ int arcle_pack_mask_bits(arcle_env* env, const int8_t* sel, uint8_t* bits, void*
  * For the standard 30 x 30 batch stepped with ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED the library then pipelines the PCIe
  * traffic: eight extra workgroups at the front of launch t copy step t+1's records into a device staging buffer while launch t
  * runs, and step t+1 reads them from HBM (only step 0 reads across PCIe itself).  The staging buffer (2 x 20 B per env) is allocated
- * by the first such call made outside a stream capture.
- * Ordered dispatch: a launch of one wave per env ends with its last Move / Rotate / Flip wave (they run ~1.2 us longer than the other
- * operations' waves, and the hardware starts the waves of a launch over ~2 us).  With device-resident BBOX + op arrays or BBOX5
- * records, the same 30 x 30 batch and flags, n_envs a multiple of 64 and <= 8192, one extra workgroup per XCD at the front of
- * launch t reads step t+1's op indices and writes the order in which launch t+1 hands envs to its waves: object operations to the
- * waves that start first (a permutation inside every XCD's env range; 12 B per env of tables, allocated by the first such call
- * outside a stream capture).  The same holds for BBOX / BBOX5 with the fused packed row (ARCLE_STEP_PACK_OBS) or the research env's flag set
- * with incremental FilterO2ARC rows, and for POINT tuples.  It is scheduling only — results, outputs and their order in memory are exactly those of n_steps
- * arcle_step_* calls, and a caller that rewrites step t+1's actions while step t runs loses nothing but the ordering.
- * arcle_set_dispatch_order(env, 0) turns it off (default on); (env, 1) also allocates the tables at once — call it before capturing
- * arcle_step_many into a hipGraph on a handle that has not run an ordered arcle_step_many yet. */
-int arcle_set_dispatch_order(arcle_env* env, int enable);
-/* Ordered dispatch for callers that step ONE launch at a time (the Gym loop, examples/example_bbox.py:13-15) but know the next step's
- * operations a step ahead (action chunks, scripted / replayed policies, actors that run one step behind their learner): a ONE-SHOT
- * hint.  next_op: device int32, element s at next_op[s * stride] = the operation env s will receive in the step AFTER the next
- * arcle_step_* call (stride 1: an op array; 5: the op field of BBoxWrapper records, pass act5 + 4).  The next arcle_step_bbox / _bbox5 /
- * _point launch (the flag sets ARCVecEnv / ShardedVecEnv / the research env step with, 30 x 30, n_envs a multiple of 64 and <= 8192)
- * then carries the front workgroups that sort the following launch's dispatch slots, and that following launch hands out its envs in
- * that order — exactly what arcle_step_many does between its own launches.  Scheduling only: results do not depend on the hint, a
- * wrong or stale hint costs nothing but the ordering, an ineligible launch ignores it.  NULL withdraws a pending hint. */
-int arcle_hint_next_ops(arcle_env* env, const int32_t* next_op, int32_t stride);
+ * by the first such call made outside a stream capture. */
 int arcle_step_many(arcle_env* env, int ingress, int32_t n_steps, const void* sel, const int32_t* op, int32_t* reward,
                     uint8_t* term, uint32_t flags, void* stream);
+/* Dispatch order (ABI 5).  A launch of one wave per env ends with its last Move / Rotate / Flip wave (they run ~1.2 us longer than the
+ * other operations' waves, and the hardware starts the waves of a launch over ~2 us), so the library hands the object operations to
+ * the waves that start first.  Since ABI 5 every launch does that for ITSELF, from the operations it is about to execute: the standard
+ * 30 x 30 batch (plane stride 1024) stepped through arcle_step_bbox / _bbox5 / _point — and arcle_step_many over them — with the flag sets
+ * ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED, the same + ARCLE_STEP_PACK_OBS, or the research env's set with incremental
+ * FilterO2ARC rows; n_envs a multiple of 256 in [2304, 12288], actions in DEVICE memory, an op table with object operations, no byte
+ * accounting.  Waves of a group of 32 consecutive envs read the group's 32 actions and permute the group among their 32 dispatch slots
+ * (arcle_step_kernel, GROUPED).  Scheduling only: every env is stepped exactly once whatever the operations are; results, outputs and
+ * their layout are those of the plain launch.  No tables, no extra memory, nothing to allocate before a stream capture.
+ * arcle_set_dispatch_order(env, 0) turns it off for the handle (default on).
+ * arcle_hint_next_ops: ABI 4's one-shot hint of the NEXT step's operations (the table form of ordered dispatch needed them a step
+ * ahead).  Still accepted and validated — stride 1 for op arrays, 5 for the op field of BBoxWrapper records — and ignored. */
+int arcle_set_dispatch_order(arcle_env* env, int enable);
+int arcle_hint_next_ops(arcle_env* env, const int32_t* next_op, int32_t stride);
+/* How a step launch of this handle runs, chosen by batch size from tables measured on one MI355X with a cache-resident action stream:
+ * the cache policy of the speculative grid request (0 none; 'A' spec + write-through stores, small batches; 'B' + non-temporal stores,
+ * 'H' non-temporal request, 'J' both: state beyond the 256 MiB Infinity Cache), the workgroup size (4 or 8 waves), and whether the
+ * launch orders itself.  arcle_launch_info reports the plan a launch with (ingress, flags) and device-resident actions would take:
+ * out4 = {orders itself, policy (0 or the letter), waves per workgroup, 1 if arcle_autotune chose it}.
+ * arcle_autotune replaces the tables for THIS handle: it times every plan the launch can take — on this handle's batch size, this box and
+ * the caller's own action arrays where they live (sel / op as for arcle_step_*; ingress BBOX, BBOX5, POINT, MASK or BITS; flags within
+ * ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS) — 3 + 10 launches each, and keeps the fastest for later launches with the same
+ * ingress and flags.  The env state is saved first and restored before every candidate and at the end (a temporary copy of the state
+ * in device memory; reward / terminated of the timed launches go to scratch): the handle is left exactly as it was found.  Synchronises
+ * the stream; not inside a stream capture.  report (may be NULL): int32 [report_rows][4] = {orders itself, policy, waves per workgroup,
+ * ns per launch} per candidate timed.  Returns the number of candidates timed (>= 0) or a negative ARCLE_ERR_* code. */
+int arcle_launch_info(arcle_env* env, int ingress, uint32_t flags, int32_t* out4);
+int arcle_autotune(arcle_env* env, int ingress, const void* sel, const int32_t* op, uint32_t flags, int32_t* report, int32_t report_rows,
+                   void* stream);
 
 /* n_steps consecutive step()s of every env in ONE launch — a rollout / trace replay for callers that already hold
  * the whole action sequence (the loop `for a in trace: env.step(a)`, e.g. tests/o2arc_check.py:139-199 of the
@@ -415,13 +425,8 @@ int arcle_get_accounting_ex(arcle_env* env, uint64_t* bytes, uint64_t* issued, u
 const char* arcle_last_error(const arcle_env* env);
 int arcle_abi_version(void);
 
-/* ---- test hooks (stable, but not part of the drop-in surface) ---------------------------------------------------------------
- * The dispatch-order tables the last ordered arcle_step_many / hinted step wrote, copied to host_out uint32 [3][n_envs] after a
- * device synchronisation: [0] and [1] alternate by step parity, [2] is the identity.  Lets a test check that a table is a
- * permutation of every XCD's env range with the object operations in the lowest slots.  (Diagnostic builds compiled with
- * -DARCLE_TRACE_WAVES additionally export a per-wave timestamp dump used by tools/wavetrace.py; it does not exist in the shipped
- * library and is therefore not declared here.) */
-int arcle_debug_copy_order(arcle_env* env, uint32_t* host_out);
+/* (Diagnostic builds compiled with -DARCLE_TRACE_WAVES additionally export a per-wave timestamp dump used by tools/wavetrace.py; it does
+ * not exist in the shipped library and is therefore not declared here.) */
 
 #ifdef __cplusplus
 }

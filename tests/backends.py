@@ -141,8 +141,7 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("wpw", ctypes.c_int32), ("flat_tail", ctypes.c_int32), ("rows_in", ctypes.c_void_p),
                 ("rows_in_stride", ctypes.c_int32), ("n_resident", ctypes.c_int32), ("dense_cache", ctypes.c_void_p),
                 ("next_sel", ctypes.c_void_p), ("stage_out", ctypes.c_void_p),
-                ("order", ctypes.c_void_p), ("order_next", ctypes.c_void_p), ("next_op", ctypes.c_void_p),
-                ("next_op_stride", ctypes.c_int32), ("long_mask", ctypes.c_uint64), ("spec_grid", ctypes.c_int32)]
+                ("long_mask", ctypes.c_uint64), ("group_magic", ctypes.c_uint32), ("spec_grid", ctypes.c_int32)]
 
 
 _emu = None

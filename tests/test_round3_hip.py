@@ -581,12 +581,10 @@ def test_vec_transition_in_place_walks_trajectories():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [8192, 1024, 960])
 def test_step_many_ordered_dispatch_is_scheduling_only(n):
-    """arcle_step_many's ordered dispatch (launch t sorts step t+1's dispatch slots from that step's op array, object operations
-    first): rewards, terminated flags and every byte of state equal the unordered run — bbox + op arrays and 5-tuple records, eager
-    and replayed as a hipGraph with the action buffers rewritten in between, bad op indices included; the table itself is a
-    permutation of every XCD's env range with the object ops in the lowest slots.  (n = 960 is not a multiple of 64, n = 1024 runs
-    256-thread workgroups like every batch of at most 2048 envs: the library steps those unordered, silently.)"""
-    import ctypes
+    """arcle_step_many with the dispatch order on (since round 5 every launch orders itself inside groups of 32 envs) and off
+    (arcle_set_dispatch_order): rewards, terminated flags and every byte of state are equal — bbox + op arrays and 5-tuple records,
+    eager and replayed as a hipGraph with the action buffers rewritten in between, bad op indices included.  (n = 960 is not a multiple
+    of 256 and n = 1024 is below the window: the library steps those in plain env order, silently.)"""
     import torch
     import bench
     K = 30
@@ -608,19 +606,6 @@ def test_step_many_ordered_dispatch_is_scheduling_only(n):
         for k in a.planes:
             assert torch.equal(a.planes[k], b.planes[k]), (form, k)
         assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt) and a.status() == b.status() == 1, form  # (1 = ARCLE_ST_BAD_OP)
-        if n % 64 == 0 and n > 2048:  # the table launch K-2 wrote for step K-1 (batches of at most 2048 envs run 256-thread workgroups: unordered)
-            tab = np.zeros((3, n), np.uint32)
-            b.L.arcle_debug_copy_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-            assert b.L.arcle_debug_copy_order(b._h, tab.ctypes.data) == 0
-            t, rs = tab[(K - 1) & 1].astype(np.int64), n // 8
-            lg = (op_np[K - 1] >= 20) & (op_np[K - 1] < 28)
-            assert (tab[2] == np.arange(n)).all()
-            for x in range(8):
-                seg = t[x * rs:(x + 1) * rs]
-                assert sorted(seg.tolist()) == list(range(x * rs, (x + 1) * rs)), f"XCD {x}: not a permutation of its env range"
-                L = int(lg[x * rs:(x + 1) * rs].sum())
-                assert lg[seg[:L]].all() and not lg[seg[L:]].any(), f"XCD {x}: object ops are not in the first {L} slots"
-            assert (t != np.arange(n)).any()
         # replayed as a graph, with new actions written into the captured buffers between replays
         g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())

@@ -1,8 +1,8 @@
 """Round-4 GPU tests: the oracle meets exactly what bench.py times, at the sizes BASELINE.json names.
 
-  * the headline kernel `arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>` (K single-step calls) and the `ordered` leg's
-    `<..., autoreset|elide|ordered, 30>` (one arcle_step_many call), 8192 envs x 64 steps of bench.py's own task / action streams,
-    against the oracle stepping a sample of the envs (envs are independent, o2arcenv.py:130-151, so a sample is exact);
+  * the headline kernel `arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|grouped, 30>` (K single-step calls whose launches order
+    themselves; since round 5 also what one arcle_step_many call enqueues) and the plain `<..., autoreset|elide, 30>` (dispatch order
+    off), 8192 envs x 64 steps of bench.py's own task / action streams, against the oracle stepping the WHOLE batch (round 5);
   * c4's per-node batch on ONE GPU: 65 536 envs stepped with the fused packed-row epilogue, the packed rows unpacked and compared;
   * c5 at 32 768 envs (ARCEnv, 70 % flood fills);
   * a 300-step slice of tools/soak.py;
@@ -66,13 +66,13 @@ def _compare_sample(batch, orc, sample, fields, what):
     assert np.array_equal((batch.cnt if full else batch.cnt[idx]).cpu().numpy(), orc.counters()), f"{what}: counters differ"
 
 
-@pytest.mark.parametrize("form", ["per_step_calls", "ordered_step_many", "ordered_bbox5", "hinted_calls"])
+@pytest.mark.parametrize("form", ["per_step_calls", "unordered_calls", "step_many", "step_many_bbox5", "hinted_calls"])
 @pytest.mark.parametrize("max_trial", [-1, 3])
 def test_bench_headline_kernels_vs_oracle_8192(form, max_trial):
     """What bench.py times, checked DIRECTLY against the oracle: 8192 envs x 64 steps of bench.make_tasks / make_actions with
-    ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED — as K arcle_step_bbox calls (`value`) and as one arcle_step_many call with
-    ordered dispatch (`ordered`; bbox + op arrays and 5-tuple records).  Sample: 448 envs, every field, reward and terminated of
-    every step; the sticky status must stay 0."""
+    ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED — as K arcle_step_bbox calls (`value`: self-ordering launches), the same with the
+    dispatch order off (the plain instantiation), as one arcle_step_many call (bbox + op arrays and 5-tuple records) and as hinted single
+    steps.  Every env of the batch, every field, reward and terminated of every step; the sticky status must stay 0."""
     import torch
     import bench
     from arcle_amd import actions
@@ -88,7 +88,8 @@ def test_bench_headline_kernels_vs_oracle_8192(form, max_trial):
     FL = batch.elide_flag | 1
     assert FL == 3, "the O2ARC table permits the zero-fill elision: this is the instantiation bench.py launches"
     bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
-    if form == "per_step_calls":
+    if form in ("per_step_calls", "unordered_calls"):
+        batch.set_dispatch_order(form == "per_step_calls")  # (off: the plain instantiation, every wave steps the env of its own slot)
         rew, trm = torch.empty((K, n), dtype=torch.int32, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev)
         for s in range(K):
             r, t = batch.step_bbox(bb[s], op[s], FL)
@@ -100,11 +101,9 @@ def test_bench_headline_kernels_vs_oracle_8192(form, max_trial):
                 batch.hint_next_ops(op[s + 1])
             r, t = batch.step_bbox(bb[s], op[s], FL)
             rew[s], trm[s] = r, t
-    elif form == "ordered_step_many":
-        batch.set_dispatch_order(True)
+    elif form == "step_many":
         rew, trm = batch.step_many("bbox", bb, op, FL)
     else:
-        batch.set_dispatch_order(True)
         rew, trm = batch.step_many("bbox5", torch.cat([bb, op[:, :, None]], 2).contiguous(), None, FL)
     torch.cuda.synchronize()
     assert batch.status() == 0
@@ -120,19 +119,11 @@ def test_bench_headline_kernels_vs_oracle_8192(form, max_trial):
     _compare_sample(batch, orc, sample, FIELDS_O2, form)
 
 
-def _order_tables(b):
-    n = b.N
-    tab = np.zeros((3, n), np.uint32)
-    assert b.L.arcle_debug_copy_order(b._h, tab.ctypes.data) == 0
-    return tab.astype(np.int64)
-
-
 @pytest.mark.parametrize("variant", ["bbox", "point", "bbox5", "bbox_pack"])
 def test_hinted_single_steps_are_scheduling_only(variant):
-    """arcle_hint_next_ops + single-step calls (the flag sets ARCVecEnv / ShardedVecEnv step with): rewards, terminated flags, packed
-    rows and every byte of state equal the unhinted run — wrong hints (the ops of some other step) and dropped hints included — and
-    the table a hinted launch wrote is a permutation of every XCD's env range with the hinted step's object operations in the lowest
-    slots."""
+    """arcle_hint_next_ops (ABI 4's hint of the next step's operations; launches order themselves since ABI 5 and ignore it) + single-step
+    calls with the flag sets ARCVecEnv / ShardedVecEnv step with: rewards, terminated flags, packed rows and every byte of state equal
+    the run that never hints and has the dispatch order switched off — wrong hints (the ops of some other step) and dropped hints included."""
     import torch
     import bench
     from arcle_amd.engine import STEP_PACK_OBS
@@ -142,6 +133,7 @@ def test_hinted_single_steps_are_scheduling_only(variant):
     xy = bb[:, :, :2].contiguous()
     act5 = torch.cat([bb, op[:, :, None]], 2).contiguous()
     a, b = bench.make_batch(dev, n, seed=11), bench.make_batch(dev, n, seed=11)
+    a.set_dispatch_order(False)
     FL = a.elide_flag | 1
     if variant == "bbox_pack":
         FL |= STEP_PACK_OBS
@@ -160,27 +152,10 @@ def test_hinted_single_steps_are_scheduling_only(variant):
             wrong = s % 5 == 3        # (every 5th: the ops of ANOTHER step — costs nothing but the ordering)
             nxt = (s + 4) % K if wrong else s + 1
             b.hint_next_ops(act5[nxt] if variant == "bbox5" else op[nxt])
-            hinted_for = nxt
-        else:
-            hinted_for = None
         rb, tb = one(b, s)
         assert torch.equal(ra, rb) and torch.equal(ta, tb), (variant, s)
         if variant == "bbox_pack":
             assert torch.equal(pa, pb), (variant, s)
-        if hinted_for is not None and s in (0, 1, 8):
-            torch.cuda.synchronize()
-            tabs, rs = _order_tables(b), n // 8
-            lg = (op_np[hinted_for] >= 20) & (op_np[hinted_for] < 28)
-            good = 0
-            for t in tabs[:2]:
-                ok = True
-                for x in range(8):
-                    seg = t[x * rs:(x + 1) * rs]
-                    assert sorted(seg.tolist()) == list(range(x * rs, (x + 1) * rs)), f"{variant} step {s}: XCD {x} is not a permutation of its env range"
-                    L = int(lg[x * rs:(x + 1) * rs].sum())
-                    ok = ok and bool(lg[seg[:L]].all()) and not bool(lg[seg[L:]].any())
-                good += ok
-            assert good >= 1, f"{variant} step {s}: no table holds the hinted step's object operations in the lowest slots"
     torch.cuda.synchronize()
     for k in a.planes:
         assert torch.equal(a.planes[k], b.planes[k]), (variant, k)
@@ -218,7 +193,6 @@ def test_vec_env_next_operation_argument_and_research_flags_ordered():
     for k in va.batch.planes:
         assert torch.equal(va.batch.planes[k], vb.batch.planes[k]), k
     va.check_errors(), vb.check_errors()
-    assert _order_tables(vb.batch)[:2].std() > 0, "the research step must have run with ordered dispatch (tables written)"
 
 
 class _Env:
@@ -451,4 +425,6 @@ def test_bench_one_rank_is_the_same_line_with_and_without_a_launcher():
     for k in ("metric", "unit", "n_gpus", "steps", "warmup", "config", "headline_form", "dtype", "scaling"):
         assert plain[k] == launched[k], k
     assert plain["roofline"]["algorithmic_bytes_per_launch"] == launched["roofline"]["algorithmic_bytes_per_launch"]
-    assert plain["ordered"]["value"] > 0 and plain["roofline"]["kernel"].startswith("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>")
+    assert plain["forms"]["step_many"]["value"] > 0 and plain["forms"]["dispatch_order_off"]["value"] > 0
+    assert plain["roofline"]["kernel"].startswith("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide|grouped, 30>")
+    assert plain["roofline"]["plan"]["orders_itself"] is True

@@ -146,3 +146,62 @@ def test_grouped_research_step_matches_ungrouped():
         assert torch.equal(va.batch.planes[k], vb.batch.planes[k]), k
     assert torch.equal(va.batch.cnt, vb.batch.cnt)
     va.check_errors(), vb.check_errors()
+
+
+def test_launch_info_and_autotune_keep_state_and_results():
+    """arcle_launch_info reports the plan (self-ordering inside the window, policy letters outside); arcle_autotune times the candidates on
+    the caller's own actions, leaves every byte of state untouched, and the steps that follow — now on the tuned plan — still equal the
+    untuned twin's."""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    for n, want in ((8192, True), (1024, False), (40960, False)):
+        b = bench.make_batch(dev, n, seed=2)
+        info = b.launch_info("bbox", b.elide_flag | 1)
+        assert info["orders_itself"] == want and not info["autotuned"], (n, info)
+        assert info["policy"] == {8192: "", 1024: "A", 40960: "B"}[n] and info["waves_per_workgroup"] in (4, 8), (n, info)
+        del b
+    n, K = 8192, 12
+    bb_np, op_np = _streams(K, n, 31)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    a, b = bench.make_batch(dev, n, seed=4), bench.make_batch(dev, n, seed=4)
+    FL = a.elide_flag | 1
+    for s in range(3):
+        a.step_bbox(bb[s], op[s], FL), b.step_bbox(bb[s], op[s], FL)
+    before = {k: v.clone() for k, v in b.planes.items()}
+    rec, cnt = b.rec.clone(), b.cnt.clone()
+    rows = b.autotune("bbox", bb[3], op[3], FL)
+    assert len(rows) >= 6 and rows[0]["us_per_launch"] > 0, rows
+    assert any(r["orders_itself"] for r in rows) and any(r["policy"] == "B" for r in rows), rows
+    for k in before:
+        assert torch.equal(before[k], b.planes[k]), k
+    assert torch.equal(rec, b.rec) and torch.equal(cnt, b.cnt)
+    info = b.launch_info("bbox", FL)
+    assert info["autotuned"] and info["orders_itself"] == rows[0]["orders_itself"] and info["policy"] == rows[0]["policy"], (info, rows[0])
+    for s in range(3, K):
+        ra, ta = a.step_bbox(bb[s], op[s], FL)
+        rb, tb = b.step_bbox(bb[s], op[s], FL)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb), s
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), k
+    assert a.status() == b.status()
+
+
+def test_host_resident_records_keep_per_env_loads():
+    """A self-ordering launch reads the actions of 32 envs per wave; records in pinned host memory (ARCVecEnv.step_bbox5 accepts them) must
+    keep the scalar per-env loads — same results either way."""
+    import torch
+    import bench
+    n, K, dev = 4096, 10, torch.device("cuda:0")
+    bb_np, op_np = _streams(K, n, 8)
+    act5 = torch.cat([torch.from_numpy(bb_np), torch.from_numpy(op_np)[:, :, None]], 2).contiguous()
+    host, devc = act5.pin_memory(), act5.to(dev)
+    a, b = bench.make_batch(dev, n, seed=6), bench.make_batch(dev, n, seed=6)
+    FL = a.elide_flag | 1
+    for s in range(K):
+        ra, ta = a.step_bbox5(devc[s], FL)
+        rb, tb = b.step_bbox5(host[s], FL)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb), s
+    torch.cuda.synchronize()
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), k
