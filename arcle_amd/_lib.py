@@ -24,7 +24,7 @@ EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buff
            "arcle_step_many", "arcle_set_dispatch_order", "arcle_hint_next_ops", "arcle_launch_info", "arcle_autotune", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation",
            "arcle_packed_obs_size", "arcle_pack_obs", "arcle_set_packed_output", "arcle_set_sampler", "arcle_reset_sampled",
            "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_invalidate", "arcle_flat_obs_size", "arcle_flatten_obs",
-           "arcle_set_flat_output", "arcle_set_flat_output_ex", "arcle_get_state_rows", "arcle_set_state_rows",
+           "arcle_set_flat_output", "arcle_set_flat_output_ex", "arcle_set_flat_seq", "arcle_get_state_rows", "arcle_set_state_rows",
            "arcle_transition_rows", "arcle_get_plane", "arcle_set_plane", "arcle_get_status",
            "arcle_enable_accounting", "arcle_get_accounting", "arcle_get_accounting_ex", "arcle_last_error"]
 
@@ -94,6 +94,7 @@ def lib():
     L.arcle_launch_info.argtypes = [vp, ctypes.c_int, u32, vp]
     L.arcle_autotune.argtypes = [vp, ctypes.c_int, vp, vp, u32, vp, i32, vp]
     L.arcle_set_flat_output_ex.argtypes = [vp, vp, i32, ctypes.c_int, ctypes.c_int]
+    L.arcle_set_flat_seq.argtypes = [vp, i32]
     L.arcle_get_state_rows.argtypes = [vp, vp, i32, vp]
     L.arcle_set_state_rows.argtypes = [vp, vp, i32, vp, vp]
     L.arcle_transition_rows.argtypes = [vp, i32, vp, i32, ctypes.c_int, vp, vp, vp, vp, i32, ctypes.c_int, vp, vp, u32, vp]

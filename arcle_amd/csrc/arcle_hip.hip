@@ -115,6 +115,9 @@ ARCLE_DEV void store_at(void* base, uint32_t off, const T& v) {
   static_assert(sizeof(R) == sizeof(T), "16 / 8 / 4 / 1 byte values");
   *reinterpret_cast<ARCLE_AS_GLOBAL R*>((uintptr_t)base + off) = __builtin_bit_cast(R, v);
 }
+// release at SYSTEM scope + the store: everything this wave stored before (vmcnt is per wave: all lanes' stores) is visible to the host
+// when it reads `v` — s_waitcnt vmcnt(0), L2 write-back of non-coherent lines, then the store itself
+ARCLE_DEV void release_store_system(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 ARCLE_DEV uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz constant clock
 // neighbouring lane's value through DPP wave shifts (no LDS): lane j-1 / lane j+1, 0 at the wave boundary
 ARCLE_DEV uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
@@ -549,6 +552,7 @@ struct arcle_env {
   int32_t flat_stride;
   int flat_filtered;
   int flat_tail;
+  int flat_seq;  // arcle_set_flat_seq: the next rows' tails carry this sequence number behind a system-scope release (0: off)
   uint32_t* retired_ops[64];  // op tables replaced by arcle_set_op_table: launches in flight (and captured graphs) may still read them
   int n_retired;
   int32_t* d_stage;           // int32 [2][n_envs][5]: staging of host-resident action records (arcle_step_many), allocated on first use
@@ -1096,6 +1100,7 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     p.flat_stride = e->flat_stride;
     p.flat_filter = e->flat_filtered ? 1 : 0;
     p.flat_tail = e->flat_tail ? 1 : 0;
+    p.flat_seq = e->flat_tail ? e->flat_seq : 0;
   }
   if (flags & ARCLE_STEP_PACK_OBS) {
     if (!e->pack_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output");
@@ -1547,6 +1552,13 @@ extern "C" int arcle_set_flat_output_ex(arcle_env* e, int8_t* out, int32_t out_s
   return rc;
 }
 
+extern "C" int arcle_set_flat_seq(arcle_env* e, int32_t seq) {
+  if (!e) return ARCLE_ERR_ARG;
+  if (seq < 0 || seq > 255) return fail(e, ARCLE_ERR_ARG, "arcle_set_flat_seq: 0 (off) .. 255");
+  e->flat_seq = seq;
+  return ARCLE_OK;
+}
+
 // ---- state rows at the boundary: ingest (inverse of arcle_flatten_obs), stateless batched transition, plane copies ----------
 static int check_rows(arcle_env* e, const void* rows, int32_t stride, int extra) {
   const int len = arcle::flat_obs_len(e->base, 0);
@@ -1616,6 +1628,7 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
   p.flat_stride = out_stride;
   p.flat_filter = 0;
   p.flat_tail = tail ? 1 : 0;
+  p.flat_seq = tail ? e->flat_seq : 0;
   // in place: a plane the op did not touch stays where it is (the writer's incremental mode); otherwise it is passed through
   if (rows_out == rows_in && out_stride == in_stride) p.flags |= ARCLE_STEP_ROWS_INCREMENTAL;
   const dim3 g = grid_for(n_rows), b(64 * WAVES_PER_WG);

@@ -84,7 +84,8 @@ struct StepParams {
   uint32_t div_magic;  // floor(65536/W)+1 : (n*div_magic)>>16 == n/W for n < 1040 (checked at create)
   int32_t nseg;        // max row segments a 16-cell lane window can span
   int32_t n_steps;     // rollout kernel only: steps per launch
-  int32_t env_stride;  // reserved (0)
+  int32_t flat_seq;    // != 0 with a row tail: byte 15 of the tail carries this sequence number, stored LAST behind a system-scope release
+                       // (arcle_set_flat_seq: the completion signal a host polls in pinned memory instead of synchronising the stream)
   int32_t step_limit;  // ARCLE_STEP_TRUNCATE: truncated = action_steps >= step_limit (TimeLimit, agents/train.py:67)
   uint32_t* status;
   uint32_t* acct;         // optional per-env algorithmic-byte accumulator (ACCT instantiations)
@@ -2131,7 +2132,18 @@ ARCLE_DEV void flat_tail(const Wave& w, const StepOut& out, const I2& cnt, bool 
     t[1] = (uint32_t)cnt.x;
     t[2] = (uint32_t)cnt.y;
     t[3] = (uint32_t)out.term | ((uint32_t)truncated << 8) | ((out.status & 0xffu) << 16);
-    *reinterpret_cast<U4*>(p.flat_out + (size_t)w.env * p.flat_stride + (p.flat_stride - 16)) = t;
+    int8_t* const dst = p.flat_out + (size_t)w.env * p.flat_stride + (p.flat_stride - 16);
+    if (p.flat_seq) {
+      // completion signal for a host that polls the row's tail in pinned memory (the single-env classes): every store of this wave —
+      // the whole row, the first three tail words — is made visible at system scope BEFORE the last word, which carries the caller's
+      // sequence number in its top byte
+      reinterpret_cast<uint32_t*>(dst)[0] = t[0];
+      reinterpret_cast<uint32_t*>(dst)[1] = t[1];
+      reinterpret_cast<uint32_t*>(dst)[2] = t[2];
+      xl::release_store_system(reinterpret_cast<uint32_t*>(dst) + 3, t[3] | ((uint32_t)p.flat_seq << 24));
+    } else {
+      *reinterpret_cast<U4*>(dst) = t;
+    }
   }
 }
 

@@ -130,6 +130,25 @@ class EnvBatch:
         if rc != 0:
             raise ArcleHipError(f"hipStreamSynchronize failed ({rc})")
 
+    def next_seq(self):
+        """Arms the completion signal of the next launch that writes a row tail (arcle_set_flat_seq) and returns its sequence number."""
+        self._seq = getattr(self, "_seq", 0) % 255 + 1
+        rc = self.L.arcle_set_flat_seq(self._h, self._seq)
+        if rc != 0:
+            self._check(rc, "arcle_set_flat_seq")
+        return self._seq
+
+    def wait_tail(self, tail_u8, seq, stream=None, spins=40000):
+        """Waits for the launch armed with `seq` by polling byte 15 of its row tail in PINNED host memory (`tail_u8`: a 16-element uint8
+        numpy view): the kernel stores that byte last, behind a system-scope release, so the row is complete when it shows up.  A bounded
+        spin (~2 ms); then the stream is synchronised instead (a hung or failed launch surfaces there)."""
+        for _ in range(spins):
+            if tail_u8[15] == seq:
+                return
+        self.sync(stream)
+        if tail_u8[15] != seq:
+            raise ArcleHipError("the step finished without writing its row tail")
+
     def plane(self, name):
         """Zero-copy [N,H,W] int8 view of a state plane (row stride PS)."""
         return self.planes[name][:, :self.P].view(self.N, self.H, self.W)

@@ -20,6 +20,11 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
     """Abstract ARC environment (base.py:15-66).  Subclasses define KIND, STATE_KEYS and create_operations()."""
 
     metadata = {"render_modes": [], "render_fps": 5}
+    # Observations: the reference hands out ONE state dict per env and mutates its arrays in place from step to step (np.copyto /
+    # state['grid'][:, :] = ..., actions/object.py:80-165, critical.py:17-65), so an observation kept from an earlier step changes under
+    # later ones.  Same here by default: the arrays of the dict step() returns are views of the pinned host row the step kernel writes
+    # (zero copies, nothing rebuilt per step).  True: an independent copy of the row per step (round 4's behaviour, +6 us per step).
+    copy_observations = False
     KIND = "raw"
 
     def __init__(self, data_loader: Loader, max_grid_size, colors, max_trial=-1, render_mode=None, render_size=None,
@@ -74,7 +79,8 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             flat = b.set_flat_output(False, tail=True, host=True)
             P = self.H * self.W
             act = torch.zeros(((P + 3) & ~3) + 4, dtype=torch.int8).pin_memory()  # selection bytes, then the op as int32
-            self._io_bufs = dict(flat=flat, row=flat[0].numpy(), tail=b.flat_tail[0].numpy(), act=act, sel=act[:P].numpy(),
+            self._io_bufs = dict(flat=flat, row=flat[0].numpy(), tail=b.flat_tail[0].numpy(), tail_u8=b.flat_tail[0].numpy().view(np.uint8),
+                                 act=act, sel=act[:P].numpy(),
                                  op=act[(P + 3) & ~3:].view(torch.int32).numpy(), sel_ptr=act.data_ptr(),
                                  op_ptr=act.data_ptr() + ((P + 3) & ~3), L=flat.shape[1])
         return self._io_bufs
@@ -103,11 +109,18 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self._plan, self._row_len = plan, off
         return self._plan
 
-    def _state_from_row(self, row):
-        """The reference's obs dict (fresh numpy int8 arrays, independent of the staging buffer) from one flattened row: ONE copy of
-        the row, every key a view into that copy."""
+    def _state_from_row(self, row, live=False):
+        """The reference's obs dict from one flattened row.  live (the env's own pinned row, copy_observations False): the dict whose
+        arrays ARE the row — built once, the kernel rewrites it under the caller.  Otherwise fresh numpy int8 arrays, independent of the
+        staging buffer: ONE copy of the row, every key a view into that copy."""
         plan = self._row_plan()
-        buf = row[:self._row_len].copy()
+        if live and not self.copy_observations:
+            st = getattr(self, "_live_state", None)
+            if st is not None and self._live_row is row:
+                return st
+            buf = row[:self._row_len]
+        else:
+            buf = row[:self._row_len].copy()
         st = {}
         for path, lo, hi, shape in plan:
             v = buf[lo:hi]
@@ -117,6 +130,8 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
                 st[path[0]] = v
             else:
                 st.setdefault(path[0], {})[path[1]] = v
+        if live and not self.copy_observations:
+            self._live_state, self._live_row = st, row
         return st
 
     def _fetch_state(self, b):
@@ -125,18 +140,14 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         buf = b._flat_buf
         b._check(b.L.arcle_flatten_obs(b._h, buf.data_ptr(), buf.shape[1], 0, b._stream()), "arcle_flatten_obs")
         b.sync()
-        return self._state_from_row(io["row"])
+        return self._state_from_row(io["row"], live=True)
 
     def _row_from_state(self, state, out):
         """Inverse of _state_from_row: writes the obs dict `state` into the numpy int8 row `out` (full layout)."""
-        off = 0
-        for path, n in self._flat_layout():
-            v = state
-            for k in path:
-                v = v[k]
-            out[off:off + n] = np.asarray(v, np.int8).reshape(-1)
-            off += n
-        return off
+        for path, lo, hi, _ in self._row_plan():
+            v = state[path[0]] if len(path) == 1 else state[path[0]][path[1]]
+            out[lo:hi] = v.ravel() if type(v) is np.ndarray and v.dtype == np.int8 else np.asarray(v, np.int8).reshape(-1)
+        return self._row_len
 
     @staticmethod
     def _state_from_device(b, n=0):
@@ -257,9 +268,10 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         io["sel"][:] = sel.reshape(-1)  # (any integer / bool dtype -> int8, straight into the pinned buffer the kernel reads)
         io["op"][0] = op
         st = b._stream()
+        seq = b.next_seq()
         b._check(b.L.arcle_step_mask(b._h, io["sel_ptr"], io["op_ptr"], b._reward_ptr, b._term_ptr,
                                      self._step_flags() | STEP_FLAT_OBS, st), "arcle_step_mask")
-        b.sync(st)  # the one synchronisation of the step: row + tail are on the host now
+        b.wait_tail(io["tail_u8"], seq, st)  # the one wait of the step: the kernel's own completion signal in the pinned row's tail
         tail = io["tail"]
         status = (int(tail[3]) >> 16) & 0xFF
         if status:
@@ -287,7 +299,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self.last_action_op = int(action["operation"]) % len(self.operations)
             self.last_action = action
             io = self._io()
-            self.current_state = self._state_from_row(io["row"])  # (the kernel wrote it into pinned host memory)
+            self.current_state = self._state_from_row(io["row"], live=True)  # (the kernel wrote it into pinned host memory)
             self.action_steps, self.submit_count = int(io["tail"][1]), int(io["tail"][2])
             # a subclass that overrides reward() (e.g. the dense reward of agents/env.py:44-58) is evaluated on the host;
             # so is the reward of a host-applied last op
@@ -312,6 +324,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             act = torch.zeros(((P + 3) & ~3) + 4, dtype=torch.int8).pin_memory()
             self._tio_bufs = dict(rin=rin, rout=rout, act=act, rin_np=rin[0].numpy(), rout_np=rout[0].numpy(), sel=act[:P].numpy(),
                                   op=act[(P + 3) & ~3:].view(torch.int32).numpy(), tail=rout[0, stride - 16:].view(torch.int32).numpy(),
+                                  tail_u8=rout[0, stride - 16:].numpy().view(np.uint8),
                                   stride=stride, L=L, op_off=(P + 3) & ~3)
         return self._tio_bufs
 
@@ -332,10 +345,12 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         t["sel"][:] = sel.reshape(-1)
         t["op"][0] = op
         ap = t["act"].data_ptr()
+        st = b._stream()
+        seq = b.next_seq()
         b._check(b.L.arcle_transition_rows(b._h, 1, t["rin"].data_ptr(), t["stride"], 0, ap, ap + t["op_off"], None,
                                            t["rout"].data_ptr(), t["stride"], 1, b._reward_ptr, b._term_ptr, self._step_flags(),
-                                           b._stream()), "arcle_transition_rows")
-        b.sync()
+                                           st), "arcle_transition_rows")
+        b.wait_tail(t["tail_u8"], seq, st)
         status = (int(t["tail"][3]) >> 16) & 0xFF
         if status:
             b.status()

@@ -761,7 +761,7 @@ def transition_leg(dev, n, bbox, op, K=32):
     FL = batch.elide_flag | STEP_AUTORESET
     for i in range(20):
         batch.step_bbox_ptr(bbox[i].data_ptr(), op[i].data_ptr(), FL, torch.cuda.current_stream(dev).cuda_stream)
-    rows = batch.get_state_rows().clone()
+    rows = batch.get_state_rows()  # (as the library hands rows out: a [n, L] view of a 16-byte aligned buffer, stride L rounded up to 16)
     stride = rows.stride(0)
     out = torch.empty((n, ((batch.state_row_size() + 15) & ~15)), dtype=torch.int8, device=dev)
     rw, tm = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
@@ -775,6 +775,15 @@ def transition_leg(dev, n, bbox, op, K=32):
     sec, _ = graph_time(dev, enqueue, K)
     L = batch.state_row_size()
     moved = n * (2 * L + 1024 + 16 + 24)
+    # ... and from densely packed rows (stride L, no alignment: a contiguous clone) — those cannot be staged chunk-wise and take the on-demand form
+    rows_d = rows.clone()
+
+    def enqueue_dense(sh):
+        for i in range(K):
+            rc = batch.L.arcle_transition_rows(batch._h, n, rows_d.data_ptr(), rows_d.stride(0), 1, bbox[i].data_ptr(), op[i].data_ptr(), None,
+                                               out.data_ptr(), out.shape[1], 0, rw.data_ptr(), tm.data_ptr(), 0, sh)
+            assert rc == 0
+    sec_d, _ = graph_time(dev, enqueue_dense, K)
     # in place: rows_out IS rows_in — the kernel rewrites only the planes the op changed (walking n trajectories forward)
     buf = torch.zeros((n, out.shape[1]), dtype=torch.int8, device=dev)
     buf[:, :L] = rows
@@ -787,6 +796,7 @@ def transition_leg(dev, n, bbox, op, K=32):
     sec_ip, _ = graph_time(dev, enqueue_in_place, K)
     return {"mode": f"arcle_transition_rows, {n} (row, bbox action) pairs per launch, rows {L} B", "value": n / sec, "unit": "transitions/s",
             "us_per_step_batch": sec * 1e6,
+            "rows_densely_packed": {"us_per_step_batch": sec_d * 1e6, "note": "input rows with stride L (unaligned): the on-demand form, as in round 4"},
             "in_place": {"us_per_step_batch": sec_ip * 1e6, "value": n / sec_ip, "unit": "transitions/s",
                          "note": "rows_out is rows_in: only the planes the op changed are rewritten"},
             "roofline": {"bound": "hbm", "achieved": moved / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": moved / sec / HBM_PEAK,

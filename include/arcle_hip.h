@@ -364,6 +364,12 @@ int arcle_set_flat_output(arcle_env* env, int8_t* out, int32_t out_stride, int f
  * (status: the ARCLE_ST_* bits THIS env raised in THIS step) — so that one copy of the row (or none, when `out` is pinned host
  * memory) returns everything step() returns.  out_stride >= arcle_flat_obs_size() rounded up to 16, plus 16. */
 int arcle_set_flat_output_ex(arcle_env* env, int8_t* out, int32_t out_stride, int filtered, int tail);
+/* Completion signal in the row tail (ABI 5): with seq in 1..255 the LAST byte of every tail written from now on — by steps carrying
+ * ARCLE_STEP_FLAT_OBS and by arcle_transition_rows with a tail — holds `seq`, and that word is stored last, behind a release at
+ * system scope: a host that finds `seq` in the tail of a row in PINNED memory also finds the whole row and the other tail words.  It
+ * can therefore poll that byte instead of synchronising the stream (a blocking synchronise wakes up tens of microseconds late): what
+ * the single-env classes do — the caller changes seq from launch to launch.  0 (default) writes the tail as one plain 16-byte store. */
+int arcle_set_flat_seq(arcle_env* env, int32_t seq);
 
 /* ---- state rows at the boundary -------------------------------------------------------------------------------------------
  * A "state row" is the full (unfiltered) flattened observation of one env: the reference's state dict (base.py:155-166,

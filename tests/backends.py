@@ -127,7 +127,7 @@ class _StepParams(ctypes.Structure):  # mirror of arcle::StepParams (arcle_amd/c
                 ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32),
                 ("ingress", ctypes.c_int32), ("flags", ctypes.c_uint32), ("div_magic", ctypes.c_uint32),
-                ("nseg", ctypes.c_int32), ("n_steps", ctypes.c_int32), ("env_stride", ctypes.c_int32),
+                ("nseg", ctypes.c_int32), ("n_steps", ctypes.c_int32), ("flat_seq", ctypes.c_int32),
                 ("step_limit", ctypes.c_int32),
                 ("status", ctypes.c_void_p), ("acct", ctypes.c_void_p), ("d_ops", ctypes.c_void_p),
                 ("trunc", ctypes.c_void_p), ("dense", ctypes.c_void_p), ("flat_out", ctypes.c_void_p),

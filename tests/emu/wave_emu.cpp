@@ -114,6 +114,7 @@ ARCLE_DEV U4 uload4(const void* p) { U4 v; memcpy(&v, p, 16); return v; }
 ARCLE_DEV U4 load16(const int8_t* base, uint32_t off) { U4 v; memcpy(&v, base + off, 16); return v; }
 ARCLE_DEV void store16(int8_t* base, uint32_t off, const U4& v) { memcpy(base + off, &v, 16); }
 ARCLE_DEV void store16_nt(int8_t* base, uint32_t off, const U4& v) { store16(base, off, v); }
+ARCLE_DEV void release_store_system(uint32_t* p, uint32_t v) { *p = v; }
 ARCLE_DEV void wg_barrier() { yield(8); }
 ARCLE_DEV void lanes_converged() { yield(9); }
 ARCLE_DEV uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }

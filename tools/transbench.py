@@ -8,7 +8,8 @@ dev = torch.device("cuda:0"); n = 8192
 bb, op = bench.make_actions(64, n, 2000)
 bbox, ops = torch.from_numpy(bb).to(dev), torch.from_numpy(op).to(dev)
 r = bench.transition_leg(dev, n, bbox, ops)
-print(os.environ.get("ARCLE_HIP_LIB", "default"), "out of place", round(r["us_per_step_batch"], 2), "us  frac", round(r["roofline"]["frac"], 3), flush=True)
+print(os.environ.get("ARCLE_HIP_LIB", "default"), "out of place", round(r["us_per_step_batch"], 2), "us  frac", round(r["roofline"]["frac"], 3),
+      " densely packed rows", round(r["rows_densely_packed"]["us_per_step_batch"], 2), "us  in place (leg)", round(r["in_place"]["us_per_step_batch"], 2), flush=True)
 # in place: rows_out is rows_in
 batch = bench.make_batch(dev, n)
 rows = batch.get_state_rows().clone()
