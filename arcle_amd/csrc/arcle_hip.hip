@@ -442,9 +442,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #endif
 }
 
-template <int ING, int FW, int WC = 0>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const StepParams pa) {
+#ifndef ARCLE_ROLLOUT_WAVES
+#define ARCLE_ROLLOUT_WAVES 4  // waves per SIMD the rollout kernels are compiled for (the register allocator's target: 512 / waves VGPRs)
+#endif
+template <int ING, int FW, int WC = 0, int FL = -1>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(ARCLE_ROLLOUT_WAVES))) void arcle_rollout_kernel(const StepParams pa) {
   StepParams p = pa;
+  if (FL >= 0) p.flags = (uint32_t)FL;  // (the launcher checked that the launch's flags are this instantiation's constant)
   if (WC == 30) {  // the standard 30 x 30 grid: dimensions as compile-time constants (as in arcle_step_kernel)
     p.H = p.W = 30;
     p.P = 900;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_rollout_kernel(const 
   xl::wg_barrier();
   const int env = wave_of_launch();
   if (env >= p.n_envs) return;
-  arcle::wave_rollout<ING, FW>(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
+  arcle::wave_rollout<ING, FW, FL>(p, &lds.wave[threadIdx.x >> 6], lds.lut, env, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void arcle_flatten_kernel(const StepParams p) {
@@ -1362,7 +1366,13 @@ extern "C" int arcle_pack_mask_bits(arcle_env* e, const int8_t* sel, uint8_t* bi
 
 #ifdef ARCLE_FAST_BUILD
 template <int ING>
-static int launch_rollout_ing(int, dim3, dim3, hipStream_t, const StepParams&) { return ARCLE_ERR_CONFIG; }
+static int launch_rollout_ing(int fw, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {  // (development builds: the 30 x 30 bbox rollouts only)
+  if (ING != arcle::INGRESS_BBOX || fw == arcle::FW_GENERIC || p.H != 30 || p.W != 30) return ARCLE_ERR_CONFIG;
+  if (p.flags == (uint32_t)HOT_FLAGS) hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_BBOX, arcle::FW_FAST, 30, HOT_FLAGS>), g, b, 0, st, p);
+  else if (p.flags == (uint32_t)HOT_PACK_FLAGS) hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_BBOX, arcle::FW_FAST, 30, HOT_PACK_FLAGS>), g, b, 0, st, p);
+  else hipLaunchKernelGGL((arcle_rollout_kernel<arcle::INGRESS_BBOX, arcle::FW_FAST, 30>), g, b, 0, st, p);
+  return ARCLE_OK;
+}
 #else
 template <int ING, int FW>
 static void launch_rollout_tbl(dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
@@ -1371,6 +1381,16 @@ static void launch_rollout_tbl(dim3 g, dim3 b, hipStream_t st, const StepParams&
 template <int ING>
 static int launch_rollout_ing(int fw, dim3 g, dim3 b, hipStream_t st, const StepParams& p) {
   // (the rollout keeps planes in registers: lane predication does not matter, FW_FULL shares FW_FAST's code)
+  if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_POINT) {  // the front-ends' flag sets: compile-time constants of lean instantiations
+    if (fw != arcle::FW_GENERIC && p.H == 30 && p.W == 30 && p.flags == (uint32_t)HOT_FLAGS) {
+      hipLaunchKernelGGL((arcle_rollout_kernel<ING, arcle::FW_FAST, 30, HOT_FLAGS>), g, b, 0, st, p);
+      return ARCLE_OK;
+    }
+    if (fw != arcle::FW_GENERIC && p.H == 30 && p.W == 30 && p.flags == (uint32_t)HOT_PACK_FLAGS) {
+      hipLaunchKernelGGL((arcle_rollout_kernel<ING, arcle::FW_FAST, 30, HOT_PACK_FLAGS>), g, b, 0, st, p);
+      return ARCLE_OK;
+    }
+  }
   if (fw != arcle::FW_GENERIC && p.H == 30 && p.W == 30) hipLaunchKernelGGL((arcle_rollout_kernel<ING, arcle::FW_FAST, 30>), g, b, 0, st, p);
   else if (fw != arcle::FW_GENERIC) launch_rollout_tbl<ING, arcle::FW_FAST>(g, b, st, p);
   else launch_rollout_tbl<ING, arcle::FW_GENERIC>(g, b, st, p);
@@ -1383,10 +1403,12 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   if (!e || !sel || !op || !reward || !term) return ARCLE_ERR_ARG;
   if (n_steps <= 0) return fail(e, ARCLE_ERR_ARG, "n_steps must be positive");
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
-  if (flags & ~(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT))
+  if (flags & ~(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT | ARCLE_STEP_PACK_OBS))
     return fail(e, ARCLE_ERR_ARG, "flag not supported by the rollout kernels");
-  if ((flags & ARCLE_STEP_FEATURE_FLAGS) && ingress != arcle::INGRESS_MASK)
+  if ((flags & (ARCLE_STEP_CONTINUE_RULE | ARCLE_STEP_RESET_ON_SUBMIT)) && ingress != arcle::INGRESS_MASK)
     return fail(e, ARCLE_ERR_CONFIG, "the rollout kernels take ARCLE_STEP_CONTINUE_RULE / _RESET_ON_SUBMIT with mask ingress only");
+  if ((flags & ARCLE_STEP_PACK_OBS) && !e->pack_out)
+    return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output (rollouts: uint8 [n_steps][n_envs][arcle_packed_obs_size()])");
   DeviceGuard guard(e->device);
   if (e->d_dense_cache) HIP_TRY(e, hipMemsetAsync(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8, (hipStream_t)stream));  // (rollouts move grids, keep no pairs)
   StepParams p = e->base;
@@ -1399,6 +1421,7 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
   p.acct = nullptr;
   p.rmask = nullptr;
   p.n_steps = n_steps;
+  p.pack_out = e->pack_out;
   const dim3 g = grid_for(p.n_envs), b(64 * WAVES_PER_WG);
   hipStream_t st = (hipStream_t)stream;
   const int fw = width_class(p);

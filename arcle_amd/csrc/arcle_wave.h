@@ -1912,7 +1912,7 @@ ARCLE_DEV void wave_step(Wave& w, int env, StepInputs& in, uint64_t t_entry = 0,
 //   sel: int32 [n_steps][n_envs][4|2] | int8 [n_steps][n_envs][P]   op: int32 [n_steps][n_envs]
 //   reward: int32 [n_steps][n_envs]     term: uint8 [n_steps][n_envs]
 // ------------------------------------------------------------------------------------------------
-template <int ING, int FW>
+template <int ING, int FW, int FL = -1>
 ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, const U2* lut, int env, int lane) {
   Wave w(p, lds, lut, lane, ING, FW, false);
   w.set_env(env);
@@ -1937,11 +1937,19 @@ ARCLE_DEV void wave_rollout(const StepParams& p, WaveLDS* lds, const U2* lut, in
       next_payload = load_payload_v(w, env, (size_t)t + 1);
       next_op = (uint32_t)p.op[((size_t)t + 1) * N + env];
     }
-    // (the feature flags a rollout accepts — continuation rule, reset_on_submit — belong to mask-ingress trace replay)
-    const StepOut out = step_core<ING, FW, 0, is_cells(ING) ? 1 : 0>(w, r, cnt, payload, op);
+    // (the feature flags a rollout accepts — continuation rule, reset_on_submit — belong to mask-ingress trace replay;
+    //  FL >= 0: the flag set is a compile-time constant of this instantiation, as in the step kernel)
+    const StepOut out = step_core<ING, FW, 0, is_cells(ING) ? 1 : 0, FL>(w, r, cnt, payload, op);
     if (lane == 0) {
       p.reward[(size_t)t * N + env] = out.reward;
       p.term[(size_t)t * N + env] = (uint8_t)out.term;
+    }
+    // ARCLE_STEP_PACK_OBS (round 5): the packed observation row of EVERY step — grid | grid_dim | reward | terminated, what a learner gathers —
+    // out of the registers the state lives in: pack_out is [n_steps][n_envs][packed stride]; the Gym contract "an observation after every
+    // step" without leaving the chip between the steps
+    if ((FL >= 0 ? (uint32_t)FL : p.flags) & ARCLE_STEP_PACK_OBS) {
+      const int stride = packed_stride(p.P);
+      pack_row(w, r, (uint32_t)out.reward, (uint32_t)out.term, p.pack_out + (size_t)t * N * (size_t)stride, stride, true, w.load(ARCLE_PL_GRID));
     }
   }
 #pragma unroll

@@ -381,10 +381,21 @@ class EnvBatch:
         if rc != 0:
             self._check(rc, "arcle_step_bbox")
 
-    def rollout(self, payload, op, flags=0, point=False, mask=False):
+    def rollout(self, payload, op, flags=0, point=False, mask=False, packed=None):
         """T steps in one launch.  payload int32 [T,N,4] (bbox) / [T,N,2] (point) / int8 [T,N,H,W] (mask=True), op
-        int32 [T,N]; returns (reward int32 [T,N], terminated uint8 [T,N]).  Same semantics as T step_* calls."""
+        int32 [T,N]; returns (reward int32 [T,N], terminated uint8 [T,N]).  Same semantics as T step_* calls.
+        packed: a uint8 [T, N, packed_obs_size()] device tensor — the launch then also writes the packed observation row of EVERY step
+        (grid | grid_dim | reward | terminated; STEP_PACK_OBS; unpack with EnvBatch.unpack_obs): an observation after every step although
+        the state never leaves the chip between the steps."""
         T = int(op.shape[0])
+        if packed is not None:
+            assert packed.shape == (T, self.N, self.packed_obs_size()) and packed.dtype == torch.uint8 and packed.is_contiguous() and packed.device == self.device
+            prev = getattr(self, "packed", None)
+            self._check(self.L.arcle_set_packed_output(self._h, _ptr(packed)), "arcle_set_packed_output")
+            try:
+                return self.rollout(payload, op, int(flags) | STEP_PACK_OBS, point, mask)
+            finally:
+                self._check(self.L.arcle_set_packed_output(self._h, _ptr(prev)), "arcle_set_packed_output")
         op = op.to(device=self.device, dtype=torch.int32).contiguous()
         if mask:
             payload = payload.to(device=self.device, dtype=torch.int8).contiguous()

@@ -576,12 +576,13 @@ class ARCVecEnv:
         self.batch.set_state(st)
         self._refresh_rows()
 
-    def rollout_bbox(self, bbox, operation):
+    def rollout_bbox(self, bbox, operation, packed=None):
         """T steps in ONE launch: bbox int32 [T,N,4], operation int32 [T,N] -> (obs, reward [T,N], terminated [T,N]).
-        For callers that already hold the action sequence (trace replay, scripted policies); the state is only
-        observable after the last step."""
-        reward, term = self.batch.rollout(bbox, operation, self._rollout_flags())
-        self._refresh_rows()  # (a rollout keeps no per-step rows: the live mirror is rewritten from the final state)
+        For callers that already hold the action sequence (action chunks, trace replay, scripted policies).  The state dict is only
+        observable after the last step; packed = a uint8 [T, N, batch.packed_obs_size()] device tensor additionally receives the packed
+        observation row (grid | grid_dim | reward | terminated, `EnvBatch.unpack_obs`) of EVERY step."""
+        reward, term = self.batch.rollout(bbox, operation, self._rollout_flags(), packed=packed)
+        self._refresh_rows()  # (a rollout keeps no per-step flat rows: the live mirror is rewritten from the final state)
         return self._obs, reward, term.bool(), self._info()
 
     def rollout_point(self, xy, operation):

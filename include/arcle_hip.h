@@ -305,7 +305,10 @@ int arcle_autotune(arcle_env* env, int ingress, const void* sel, const int32_t* 
  * reference).  Semantically identical to n_steps calls of arcle_step_bbox/_point; the env state is kept on chip
  * between the steps, so only the final state is observable afterwards.
  *   bbox / xy  device int32[n_steps][n_envs][4 | 2]      op      device int32[n_steps][n_envs]
- *   reward     device int32[n_steps][n_envs] out         term    device uint8[n_steps][n_envs] out */
+ *   reward     device int32[n_steps][n_envs] out         term    device uint8[n_steps][n_envs] out
+ * flags: ARCLE_STEP_AUTORESET | _ELIDE_SELECTED; mask ingress also _CONTINUE_RULE | _RESET_ON_SUBMIT; and (ABI 5) ARCLE_STEP_PACK_OBS:
+ * the launch then also writes the packed observation row of EVERY step — the buffer installed with arcle_set_packed_output must hold
+ * uint8 [n_steps][n_envs][arcle_packed_obs_size()] — so an action-chunk caller keeps Gym's "observation after every step". */
 int arcle_rollout_bbox(arcle_env* env, int32_t n_steps, const int32_t* bbox, const int32_t* op, int32_t* reward,
                        uint8_t* term, uint32_t flags, void* stream);
 int arcle_rollout_point(arcle_env* env, int32_t n_steps, const int32_t* xy, const int32_t* op, int32_t* reward,

@@ -205,3 +205,28 @@ def test_host_resident_records_keep_per_env_loads():
     torch.cuda.synchronize()
     for k in a.planes:
         assert torch.equal(a.planes[k], b.planes[k]), k
+
+
+@pytest.mark.parametrize("n", [192, 8192])
+def test_rollout_emits_the_packed_row_of_every_step(n):
+    """arcle_rollout_bbox with ARCLE_STEP_PACK_OBS (round 5): T steps in one launch, state resident in registers, AND the packed
+    observation row of every step — equal to the rows T single steps pack, reward / terminated / final state included."""
+    import torch
+    import bench
+    from arcle_amd.engine import STEP_PACK_OBS
+    T, dev = 24, torch.device("cuda:0")
+    bb_np, op_np = _streams(T, n, 13) if n % 32 == 0 and n >= 2304 else bench.make_actions(T, n, 13)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np % 35).to(dev)
+    a, b = bench.make_batch(dev, n, seed=21), bench.make_batch(dev, n, seed=21)
+    FL = a.elide_flag | 1
+    R = a.packed_obs_size()
+    rows = torch.full((T, n, R), 0x55, dtype=torch.uint8, device=dev)
+    rr, tt = b.rollout(bb, op, FL, packed=rows)
+    pa = a.set_packed_output()
+    for s in range(T):
+        ra, ta = a.step_bbox(bb[s], op[s], FL | STEP_PACK_OBS)
+        assert torch.equal(ra, rr[s]) and torch.equal(ta, tt[s]), s
+        assert torch.equal(pa, rows[s]), f"packed rows of step {s} differ"
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), k
+    assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt)

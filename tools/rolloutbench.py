@@ -14,12 +14,13 @@ for T in (16, 64, 256):
     b.set_tasks_padded(*bench.make_tasks(N, 1)); b.reset()
     bn, on = bench.make_actions(T, N, 7)
     bb, oo = torch.from_numpy(bn).to(dev), torch.from_numpy(on).to(dev)
-    b.rollout(bb, oo); torch.cuda.synchronize()
+    FL = (b.elide_flag | 1) if os.environ.get("ROLL_FLAGS", "hot") == "hot" else 0   # (ARCVecEnv's flag set: the lean instantiation)
+    b.rollout(bb, oo, FL); torch.cuda.synchronize()
     reps = max(2, 2048 // T)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        b.rollout(bb, oo)
+        b.rollout(bb, oo, FL)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"rollout T={T:4d}: {us:9.1f} us/launch = {us/T:6.2f} us per step-batch -> {N*T/us:8.1f} M env-steps/s", flush=True)
