@@ -92,7 +92,7 @@ def lib():
     L.arcle_set_dispatch_order.argtypes = [vp, ctypes.c_int]
     L.arcle_hint_next_ops.argtypes = [vp, vp, i32]
     L.arcle_launch_info.argtypes = [vp, ctypes.c_int, u32, vp]
-    L.arcle_autotune.argtypes = [vp, ctypes.c_int, vp, vp, u32, vp, i32, vp]
+    L.arcle_autotune.argtypes = [vp, ctypes.c_int, i32, vp, vp, u32, vp, i32, vp]
     L.arcle_set_flat_output_ex.argtypes = [vp, vp, i32, ctypes.c_int, ctypes.c_int]
     L.arcle_set_flat_seq.argtypes = [vp, i32]
     L.arcle_get_state_rows.argtypes = [vp, vp, i32, vp]

@@ -1136,6 +1136,8 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   return ARCLE_OK;
 }
 
+static size_t payload_bytes(const arcle_env* e, int ingress);
+
 extern "C" int arcle_launch_info(arcle_env* e, int ingress, uint32_t flags, int32_t* out4) {
   if (!e || !out4) return ARCLE_ERR_ARG;
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
@@ -1155,10 +1157,11 @@ extern "C" int arcle_launch_info(arcle_env* e, int ingress, uint32_t flags, int3
 // Times the candidate launch plans of THIS handle — its batch size, this box, the caller's own action arrays where they live — and keeps the
 // fastest for later launches with the same ingress form and flags.  The env state is saved first and restored before every candidate and at
 // the end, so the call leaves the handle exactly as it found it (only stream order: no host synchronisation is left pending).
-extern "C" int arcle_autotune(arcle_env* e, int ingress, const void* sel, const int32_t* op, uint32_t flags, int32_t* report, int32_t report_rows,
-                              void* stream) {
+extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, const void* sel, const int32_t* op, uint32_t flags, int32_t* report,
+                              int32_t report_rows, void* stream) {
   if (!e || !sel || (!op && ingress != arcle::INGRESS_BBOX5)) return ARCLE_ERR_ARG;
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  if (n_batches <= 0) return fail(e, ARCLE_ERR_ARG, "arcle_autotune: n_batches must be positive");
   if (flags & ~(uint32_t)(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_PACK_OBS))
     return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS only (other flags keep per-env side state it does not save)");
   if (e->d_acct) return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: not with byte accounting enabled");
@@ -1169,7 +1172,10 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, const void* sel, const 
     return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: not inside a stream capture");
   }
   DeviceGuard guard(e->device);
-  const size_t n = (size_t)e->cfg.n_envs, pbytes = n * (size_t)e->base.PS;
+  const size_t n = (size_t)e->cfg.n_envs, pbytes = n * (size_t)e->base.PS, pb = payload_bytes(e, ingress);
+  // (the timed launches walk the caller's action batches in order, like arcle_step_many: ONE repeated batch is not a workload — the state
+  // degenerates under it and the actions never leave the caches; profiles/round5_policy_autotune.txt)
+  const int n_warm = n_batches < 3 ? 3 : (n_batches < 8 ? n_batches : 8), n_timed = n_batches < 10 ? 10 : (n_batches < 64 ? n_batches : 64);
   // scratch: a copy of every plane, the records, the counters; outputs of the timed launches
   int8_t* save_plane[ARCLE_N_PLANES] = {nullptr};
   int8_t* save_rec = nullptr;
@@ -1211,9 +1217,10 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, const void* sel, const 
           if (got.policy == cand.policy && got.wpw == cand.wpw && got.grouped == cand.grouped) {
             float ms = 0.f;
             bool r = copy_state(false);
-            for (int it = 0; r && it < 3 + 10; it++) {
-              if (it == 3) r = hipEventRecord(ev0, st) == hipSuccess;
-              if (r) rc = launch_step(e, ingress, sel, op, t_reward, (uint8_t*)t_term, flags, stream);
+            for (int it = 0; r && it < n_warm + n_timed; it++) {
+              if (it == n_warm) r = hipEventRecord(ev0, st) == hipSuccess;
+              const size_t bi = (size_t)(it % n_batches);
+              if (r) rc = launch_step(e, ingress, (const char*)sel + bi * pb, op ? op + bi * n : nullptr, t_reward, (uint8_t*)t_term, flags, stream);
               r = r && rc == ARCLE_OK;
             }
             r = r && hipEventRecord(ev1, st) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess;
@@ -1222,7 +1229,7 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, const void* sel, const 
               if (best_ms < 0.f || ms < best_ms) best_ms = ms, best = cand;
               if (report && rows < report_rows) {
                 report[4 * rows + 0] = cand.grouped, report[4 * rows + 1] = cand.policy, report[4 * rows + 2] = cand.wpw;
-                report[4 * rows + 3] = (int32_t)(ms * 1e5f);  // ns per launch (10 launches)
+                report[4 * rows + 3] = (int32_t)(ms * 1e6f / (float)n_timed);  // ns per launch
                 rows++;
               }
             }

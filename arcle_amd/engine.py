@@ -359,11 +359,15 @@ class EnvBatch:
         return self.launch_info(form, flags)["orders_itself"]
 
     def autotune(self, form, payload, op, flags):
-        """Times every launch plan this handle can take on the caller's own action tensors (arcle_autotune: state saved and restored, stream
-        synchronised) and keeps the fastest for later (form, flags) launches.  Returns the candidates as a list of dicts sorted by time."""
+        """Times every launch plan this handle can take on the caller's own action tensors — payload [K, N, ...] / op [K, N]: K consecutive
+        action batches, a representative stretch of the policy's output (a single [N, ...] batch is accepted, but one repeated batch is
+        a poor sample) — and keeps the fastest for later (form, flags) launches (arcle_autotune: state saved and restored, stream
+        synchronised).  Returns the candidates as a list of dicts sorted by time."""
         import numpy as np
         rep = np.zeros((16, 4), np.int32)
-        rc = self.L.arcle_autotune(self._h, _lib.INGRESS[form], _ptr(payload), _ptr(op), int(flags), rep.ctypes.data, 16, self._stream())
+        K = int(payload.shape[0]) if (op is not None and op.dim() == 2) or (op is None and payload.dim() == 3) else 1
+        assert payload.is_contiguous() and (op is None or op.is_contiguous())
+        rc = self.L.arcle_autotune(self._h, _lib.INGRESS[form], K, _ptr(payload), _ptr(op), int(flags), rep.ctypes.data, 16, self._stream())
         if rc < 0:
             self._check(rc, "arcle_autotune")
         rows = [{"orders_itself": bool(r[0]), "policy": chr(r[1]) if r[1] else "", "waves_per_workgroup": int(r[2]), "us_per_launch": r[3] / 1e3} for r in rep[:rc]]

@@ -507,17 +507,23 @@ def rollout_leg(batch, bbox, op, dev, T=128, reps=8):
     resident in registers between the steps; only per-step reward/terminated and the final state reach HBM)."""
     T = min(T, bbox.shape[0])
     bb, oo = bbox[:T].contiguous(), op[:T].contiguous()
-    batch.rollout(bb, oo)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        batch.rollout(bb, oo)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    FL = batch.elide_flag | STEP_AUTORESET  # (what ARCVecEnv.rollout_bbox passes: the lean instantiation with the flags as constants)
+
+    def timed(**kw):
+        batch.rollout(bb, oo, FL, **kw)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            batch.rollout(bb, oo, FL, **kw)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    sec = timed()
+    rows = torch.empty((T, batch.N, batch.packed_obs_size()), dtype=torch.uint8, device=dev)
+    sec_rows = timed(packed=rows)  # ... and with the packed observation row of every step (ARCLE_STEP_PACK_OBS: 912 B per env-step out)
     return {"mode": "arcle_rollout_bbox", "steps_per_launch": T, "value": T * batch.N / sec, "unit": "env-steps/s",
-            "us_per_step_batch": sec / T * 1e6,
+            "us_per_step_batch": sec / T * 1e6, "with_packed_rows_us_per_step_batch": sec_rows / T * 1e6,
             "note": "state stays on chip between steps; not comparable with the per-step HBM roofline above"}
 
 
@@ -823,7 +829,7 @@ def batch_sweep_leg(dev, bbox, op, sizes=(32768, 65536, 131072), K=24):
         alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
         plan0 = batch.launch_info("bbox", FL)
         sec0, _ = graph_time(dev, enqueue, K, reps=7, warm=8)  # (1 GB of freshly allocated state: let TLBs and clocks settle)
-        cands = batch.autotune("bbox", bb[0], oo[0], FL)
+        cands = batch.autotune("bbox", bb, oo, FL)  # (on the leg's own K action batches)
         plan1 = batch.launch_info("bbox", FL)
         sec1, _ = graph_time(dev, enqueue, K, reps=7, warm=4)
         sec, plan = (sec1, plan1) if sec1 <= sec0 else (sec0, plan0)
@@ -831,8 +837,8 @@ def batch_sweep_leg(dev, bbox, op, sizes=(32768, 65536, 131072), K=24):
                "roofline": roofline_block("arcle_step_kernel<bbox, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, N, plan=plan),
                "table_plan": {"plan": plan0, "us_per_step_batch": sec0 * 1e6}, "autotuned_plan": {"plan": plan1, "us_per_step_batch": sec1 * 1e6},
                "autotune": {"candidates": [f"{'grouped' if r['orders_itself'] else (r['policy'] or 'plain')}/{r['waves_per_workgroup']}w {r['us_per_launch']:.2f}us" for r in cands],
-                            "note": "arcle_autotune: 10 launches of one action batch per candidate on the saved state; the leg's own graph of "
-                                    "K distinct batches is then timed with the table's plan and with the tuned plan, the faster one is the leg's figure"}}
+                            "note": "arcle_autotune: every candidate walks the leg's K action batches from the saved state; the leg's own graph is "
+                                    "then timed with the table's plan and with the tuned plan, the faster one is the leg's figure"}}
         out.append(leg)
         del batch, bb, oo
         torch.cuda.empty_cache()

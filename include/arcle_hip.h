@@ -290,15 +290,17 @@ int arcle_hint_next_ops(arcle_env* env, const int32_t* next_op, int32_t stride);
  * launch orders itself.  arcle_launch_info reports the plan a launch with (ingress, flags) and device-resident actions would take:
  * out4 = {orders itself, policy (0 or the letter), waves per workgroup, 1 if arcle_autotune chose it}.
  * arcle_autotune replaces the tables for THIS handle: it times every plan the launch can take — on this handle's batch size, this box and
- * the caller's own action arrays where they live (sel / op as for arcle_step_*; ingress BBOX, BBOX5, POINT, MASK or BITS; flags within
- * ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS) — 3 + 10 launches each, and keeps the fastest for later launches with the same
+ * the caller's own action arrays where they live (n_batches consecutive action batches laid out as for arcle_step_many: sel
+ * [n_batches][n_envs][...], op [n_batches][n_envs]; a representative stretch of the policy's output — ONE repeated batch is not: the
+ * state degenerates under it; ingress BBOX, BBOX5, POINT, MASK or BITS; flags within ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS)
+ * — a few warm-up and 10 .. 64 timed launches each, walking the batches in order — and keeps the fastest for later launches with the same
  * ingress and flags.  The env state is saved first and restored before every candidate and at the end (a temporary copy of the state
  * in device memory; reward / terminated of the timed launches go to scratch): the handle is left exactly as it was found.  Synchronises
  * the stream; not inside a stream capture.  report (may be NULL): int32 [report_rows][4] = {orders itself, policy, waves per workgroup,
  * ns per launch} per candidate timed.  Returns the number of candidates timed (>= 0) or a negative ARCLE_ERR_* code. */
 int arcle_launch_info(arcle_env* env, int ingress, uint32_t flags, int32_t* out4);
-int arcle_autotune(arcle_env* env, int ingress, const void* sel, const int32_t* op, uint32_t flags, int32_t* report, int32_t report_rows,
-                   void* stream);
+int arcle_autotune(arcle_env* env, int ingress, int32_t n_batches, const void* sel, const int32_t* op, uint32_t flags, int32_t* report,
+                   int32_t report_rows, void* stream);
 
 /* n_steps consecutive step()s of every env in ONE launch — a rollout / trace replay for callers that already hold
  * the whole action sequence (the loop `for a in trace: env.step(a)`, e.g. tests/o2arc_check.py:139-199 of the

@@ -170,7 +170,7 @@ def test_launch_info_and_autotune_keep_state_and_results():
         a.step_bbox(bb[s], op[s], FL), b.step_bbox(bb[s], op[s], FL)
     before = {k: v.clone() for k, v in b.planes.items()}
     rec, cnt = b.rec.clone(), b.cnt.clone()
-    rows = b.autotune("bbox", bb[3], op[3], FL)
+    rows = b.autotune("bbox", bb[3:].contiguous(), op[3:].contiguous(), FL)  # (K - 3 consecutive action batches)
     assert len(rows) >= 6 and rows[0]["us_per_launch"] > 0, rows
     assert any(r["orders_itself"] for r in rows) and any(r["policy"] == "B" for r in rows), rows
     for k in before:
