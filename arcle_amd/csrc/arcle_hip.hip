@@ -1175,7 +1175,11 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, cons
   const size_t n = (size_t)e->cfg.n_envs, pbytes = n * (size_t)e->base.PS, pb = payload_bytes(e, ingress);
   // (the timed launches walk the caller's action batches in order, like arcle_step_many: ONE repeated batch is not a workload — the state
   // degenerates under it and the actions never leave the caches; profiles/round5_policy_autotune.txt)
-  const int n_warm = n_batches < 3 ? 3 : (n_batches < 8 ? n_batches : 8), n_timed = n_batches < 10 ? 10 : (n_batches < 64 ? n_batches : 64);
+  // (... and the warm-up must reach the steady state of the caches: a plan timed 8 launches after the state copy ranks the non-temporal
+  // policies wrongly — 65 536 envs: B 32.2 us measured, 26.3 on a replayed graph; from 48 warm-up launches on the two agree, tools/autotunebench.py)
+  int n_warm = 2 * n_batches < 48 ? 48 : (2 * n_batches < 96 ? 2 * n_batches : 96), n_timed = n_batches < 24 ? 24 : (n_batches < 64 ? n_batches : 64);
+  if (const char* w = getenv("ARCLE_AUTOTUNE_WARM")) n_warm = atoi(w) > 0 ? atoi(w) : n_warm;
+  if (const char* w = getenv("ARCLE_AUTOTUNE_TIMED")) n_timed = atoi(w) > 0 ? atoi(w) : n_timed;
   // scratch: a copy of every plane, the records, the counters; outputs of the timed launches
   int8_t* save_plane[ARCLE_N_PLANES] = {nullptr};
   int8_t* save_rec = nullptr;

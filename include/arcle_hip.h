@@ -293,8 +293,8 @@ int arcle_hint_next_ops(arcle_env* env, const int32_t* next_op, int32_t stride);
  * the caller's own action arrays where they live (n_batches consecutive action batches laid out as for arcle_step_many: sel
  * [n_batches][n_envs][...], op [n_batches][n_envs]; a representative stretch of the policy's output — ONE repeated batch is not: the
  * state degenerates under it; ingress BBOX, BBOX5, POINT, MASK or BITS; flags within ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS)
- * — a few warm-up and 10 .. 64 timed launches each, walking the batches in order — and keeps the fastest for later launches with the same
- * ingress and flags.  The env state is saved first and restored before every candidate and at the end (a temporary copy of the state
+ * — 48 .. 96 warm-up launches (the caches' steady state: fewer mis-rank the non-temporal policies) and 24 .. 64 timed ones each, walking
+ * the batches in order — and keeps the fastest for later launches with the same ingress and flags.  The env state is saved first and restored before every candidate and at the end (a temporary copy of the state
  * in device memory; reward / terminated of the timed launches go to scratch): the handle is left exactly as it was found.  Synchronises
  * the stream; not inside a stream capture.  report (may be NULL): int32 [report_rows][4] = {orders itself, policy, waves per workgroup,
  * ns per launch} per candidate timed.  Returns the number of candidates timed (>= 0) or a negative ARCLE_ERR_* code. */
