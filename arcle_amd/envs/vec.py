@@ -568,6 +568,15 @@ class ARCVecEnv:
         rows_out, reward, term = b.transition_rows(rows, form, pay, op, src_env, out, flags=fl)
         return rows_out[:, :b.state_row_size()], reward, term.view(torch.bool)
 
+    def autotune(self, payload, operation=None, form="bbox"):
+        """Times every launch plan the library has for this env's steps (self-ordering or not, the cache policies of the speculative grid
+        request, 4- or 8-wave workgroups) on K consecutive action batches of the caller — payload [K, N, ...], operation [K, N], device
+        tensors: a representative stretch of the policy's output — and keeps the fastest for the steps that follow (arcle_autotune; the
+        env state is saved and restored, the stream synchronised).  Plain / same-task-autoreset envs; returns the candidates, fastest first."""
+        if self.flags & ~(STEP_AUTORESET | self.batch.elide_flag | STEP_PACK_OBS):
+            raise NotImplementedError("autotune supports plain and same-task autoreset envs (other flag sets keep per-env side state it does not save)")
+        return self.batch.autotune(form, payload, operation, self.flags)
+
     def get_state(self):
         """Checkpoint (cloned device tensors) of the whole batch: states, tasks, counters, task-draw positions."""
         return self.batch.get_state()

@@ -230,3 +230,25 @@ def test_rollout_emits_the_packed_row_of_every_step(n):
     for k in a.planes:
         assert torch.equal(a.planes[k], b.planes[k]), k
     assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt)
+
+
+def test_vec_env_autotune_keeps_results():
+    """ARCVecEnv.autotune on the caller's own action batches: steps afterwards equal an untuned twin's; envs with side-state flag sets refuse."""
+    import torch
+    import bench
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    n, K, dev = 4096, 8, torch.device("cuda:0")
+    bb_np, op_np = bench.make_actions(K, n, 3)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    mk = lambda **kw: ARCVecEnv(O2ARCv2Env, n, SyntheticLoader(n_tasks=30, seed=2, max_size=(30, 30)), device=dev, seed=4, autoreset=True, **kw)
+    va, vb = mk(), mk()
+    va.reset(), vb.reset()
+    plans = vb.autotune(bb, op)
+    assert len(plans) >= 6 and plans[0]["us_per_launch"] <= plans[-1]["us_per_launch"]
+    for s in range(K):
+        oa, ra, ta, _, _ = va.step_bbox(bb[s], op[s])
+        ob, rb, tb, _, _ = vb.step_bbox(bb[s], op[s])
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(oa["grid"], ob["grid"]), s
+    with pytest.raises(NotImplementedError):
+        mk(dense_reward=True).autotune(bb, op)
