@@ -372,13 +372,13 @@ def test_c5_32768_envs_floodfill_vs_oracle():
 
 
 def test_soak_slice():
-    """300 steps of tools/soak.py (every state field after every step vs the oracle: the lean 30x30 instantiations with runtime and
+    """1000 steps of tools/soak.py (every state field after every step vs the oracle: the lean 30x30 instantiations with runtime and
     compile-time flags, FAST / GENERIC width classes, ARCEnv flood fills, 5-tuple / bit-packed ingress, the research flag set with
     the dense cache and incremental rows)."""
-    env = dict(os.environ, SOAK_STEPS="300")
+    env = dict(os.environ, SOAK_STEPS="1000")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py")], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if " S=300" in ln or " S=50" in ln]
+    lines = [ln for ln in p.stdout.splitlines() if " S=1000" in ln or " S=166" in ln]
     assert len(lines) >= 11 and sum(" policy " in ln for ln in p.stdout.splitlines()) == 5, p.stdout
     bad = [ln for ln in lines if ": OK" not in ln]
     assert not bad, "\n".join(bad)
