@@ -574,6 +574,9 @@ struct arcle_env {
   int tuned_valid, tuned_ingress;   // arcle_autotune's choice for (ingress, flags) launches of this handle
   uint32_t tuned_flags;
   LaunchPlan tuned;
+  const void* ptr_seen[4];    // on_device(): the last action arrays asked about, and the answers
+  bool ptr_dev[4];
+  unsigned ptr_next;
   int dense_cache_live;       // the dense-pair cache may hold pairs: 1 a dense step ran since it was last dropped, 2 always assume so (a captured dense step)
   int wpw_override;           // tuning runs: waves per workgroup of the step launches (ARCLE_WPW = 1, 2, 4 or 8), 0 = the library's choice
   int32_t* d_dense_cache;     // int32 [n_envs][2]: dense pair of every env's current grid (allocated with the first dense output)
@@ -986,11 +989,19 @@ static bool grouped_applies(const arcle_env* e, int ingress, const StepParams& p
 
 // A self-ordering launch reads the actions of 32 envs per wave: fine from device memory (one wave's request serves the whole group out of
 // L2), 32 x the PCIe traffic for a payload in pinned host memory (ARCVecEnv.step_bbox5 accepts one) — those keep the scalar per-env loads
-static bool on_device(const void* ptr) {
+// (asked once per array: a loop that steps out of the same action buffers finds its last answers in a four-entry cache of the handle; a
+// wrong answer — an address freed and handed out again as the other kind of memory — costs speed, never correctness: the kernels read both)
+static bool on_device(arcle_env* e, const void* ptr) {
+  for (int i = 0; i < 4; i++)
+    if (e->ptr_seen[i] == ptr && ptr) return e->ptr_dev[i];
   hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, ptr) == hipSuccess) return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
-  (void)hipGetLastError();
-  return false;
+  bool dev = false;
+  if (hipPointerGetAttributes(&attr, ptr) == hipSuccess) dev = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  else (void)hipGetLastError();
+  e->ptr_seen[e->ptr_next & 3] = ptr;
+  e->ptr_dev[e->ptr_next & 3] = dev;
+  e->ptr_next++;
+  return dev;
 }
 
 // Which batches request the grid plane speculatively, and with which cache policies (profiles/round4_experiments.txt; sweeps in
@@ -1111,7 +1122,7 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     p.pack_out = e->pack_out;
   }
   // (a self-ordering launch reads the actions of 32 envs per wave: only from device memory, see on_device)
-  const bool dev_payload = grouped_applies(e, ingress, p) && on_device(sel) && (ingress == arcle::INGRESS_BBOX5 || on_device(op));
+  const bool dev_payload = grouped_applies(e, ingress, p) && on_device(e, sel) && (ingress == arcle::INGRESS_BBOX5 || on_device(e, op));
   const LaunchPlan pl = plan_launch(e, ingress, p, dev_payload);
   p.spec_grid = pl.policy;
   p.wpw = pl.wpw;
@@ -1216,7 +1227,7 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, cons
           StepParams probe = e->base;
           probe.flags = flags;
           e->forced = &cand;
-          const bool dev_payload = on_device(sel) && (ingress == arcle::INGRESS_BBOX5 || on_device(op));
+          const bool dev_payload = on_device(e, sel) && (ingress == arcle::INGRESS_BBOX5 || on_device(e, op));
           const LaunchPlan got = plan_launch(e, ingress, probe, dev_payload);
           if (got.policy == cand.policy && got.wpw == cand.wpw && got.grouped == cand.grouped) {
             float ms = 0.f;
