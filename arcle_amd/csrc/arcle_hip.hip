@@ -624,7 +624,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   }
   e->group_enabled = 1;
   e->group_min = 2049;
-  e->group_max = 12288;
+  e->group_max = 10240;
   e->group_wpw = 4;
   if (const char* gs = getenv("ARCLE_GROUPED")) e->group_enabled = atoi(gs) != 0;
   if (const char* gs = getenv("ARCLE_GROUP_MIN")) e->group_min = atoi(gs);
@@ -1057,6 +1057,9 @@ static LaunchPlan plan_launch(const arcle_env* e, int ingress, const StepParams&
     // ... and for a batch of at most one occupancy round whose launch has no front workgroups to carry (no records to prefetch): 5.40 -> 5.35 us
     // at 8192 envs, 4.28 -> 4.25 at 4096; from 16384 envs on 8 waves are the better shape (profiles/round4_experiments.txt §9)
     if (!e->wpw_override && pl.wpw == WAVES_PER_WG && p.n_envs <= 8192 && !e->pf_next) pl.wpw = 4;
+    // ... round 5, the lean bbox / record kernel between 8192 and 65536 envs as well: 4-wave workgroups 2-4 % ahead of 8 at 12 288 … 49 152
+    // envs whatever the policy (profiles/round5_experiments.txt §4c: e.g. 32 768 envs plain 13.2 vs 13.7 us, 40 960 B 17.4 vs 17.6)
+    if (!e->wpw_override && any_policy && !e->pf_next) pl.wpw = 4;
     // self-ordering launches inside the window they were measured to win in with a cache-resident action stream (profiles/round5_experiments.txt)
     pl.grouped = p.n_envs >= e->group_min && p.n_envs <= e->group_max;
     if (pl.grouped && can_group && !e->wpw_override) pl.wpw = e->group_wpw;

@@ -54,7 +54,7 @@ def _streams(K, n, seed):
 
 
 @pytest.mark.parametrize("variant", ["bbox", "point", "bbox5", "bbox_pack", "bbox5_pack"])
-@pytest.mark.parametrize("n", [2304, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [2304, 4096, 8192, 16384, 66560])
 def test_grouped_launches_are_scheduling_only(variant, n):
     import torch
     import bench
@@ -66,7 +66,7 @@ def test_grouped_launches_are_scheduling_only(variant, n):
     act5 = torch.cat([bb, op[:, :, None]], 2).contiguous()
     with _Env(ARCLE_GROUPED=0):
         a = bench.make_batch(dev, n, seed=11)
-    with _Env(ARCLE_GROUPED=1, ARCLE_GROUP_MIN=0):
+    with _Env(ARCLE_GROUPED=1, ARCLE_GROUP_MIN=0, ARCLE_GROUP_MAX=10000000):  # (every size here takes the self-ordering launch where it structurally can)
         b = bench.make_batch(dev, n, seed=11)
     FL = a.elide_flag | 1
     pa = pb = None
