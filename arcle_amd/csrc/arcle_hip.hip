@@ -1,7 +1,9 @@
 // arcle_hip.hip — gfx950 kernels + the C ABI of include/arcle_hip.h  (libarcle_hip.so)
 //
 // Kernels (bodies in arcle_wave.h; one wavefront per env everywhere)
-//   arcle_step_kernel          one step() of every env; 8 waves per workgroup (4 from 65536 envs on)
+//   arcle_step_kernel          one step() of every env; 4 or 8 waves per workgroup (plan_launch); the launches of the standard batch order
+//                              themselves inside groups of 32 envs (the GROUPED block)
+//   arcle_transition_rows_kernel  the stateless transition(state, action) on flattened state rows
 //   arcle_rollout_kernel       n_steps step()s per launch with the env state resident in registers
 //   arcle_reset[_table]_kernel init_state for (masked) envs, optionally from the device task table / device-drawn tasks
 //   arcle_flatten_kernel       flattened observation rows (also an epilogue of the step kernel: ARCLE_STEP_FLAT_OBS)
