@@ -115,6 +115,8 @@ ARCLE_DEV void store_at(void* base, uint32_t off, const T& v) {
   asm volatile("" : "+v"(off));  // (the offset lives in a VGPR from here on)
   typedef std::conditional_t<sizeof(T) == 16, U4, std::conditional_t<sizeof(T) == 8, U2, std::conditional_t<sizeof(T) == 4, uint32_t, uint8_t>>> R;
   static_assert(sizeof(R) == sizeof(T), "16 / 8 / 4 / 1 byte values");
+  // (plain write-back stores: written THROUGH (`sc1`) these few bytes per wave are one fabric write each and the kernel runs 3.8 -> 5.05 us,
+  // while the ~1 us between two launches does not shrink — profiles/round5_launch_trace.txt)
   *reinterpret_cast<ARCLE_AS_GLOBAL R*>((uintptr_t)base + off) = __builtin_bit_cast(R, v);
 }
 // release at SYSTEM scope + the store: everything this wave stored before (vmcnt is per wave: all lanes' stores) is visible to the host
@@ -399,6 +401,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     }
     in.op = xl::readlane(vop, pos);
     arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, my_env, in, 0, 0, false, arcle::u4_zero());
+#ifdef ARCLE_TRACE_WAVES  // (diagnostic builds, tools/launchtrace.py: when this wave entered and left, into the launch's half of the trace buffer)
+    if (pa.acct && (threadIdx.x & 63u) == 0) {
+      uint64_t* tr = reinterpret_cast<uint64_t*>(pa.acct) + 2 * ((size_t)(pa.n_steps & 1) * (size_t)pa.n_envs + (size_t)my_env);
+      tr[0] = t_entry;
+      tr[1] = xl::clock();
+    }
+#endif
     return;
   }
   const int wv = wave_of_launch(wpw, nb8, pf_off);
@@ -439,6 +448,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
 #endif
 #ifdef ARCLE_TRACE_WAVES
   arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in, t_entry, xl::clock());
+  if (!ACCT && pa.acct && (threadIdx.x & 63u) == 0) {  // (the lean kernels: entry / exit of the wave, as in the self-ordering branch)
+    uint64_t* tr = reinterpret_cast<uint64_t*>(pa.acct) + 2 * ((size_t)(pa.n_steps & 1) * (size_t)pa.n_envs + (size_t)env);
+    tr[0] = t_entry;
+    tr[1] = xl::clock();
+  }
 #else
   arcle::wave_step<ING, FW, ACCT, FEAT, FL>(w, env, in, 0, 0, early, early_grid);
 #endif
@@ -576,6 +590,10 @@ struct arcle_env {
   int tuned_valid, tuned_ingress;   // arcle_autotune's choice for (ingress, flags) launches of this handle
   uint32_t tuned_flags;
   LaunchPlan tuned;
+#ifdef ARCLE_TRACE_WAVES
+  uint64_t* d_trace;          // diagnostic builds: uint64 [2][n_envs][2] entry / exit clocks of the waves of the last two launches
+  int trace_seq;
+#endif
   const void* ptr_seen[4];    // on_device(): the last action arrays asked about, and the answers
   bool ptr_dev[4];
   unsigned ptr_next;
@@ -1111,6 +1129,12 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   p.term = term;
   p.flags = flags;
   p.acct = e->d_acct;
+#ifdef ARCLE_TRACE_WAVES
+  if (!e->d_acct && e->d_trace) {
+    p.acct = reinterpret_cast<uint32_t*>(e->d_trace);
+    p.n_steps = e->trace_seq++;
+  }
+#endif
   p.rmask = nullptr;
   p.next_sel = e->pf_next;
   p.stage_out = e->pf_stage;
@@ -1767,7 +1791,25 @@ extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   return ARCLE_OK;
 }
 
-#ifdef ARCLE_TRACE_WAVES  // diagnostic builds only (tools/wavetrace.py); absent from the shipped library and from the header
+#ifdef ARCLE_TRACE_WAVES  // diagnostic builds only (tools/wavetrace.py, tools/launchtrace.py); absent from the shipped library and from the header
+// entry / exit clocks (100 MHz) of every wave of the last two step launches of the LEAN kernels (no accounting): host_out uint64 [2][n_envs][2],
+// half (seq & 1) written by launch number seq; *last_seq = the number of the most recent launch
+extern "C" int arcle_debug_launch_trace(arcle_env* e, int enable, uint64_t* host_out, int* last_seq) {
+  if (!e) return ARCLE_ERR_ARG;
+  DeviceGuard guard(e->device);
+  const size_t bytes = (size_t)e->cfg.n_envs * 2 * 2 * sizeof(uint64_t);
+  if (enable && !e->d_trace) {
+    HIP_TRY(e, hipMalloc((void**)&e->d_trace, bytes));
+    HIP_TRY(e, hipMemset(e->d_trace, 0, bytes));
+    e->trace_seq = 0;
+  }
+  if (host_out && e->d_trace) {
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(host_out, e->d_trace, bytes, hipMemcpyDeviceToHost));
+    if (last_seq) *last_seq = e->trace_seq - 1;
+  }
+  return ARCLE_OK;
+}
 extern "C" int arcle_debug_copy_trace(arcle_env* e, uint64_t* host_out) {  // diagnostic builds only
   if (!e || !e->d_acct) return ARCLE_ERR_ARG;
   HIP_TRY(e, hipDeviceSynchronize());
