@@ -1091,6 +1091,13 @@ static LaunchPlan plan_launch(const arcle_env* e, int ingress, const StepParams&
   return pl;
 }
 
+// (env kinds without a `selected` plane: the zero-fill elision is vacuous, see launch_step — the flag set a launch really runs with)
+static uint32_t effective_flags(const arcle_env* e, uint32_t flags) {
+  if (!e->bufs.plane[ARCLE_PL_SELECTED] && (flags & ARCLE_STEP_AUTORESET) && !(flags & ~(uint32_t)(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_PACK_OBS)))
+    flags |= ARCLE_STEP_ELIDE_SELECTED;
+  return flags;
+}
+
 static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t* op, int32_t* reward, uint8_t* term,
                        uint32_t flags, void* stream) {
   if (!e || !sel || (!op && ingress != arcle::INGRESS_BBOX5) || !reward || !term) return ARCLE_ERR_ARG;
@@ -1119,8 +1126,7 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   // env kinds without a `selected` plane (ARCEnv, RawARCEnv: no table of theirs can hold a reset_sel-wrapped op — arcle_set_op_table
   // rejects it): the zero-fill elision is vacuous there, so an auto-resetting step of such a handle takes the same lean instantiations
   // as the O2ARC batch (ARCVecEnv's flag set) instead of the runtime-flag kernel
-  if (!e->bufs.plane[ARCLE_PL_SELECTED] && (flags & ARCLE_STEP_AUTORESET) && !(flags & ~(uint32_t)(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_PACK_OBS)))
-    flags |= ARCLE_STEP_ELIDE_SELECTED;
+  flags = effective_flags(e, flags);
   StepParams p = e->base;
   p.ingress = ingress;
   p.sel = sel;
@@ -1181,6 +1187,7 @@ static size_t payload_bytes(const arcle_env* e, int ingress);
 extern "C" int arcle_launch_info(arcle_env* e, int ingress, uint32_t flags, int32_t* out4) {
   if (!e || !out4) return ARCLE_ERR_ARG;
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
+  flags = effective_flags(e, flags);
   StepParams p = e->base;
   p.flags = flags;
   p.flat_stride = e->flat_stride;
@@ -1254,7 +1261,7 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, cons
           LaunchPlan cand = {policies[pi], wpw, grouped};
           // does the candidate survive planning unchanged?  (a policy / the grouping the launch cannot take is not a candidate)
           StepParams probe = e->base;
-          probe.flags = flags;
+          probe.flags = effective_flags(e, flags);
           e->forced = &cand;
           const bool dev_payload = on_device(e, sel) && (ingress == arcle::INGRESS_BBOX5 || on_device(e, op));
           const LaunchPlan got = plan_launch(e, ingress, probe, dev_payload);
@@ -1300,7 +1307,7 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, cons
   if (best_ms >= 0.f) {
     e->tuned = best;
     e->tuned_ingress = ingress;
-    e->tuned_flags = flags;
+    e->tuned_flags = effective_flags(e, flags);
     e->tuned_valid = 1;
   }
   return rows;

@@ -252,3 +252,21 @@ def test_vec_env_autotune_keeps_results():
         assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(oa["grid"], ob["grid"]), s
     with pytest.raises(NotImplementedError):
         mk(dense_reward=True).autotune(bb, op)
+
+
+def test_autotune_on_an_env_kind_without_selected_plane():
+    """ARCEnv handles (no `selected` plane: the launcher adds the vacuous elision flag itself) keep the tuned plan too, and step the same."""
+    import torch
+    import bench
+    n, K, dev = 4096, 8, torch.device("cuda:0")
+    bb_np, op_np = bench.make_actions_c5(K, n, 3)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    a, b = bench.make_batch(dev, n, seed=5, kind="arc"), bench.make_batch(dev, n, seed=5, kind="arc")
+    rows = b.autotune("bbox", bb, op, 1)
+    assert rows and b.launch_info("bbox", 1)["autotuned"] and not a.launch_info("bbox", 1)["autotuned"]
+    for s in range(K):
+        ra, ta = a.step_bbox(bb[s], op[s], 1)
+        rb, tb = b.step_bbox(bb[s], op[s], 1)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb), s
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), k
