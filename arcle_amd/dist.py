@@ -20,6 +20,10 @@ the step stream.  Three ways to keep it off the critical path, all provided here
   * `every=K`         learners that consume K steps at a time: rows of K steps accumulate in one [K, n, R] buffer (the step kernel
                       writes slot t % K directly) and move with one K-times-larger collective — link latency paid once per K steps.
 `capture()` records step + collective of K steps into one hipGraph (RCCL collectives are capturable); replay = one host call.
+
+Every call works on torch's CURRENT stream, so ping-pong groups can also be given a HIP stream each (`with torch.cuda.stream(s[g]):
+env.step_bbox(..., group=g)`): two free-running groups on two queues overlap one group's launch turnaround and tail with the other's ramp —
+16 384 envs as 2 x 8192: 7.2 instead of 9.0-9.3 us per step of all envs (profiles/round5_experiments.txt §11); groups of 4096 or fewer lose.
 """
 import torch
 import torch.distributed as dist
