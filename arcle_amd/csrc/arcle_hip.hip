@@ -338,8 +338,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     const uint32_t gfirst = (uint32_t)xl::mul24s(rs, (int)(vb & 7u) - (int)j) + (s_local << 5);
     const uint32_t js = xl::uniform(j), gfirst_s = xl::uniform(gfirst);
     arcle::Wave w(p, &tiles[threadIdx.x >> 6], nullptr, (int)(threadIdx.x & 63), ING, FW, false, ACCT != 0, false);
-    static_assert(arcle::is_tuple(ING) && ING != arcle::INGRESS_BBOX5_PF, "grouped launches: bbox / point tuples and 5-tuple records");
-    constexpr bool REC5 = ING == arcle::INGRESS_BBOX5;
+    static_assert(ING != arcle::INGRESS_BBOX5_PF, "grouped launches: tuples, 5-tuple records, masks — not the record-prefetching form");
+    constexpr bool REC5 = ING == arcle::INGRESS_BBOX5, CELLS = arcle::is_cells(ING);  // (masks / bit-packed masks: the payload is per cell — fetched for the slot's env once it is known)
     constexpr bool BY_LIMIT = (FL & ARCLE_STEP_TRUNCATE) != 0;  // (the research step: an env about to be re-initialised counts as long: its auto-reset is that kernel's longest wave)
     // the group's inputs: lanes 0-31 read the 32 op indices (the upper half repeats them); records (16 B per env), bbox tuples (16 B), point
     // tuples and counters (8 B) as ONE contiguous block per array spread over the 64 lanes — env e's item in lanes 2 e, 2 e + 1
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     const uint32_t vop = REC5 ? xl::load32(sel, 20u * (gfirst + e) + 16u) : xl::load32(op, (gfirst + e) << 2);
     const xl::U2 vrec = xl::load8(rec, (gfirst << 4) + (lane << 3));
     xl::U4 vsel = {0u, 0u, 0u, 0u};
-    if constexpr (REC5) vsel = xl::load16u_at(sel, 20u * (gfirst + e));  // (records are only dword aligned; per lane e)
+    if constexpr (CELLS) {
+    } else if constexpr (REC5) vsel = xl::load16u_at(sel, 20u * (gfirst + e));  // (records are only dword aligned; per lane e)
     else if constexpr (ING == arcle::INGRESS_BBOX) {
       const xl::U2 t = xl::load8(sel, (gfirst << 4) + (lane << 3));
       vsel[0] = t[0], vsel[1] = t[1];
@@ -379,7 +380,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_num_sgpr(A
     in.rec[1] = xl::readlane(vrec[1], h);
     in.rec[2] = xl::readlane(xl::quad_bcast_odd(vrec[0]), h);
     in.rec[3] = xl::readlane(xl::quad_bcast_odd(vrec[1]), h);
-    if constexpr (REC5) {
+    if constexpr (CELLS) {
+      in.payload = arcle::load_payload(w, my_env, 0, sel);
+    } else if constexpr (REC5) {
 #pragma unroll
       for (int k = 0; k < 4; k++) in.payload[k] = xl::readlane(vsel[k], pos);
     } else if constexpr (ING == arcle::INGRESS_BBOX) {
@@ -944,9 +947,7 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
           return;
         }
       }
-      if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5 || ING == arcle::INGRESS_POINT) {
-        if (p.group_magic && p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_FLAGS, 0); return; }
-      }
+      if (p.group_magic && p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_FLAGS, 0); return; }  // (every ingress form)
       if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
         if (p.group_magic && p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_PACK_FLAGS, 0); return; }
         if (p.group_magic && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) { LAUNCH_GROUPED(ING, FW, RESEARCH_INC_FL, 1); return; }
@@ -995,7 +996,7 @@ static bool grouped_instantiation(int ingress, const StepParams& p) {
   return ingress == arcle::INGRESS_BBOX && p.flags == (uint32_t)HOT_FLAGS;
 #else
   const bool tuple5 = ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5;
-  if (p.flags == (uint32_t)HOT_FLAGS) return tuple5 || ingress == arcle::INGRESS_POINT;
+  if (p.flags == (uint32_t)HOT_FLAGS) return true;  // (tuples, records, int8 and bit-packed masks)
   if (p.flags == (uint32_t)HOT_PACK_FLAGS) return tuple5;
   return tuple5 && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL);
 #endif

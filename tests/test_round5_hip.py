@@ -270,3 +270,46 @@ def test_autotune_on_an_env_kind_without_selected_plane():
         assert torch.equal(ra, rb) and torch.equal(ta, tb), s
     for k in a.planes:
         assert torch.equal(a.planes[k], b.planes[k]), k
+
+
+@pytest.mark.parametrize("form", ["mask", "bits"])
+@pytest.mark.parametrize("n", [2304, 8192])
+def test_grouped_launches_with_mask_ingress(form, n):
+    """Full int8 masks and bit-packed masks order themselves too (the mask of the slot's env is fetched once the env is known): identical to
+    the plain launches, adversarial op streams included."""
+    import torch
+    import bench
+    K, dev = 10, torch.device("cuda:0")
+    bb_np, op_np = _streams(K, n, 5 + n)
+    op = torch.from_numpy(op_np).to(dev)
+    bb = torch.from_numpy(bb_np).to(dev)
+    # rectangle masks of the bbox tuples (BBoxWrapper.action, bbox.py:22-30), a few cells set to 2 / -1 so that they are not plain wrapper masks
+    r = torch.arange(30, device=dev)
+    x1, x2 = torch.minimum(bb[..., 0], bb[..., 2]), torch.maximum(bb[..., 0], bb[..., 2])
+    y1, y2 = torch.minimum(bb[..., 1], bb[..., 3]), torch.maximum(bb[..., 1], bb[..., 3])
+    rows = (r[None, None, :] >= x1[..., None]) & (r[None, None, :] <= x2[..., None])
+    cols = (r[None, None, :] >= y1[..., None]) & (r[None, None, :] <= y2[..., None])
+    masks = (rows[..., :, None] & cols[..., None, :]).to(torch.int8)
+    if form == "mask":
+        masks[:, ::7, 3, 4] = 2
+        masks[:, ::11, 0, 0] = -1
+    with _Env(ARCLE_GROUPED=0):
+        a = bench.make_batch(dev, n, seed=9)
+    b = bench.make_batch(dev, n, seed=9)
+    FL = a.elide_flag | 1
+    assert b.launch_info(form, FL)["orders_itself"] and not a.launch_info(form, FL)["orders_itself"]
+    for s in range(K):
+        if form == "mask":
+            ra, ta = a.step_mask(masks[s], op[s], FL)
+            ra, ta = ra.clone(), ta.clone()
+            rb, tb = b.step_mask(masks[s], op[s], FL)
+        else:
+            bits = a.pack_mask_bits(masks[s])
+            ra, ta = a.step_bits(bits, op[s], FL)
+            ra, ta = ra.clone(), ta.clone()
+            rb, tb = b.step_bits(bits, op[s], FL)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb), (form, n, s)
+    torch.cuda.synchronize()
+    for k in a.planes:
+        assert torch.equal(a.planes[k], b.planes[k]), (form, n, k)
+    assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt) and a.status() == b.status()
