@@ -665,7 +665,8 @@ def ingress_leg(dev, n, bbox, op, K=64):
         out[form + "_payload_cache_resident_us"] = sec_warm * 1e6
         out[form] = {"value": n / sec, "unit": "env-steps/s", "us_per_step_batch": sec * 1e6,
                      "payload_bytes_per_env": 900 if form == "mask" else 128,
-                     "roofline": roofline_block(f"arcle_step_kernel<{form}, FULL, 0, 0, autoreset|elide, 30>", sec, alg, issued, n)}
+                     "roofline": roofline_block(f"arcle_step_kernel<{form}, FULL, 0, 0, autoreset|elide{'|grouped' if batch.orders_itself(form, FL) else ''}, 30>",
+                                                sec, alg, issued, n, plan=batch.launch_info(form, FL))}
     batch = make_batch(dev, n)
     sec, _ = graph_time(dev, lambda sh: [batch.pack_mask_bits(masks[i], pay[i]) for i in range(K)], K)
     out["pack_mask_bits_us"] = sec * 1e6
