@@ -948,6 +948,10 @@ static void launch_step_tbl(bool acct, bool feat, dim3 g, dim3 b, hipStream_t st
         }
       }
       if (p.group_magic && p.flags == (uint32_t)HOT_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_FLAGS, 0); return; }  // (every ingress form)
+      if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5 || ING == arcle::INGRESS_POINT) {
+        // ... and without the auto-reset: what ARCVecEnv steps with by default (the reference has none: a terminated env keeps being mutated)
+        if (p.group_magic && p.flags == (uint32_t)ARCLE_STEP_ELIDE_SELECTED) { LAUNCH_GROUPED(ING, FW, ARCLE_STEP_ELIDE_SELECTED, 0); return; }
+      }
       if constexpr (ING == arcle::INGRESS_BBOX || ING == arcle::INGRESS_BBOX5) {
         if (p.group_magic && p.flags == (uint32_t)HOT_PACK_FLAGS) { LAUNCH_GROUPED(ING, FW, HOT_PACK_FLAGS, 0); return; }
         if (p.group_magic && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL)) { LAUNCH_GROUPED(ING, FW, RESEARCH_INC_FL, 1); return; }
@@ -997,6 +1001,7 @@ static bool grouped_instantiation(int ingress, const StepParams& p) {
 #else
   const bool tuple5 = ingress == arcle::INGRESS_BBOX || ingress == arcle::INGRESS_BBOX5;
   if (p.flags == (uint32_t)HOT_FLAGS) return true;  // (tuples, records, int8 and bit-packed masks)
+  if (p.flags == (uint32_t)ARCLE_STEP_ELIDE_SELECTED) return tuple5 || ingress == arcle::INGRESS_POINT;  // (ARCVecEnv without autoreset)
   if (p.flags == (uint32_t)HOT_PACK_FLAGS) return tuple5;
   return tuple5 && research_shape(p, ARCLE_STEP_ROWS_INCREMENTAL);
 #endif

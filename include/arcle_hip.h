@@ -274,8 +274,8 @@ int arcle_step_many(arcle_env* env, int ingress, int32_t n_steps, const void* se
  * other operations' waves, and the hardware starts the waves of a launch over ~2 us), so the library hands the object operations to
  * the waves that start first.  Since ABI 5 every launch does that for ITSELF, from the operations it is about to execute: the standard
  * 30 x 30 batch (plane stride 1024) stepped through arcle_step_bbox / _bbox5 / _point / _mask / _bits — and arcle_step_many over them — with
- * the flag set ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED; bbox / bbox5 also with the same + ARCLE_STEP_PACK_OBS or the research env's
- * set with incremental FilterO2ARC rows; n_envs a multiple of 256 in [2304, 10240], actions in DEVICE memory, an op table with object operations, no byte
+ * the flag set ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED; the tuple forms also with ARCLE_STEP_ELIDE_SELECTED alone (no auto-reset);
+ * bbox / bbox5 also with ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS or the research env's set with incremental FilterO2ARC rows; n_envs a multiple of 256 in [2304, 10240], actions in DEVICE memory, an op table with object operations, no byte
  * accounting.  Waves of a group of 32 consecutive envs read the group's 32 actions and permute the group among their 32 dispatch slots
  * (arcle_step_kernel, GROUPED).  Scheduling only: every env is stepped exactly once whatever the operations are; results, outputs and
  * their layout are those of the plain launch.  No tables, no extra memory, nothing to allocate before a stream capture.

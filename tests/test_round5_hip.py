@@ -53,7 +53,7 @@ def _streams(K, n, seed):
     return bb, op
 
 
-@pytest.mark.parametrize("variant", ["bbox", "point", "bbox5", "bbox_pack", "bbox5_pack"])
+@pytest.mark.parametrize("variant", ["bbox", "point", "bbox5", "bbox_pack", "bbox5_pack", "bbox_noreset", "point_noreset", "bbox5_noreset"])
 @pytest.mark.parametrize("n", [2304, 4096, 8192, 16384, 66560])
 def test_grouped_launches_are_scheduling_only(variant, n):
     import torch
@@ -68,14 +68,15 @@ def test_grouped_launches_are_scheduling_only(variant, n):
         a = bench.make_batch(dev, n, seed=11)
     with _Env(ARCLE_GROUPED=1, ARCLE_GROUP_MIN=0, ARCLE_GROUP_MAX=10000000):  # (every size here takes the self-ordering launch where it structurally can)
         b = bench.make_batch(dev, n, seed=11)
-    FL = a.elide_flag | 1
+    FL = a.elide_flag | (0 if variant.endswith("_noreset") else 1)  # (_noreset: ARCVecEnv's default flag set — terminated envs keep being stepped)
+    assert b.launch_info("bbox5" if variant.startswith("bbox5") else variant.split("_")[0], FL | (STEP_PACK_OBS if variant.endswith("_pack") else 0))["orders_itself"]
     pa = pb = None
     if variant.endswith("_pack"):
         FL |= STEP_PACK_OBS
         pa, pb = a.set_packed_output(), b.set_packed_output()
 
     def one(batch, s):
-        if variant == "point":
+        if variant.startswith("point"):
             return batch.step_point(xy[s], op[s], FL)
         if variant.startswith("bbox5"):
             return batch.step_bbox5(act5[s], FL)
