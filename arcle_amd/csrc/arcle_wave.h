@@ -1013,15 +1013,22 @@ ARCLE_DEV void op_floodfill(const Wave& w, Scratch& s, const Rec& r, const Sel& 
     const uint32_t P4d = P2d & xl::row_prev<2>(P2d), P4u = P2u & xl::row_next<2>(P2u);
     const uint32_t P8d = P4d & xl::row_prev<4>(P4d), P8u = P4u & xl::row_next<4>(P4u);
     uint32_t F = (w.lane == sx) ? (1u << sy) : 0u;
+#ifndef ARCLE_FILL_UNROLL
+#define ARCLE_FILL_UNROLL 2  // passes per convergence ballot: two save a compare + ballot + branch per pair of passes on the launch's longest waves and
+                             // cost at most one idle pass at the end (c5 5.57 -> 5.40 us; 3: 5.46; the C3 mix unchanged — profiles/round5_experiments.txt §14)
+#endif
     for (int it = 0; it < 2 * ARCLE_MAX_CELLS; it++) {  // one pass = vertical steps of 1, 2, 4, 8 rows (up to 15 rows of a run), then
       const uint32_t F0 = F;                            // the horizontal fill of every row; one convergence ballot per pass
-      F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;   // rows i-1 / i+1 (0 beyond the wave)
-      F |= (xl::row_prev<2>(F) & P2d) | (xl::row_next<2>(F) & P2u);
-      F |= (xl::row_prev<4>(F) & P4d) | (xl::row_next<4>(F) & P4u);
-      F |= (xl::row_prev<8>(F) & P8d) | (xl::row_next<8>(F) & P8u);
-      F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;   // (again: lets a run cross the 16-lane row boundary in the same pass)
-      const uint32_t rF = xl::bfrev(F);
-      F |= ((M ^ (M + F)) & M) | xl::bfrev((rM ^ (rM + rF)) & rM);
+#pragma unroll
+      for (int u = 0; u < ARCLE_FILL_UNROLL; u++) {
+        F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;   // rows i-1 / i+1 (0 beyond the wave)
+        F |= (xl::row_prev<2>(F) & P2d) | (xl::row_next<2>(F) & P2u);
+        F |= (xl::row_prev<4>(F) & P4d) | (xl::row_next<4>(F) & P4u);
+        F |= (xl::row_prev<8>(F) & P8d) | (xl::row_next<8>(F) & P8u);
+        F |= (xl::lane_prev(F) | xl::lane_next(F)) & M;   // (again: lets a run cross the 16-lane row boundary in the same pass)
+        const uint32_t rF = xl::bfrev(F);
+        F |= ((M ^ (M + F)) & M) | xl::bfrev((rM ^ (rM + rF)) & rM);
+      }
       if (!w.any(F != F0)) break;
     }
     vis = rows_to16(w, F, Wb);
