@@ -10,8 +10,11 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("ARCLE_HIP_LIB") or os.path.join(_CSRC, "libarcle_hip.so")  # override: A/B kernel tuning
-SOURCES = [os.path.join(_CSRC, "arcle_hip.hip"), os.path.join(_CSRC, "arcle_wave.h"),
-           os.path.join(_CSRC, "..", "..", "include", "arcle_hip.h")]
+# two translation units: the one-wavefront-per-env kernels + the C ABI (arcle_hip.hip <- arcle_wave.h) and the workgroup-per-env kernels
+# for grids of more than 1024 cells (arcle_big.hip <- arcle_big.h); arcle_big_params.h is shared
+UNITS = [os.path.join(_CSRC, "arcle_hip.hip"), os.path.join(_CSRC, "arcle_big.hip")]
+SOURCES = UNITS + [os.path.join(_CSRC, "arcle_wave.h"), os.path.join(_CSRC, "arcle_big.h"), os.path.join(_CSRC, "arcle_big_params.h"),
+                   os.path.join(_CSRC, "..", "..", "include", "arcle_hip.h")]
 
 ABI_VERSION = 5
 N_PLANES = 8
@@ -52,11 +55,23 @@ def build(force=False, verbose=False):
         raise ArcleHipError("hipcc not found: cannot build libarcle_hip.so")
     # -amdgpu-kernarg-preload-count: the step kernel's leading scalar arguments (the four per-env array bases, batch size, launch
     # shape) are in SGPRs when a wave starts instead of behind a scalar load of the argument block
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-kernarg-preload-count=13",
-           "-o", LIB_PATH, SOURCES[0]]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    objs = [os.path.join(_CSRC, os.path.basename(u)[:-4] + ".o") for u in UNITS]
+    cmds = [common + ["-mllvm", "-amdgpu-kernarg-preload-count=13", "-c", UNITS[0], "-o", objs[0]],
+            common + ["-c", UNITS[1], "-o", objs[1]]]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        for c in cmds:
+            print(" ".join(c))
+    procs = [subprocess.Popen(c) for c in cmds]  # (the two units compile side by side: the first takes minutes, the second seconds)
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise ArcleHipError(f"hipcc failed ({rcs})")
+    link = common + ["-shared", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    for o in objs:
+        os.remove(o)
     return LIB_PATH
 
 

@@ -1,0 +1,1072 @@
+// arcle_big.h — the step / reset / row kernels' bodies for grids BEYOND one wavefront: H * W > ARCLE_MAX_CELLS (1024 cells),
+// H, W <= 127 (grid dims are int8 in the reference's state dict, base.py:162-166).  The reference takes any max_grid_size
+// (/root/reference/arcle/envs/base.py:37-49); ARC itself never exceeds 30 x 30, so this is the completeness path, not the headline:
+// the 30 x 30 batch keeps its one-wavefront-per-env kernels (arcle_wave.h).
+//
+// Execution model — ONE WORKGROUP per env (256 threads = 4 wavefronts on gfx950):
+//   * a plane is PS = H*W rounded up to 128 bytes; thread t owns the 16-byte chunks t, t + NT, t + 2 NT ... of it: every global plane
+//     access is one aligned 16 B load / store per thread, consecutive threads on consecutive chunks (fully coalesced);
+//   * the selection and up to three planes are staged in the workgroup's LDS (4 x PS bytes, dynamic: 6.5 KB at 40 x 40, 64 KB at
+//     127 x 127), geometric ops (object lift / place, Rotate / Flip, Copy / Paste / Crop) gather single cells from those tiles and write
+//     whole chunks back;
+//   * reductions (any / sum / arg-max / bounding box of the selection, grid == answer) are LDS atomics + a workgroup barrier;
+//   * FloodFill runs on 128-bit row boards (one thread per row): a pass pulls the fill from the rows above and below and spreads it along
+//     the row's eligible runs with the carry trick (E + F ripples through a run of ones), until no row changes;
+//   * per-env scalars (the 16-byte record, counters, op descriptor) are loaded by every thread — the same address, one broadcast
+//     request — and kept replicated in registers; thread 0 writes them back.
+// All control flow around barriers is workgroup-uniform (it depends only on the env's record, the op and the reduced selection).
+//
+// The same header is compiled by hipcc for gfx950 (arcle_big.hip) and by g++ for tests/emu/big_emu.cpp, which runs the body on host
+// threads with a pthread barrier as the workgroup barrier — test infrastructure, never part of the product.
+//
+// Reference semantics restated here are cited per function (paths relative to /root/reference); they are the ones arcle_wave.h cites.
+#pragma once
+#include <stdint.h>
+
+#include "arcle_big_params.h"
+
+#if !defined(ARCLE_BIG_DEV)
+#error "include through arcle_big.hip (or the test emulator), which defines ARCLE_BIG_DEV and namespace bx"
+#endif
+
+namespace arcle_big {
+
+struct alignas(16) V16 {
+  uint32_t w[4];
+};
+union Chunk {
+  V16 v;
+  uint32_t w[4];
+  int8_t b[16];
+  uint8_t u[16];
+};
+struct Red {  // reduction block in LDS (64 bytes)
+  int32_t any_nz, any_pos, sum;
+  uint32_t amax;  // (value + 128) << 16 | (0xffff - cell): max value, first occurrence (np.argmax)
+  int32_t x0, x1, y0, y1;
+  int32_t neq;      // grid != answer somewhere / selection != selected somewhere
+  int32_t flag[2];  // FloodFill: some row changed in pass k (slot k & 1)
+  int32_t pad[5];
+};
+struct B128 {
+  uint64_t lo, hi;
+};
+
+ARCLE_BIG_DEV int i8w(int x) { return (int)(int8_t)(uint8_t)(x & 0xff); }  // wrap to int8 (NumPy int8 arithmetic)
+ARCLE_BIG_DEV int imin(int a, int b) { return a < b ? a : b; }
+ARCLE_BIG_DEV int imax(int a, int b) { return a > b ? a : b; }
+ARCLE_BIG_DEV int floordiv2(int a) { return a >> 1; }  // floor toward -inf (arithmetic shift)
+
+ARCLE_BIG_DEV Chunk ldg(const int8_t* base, int c) {
+  Chunk o;
+  o.v = *reinterpret_cast<const V16*>(base + 16 * (size_t)c);
+  return o;
+}
+ARCLE_BIG_DEV void stg(int8_t* base, int c, const Chunk& v) { *reinterpret_cast<V16*>(base + 16 * (size_t)c) = v.v; }
+ARCLE_BIG_DEV Chunk zero_chunk() {
+  Chunk o;
+  o.w[0] = o.w[1] = o.w[2] = o.w[3] = 0u;
+  return o;
+}
+
+// the chunk c of a plane built cell by cell: cell(f, i, j) for the cells f = i * W + j < P of the chunk, zero behind P (row padding)
+template <class F>
+ARCLE_BIG_DEV Chunk build_chunk(int c, int W, int P, F&& cell) {
+  Chunk o;
+  int f = 16 * c;
+  int i = f / W, j = f - i * W;
+#pragma unroll
+  for (int k = 0; k < 16; k++, f++) {
+    o.b[k] = f < P ? (int8_t)cell(f, i, j) : (int8_t)0;
+    if (++j == W) {
+      j = 0;
+      ++i;
+    }
+  }
+  return o;
+}
+
+// ---- task draw (the same function of (seed, global env id, episode) as arcle_wave.h draw_task, without augmentation) -------------------
+ARCLE_BIG_DEV uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+ARCLE_BIG_DEV uint32_t mulhi32(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * (uint64_t)n) >> 32); }
+ARCLE_BIG_DEV int draw_task_entry(const BigParams& p, int env, uint32_t episode) {
+  const uint64_t G = 0x9E3779B97F4A7C15ull;
+  const uint64_t z0 = mix64(p.seed + (uint64_t)(p.env_base + env) * G + (uint64_t)episode * 0xD1B54A32D192ED03ull);
+  const int problem = (int)mulhi32((uint32_t)(z0 >> 32), (uint32_t)p.n_problems);
+  const int sub = (int)mulhi32((uint32_t)z0, (uint32_t)p.pair_cnt[problem]);
+  return p.pair_off[problem] + sub;
+}
+
+// ---- 128-bit row boards ------------------------------------------------------------------------------------------------------------
+// the fill spread along the runs of E (eligible cells) that hold a seed, towards the higher bits: E + S ripples a carry through every
+// run from its lowest seed upwards; (E ^ (E + S)) & E are the cells the carry crossed
+ARCLE_BIG_DEV B128 spread_up(B128 E, B128 S) {
+  B128 t;
+  t.lo = E.lo + S.lo;
+  t.hi = E.hi + S.hi + (t.lo < E.lo ? 1ull : 0ull);
+  B128 r;
+  r.lo = ((E.lo ^ t.lo) & E.lo) | S.lo;
+  r.hi = ((E.hi ^ t.hi) & E.hi) | S.hi;
+  return r;
+}
+ARCLE_BIG_DEV B128 rev128(B128 a) {
+  B128 r;
+  r.lo = bx::brev64(a.hi);
+  r.hi = bx::brev64(a.lo);
+  return r;
+}
+ARCLE_BIG_DEV B128 spread(B128 E, B128 S) {
+  const B128 u = spread_up(E, S);
+  const B128 d = rev128(spread_up(rev128(E), rev128(S)));
+  B128 r;
+  r.lo = u.lo | d.lo;
+  r.hi = u.hi | d.hi;
+  return r;
+}
+
+struct Ctx {
+  const BigParams& p;
+  int env, tid, NT, H, W, P, PS, nch;
+  int8_t *S, *A, *B, *C;
+  Red* red;
+  uint64_t *Eb, *Fb;
+  size_t po;
+  ARCLE_BIG_DEV Ctx(const BigParams& p_, int env_, int8_t* lds)
+      : p(p_), env(env_), tid(bx::tid()), NT(bx::nt()), H(p_.H), W(p_.W), P(p_.P), PS(p_.PS), nch(p_.PS >> 4) {
+    S = lds;
+    A = lds + PS;
+    B = lds + 2 * PS;
+    C = lds + 3 * PS;
+    red = reinterpret_cast<Red*>(lds + 4 * PS);
+    Eb = reinterpret_cast<uint64_t*>(lds + 4 * PS + 64);
+    Fb = Eb + 256;
+    po = (size_t)env * (size_t)PS;
+  }
+  ARCLE_BIG_DEV int8_t* g(int pl) const { return p.plane[pl] + po; }
+  ARCLE_BIG_DEV bool has(int pl) const { return p.plane[pl] != nullptr; }
+  // global plane -> LDS tile / LDS tile -> global plane / fill
+  ARCLE_BIG_DEV void stage(int8_t* dst, const int8_t* src) const {
+    for (int c = tid; c < nch; c += NT) stg(dst, c, ldg(src, c));
+  }
+  ARCLE_BIG_DEV void fill(int8_t* dst, const Chunk& v) const {
+    for (int c = tid; c < nch; c += NT) stg(dst, c, v);
+  }
+};
+
+// init_state (base.py:155-166 + o2arcenv.py:16-34 / arcenv.py:81-89): grid := input, the other state planes := 0, the record's state
+// fields; `src` = the input plane to copy (the env's own, or a task-table entry that is also written to PL_INPUT)
+ARCLE_BIG_DEV void init_planes(const Ctx& x, const int8_t* src, bool write_input) {
+  const Chunk z = zero_chunk();
+  for (int c = x.tid; c < x.nch; c += x.NT) {
+    const Chunk in = ldg(src, c);
+    if (write_input) stg(x.g(ARCLE_PL_INPUT), c, in);
+    stg(x.g(ARCLE_PL_GRID), c, in);
+    if (x.has(ARCLE_PL_SELECTED)) stg(x.g(ARCLE_PL_SELECTED), c, z);
+    if (x.has(ARCLE_PL_CLIP)) stg(x.g(ARCLE_PL_CLIP), c, z);
+    if (x.has(ARCLE_PL_OBJECT)) stg(x.g(ARCLE_PL_OBJECT), c, z);
+    if (x.has(ARCLE_PL_OBJECT_SEL)) stg(x.g(ARCLE_PL_OBJECT_SEL), c, z);
+    if (x.has(ARCLE_PL_BACKGROUND)) stg(x.g(ARCLE_PL_BACKGROUND), c, z);
+  }
+}
+ARCLE_BIG_DEV void init_rec(int8_t* r, int max_trial) {
+  r[ARCLE_REC_GRID_DIM] = r[ARCLE_REC_INPUT_DIM];
+  r[ARCLE_REC_GRID_DIM + 1] = r[ARCLE_REC_INPUT_DIM + 1];
+  r[ARCLE_REC_CLIP_DIM] = r[ARCLE_REC_CLIP_DIM + 1] = 0;
+  r[ARCLE_REC_OBJECT_DIM] = r[ARCLE_REC_OBJECT_DIM + 1] = 0;
+  r[ARCLE_REC_OBJECT_POS] = r[ARCLE_REC_OBJECT_POS + 1] = 0;
+  r[ARCLE_REC_TRIALS] = (int8_t)i8w(max_trial);
+  r[ARCLE_REC_TERMINATED] = 0;
+  r[ARCLE_REC_ACTIVE] = 0;
+  r[ARCLE_REC_PARITY] = 0;
+}
+
+// answer.shape == grid_dim and grid[:h,:w] == answer (base.py:177, o2arcenv.py:124-127); workgroup-uniform result.
+// (two barriers; the caller has made the grid plane in global memory final and visible — a barrier since its last store)
+ARCLE_BIG_DEV bool grid_equals_answer(const Ctx& x, const int8_t* r) {
+  const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1];
+  if (gh != r[ARCLE_REC_ANSWER_DIM] || gw != r[ARCLE_REC_ANSWER_DIM + 1]) return false;
+  if (x.tid == 0) x.red->neq = 0;
+  bx::sync();
+  bool differs = false;
+  const int lastc = imin(x.nch, (gh * x.W + 15) >> 4);  // cells of the rows >= gh are never compared
+  for (int c = x.tid; c < lastc; c += x.NT) {
+    const Chunk a = ldg(x.g(ARCLE_PL_GRID), c), b = ldg(x.g(ARCLE_PL_ANSWER), c);
+    if ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) {
+      int f = 16 * c;
+      int i = f / x.W, j = f - i * x.W;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        if (i < gh && j < gw && a.b[k] != b.b[k]) differs = true;
+        if (++j == x.W) {
+          j = 0;
+          ++i;
+        }
+      }
+    }
+  }
+  if (differs) x.red->neq = 1;
+  bx::sync();
+  return x.red->neq == 0;
+}
+
+// ---- flattened rows --------------------------------------------------------------------------------------------------------------------
+// A logical row is a list of segments: a state plane (P bytes) or a few bytes of the scalar block sc[] (the 16-byte record followed by
+// reward int32 LE at 16, terminated at 20).  Layouts: gymnasium FlattenObservation of the state dict (keys sorted, object_states in
+// place) or of its FilterO2ARC subset (agents/env.py:109-126) — the orders arcle_wave.h flat_row writes — and the packed gather row
+// grid | grid_dim | reward | terminated.
+struct Seg {
+  int16_t plane;  // -1: scalars
+  int16_t soff;   // offset in sc[]
+  int32_t start, len;
+};
+struct Layout {
+  Seg s[18];
+  int n, len;
+  ARCLE_BIG_DEV void add_plane(int pl, int P) {
+    s[n].plane = (int16_t)pl;
+    s[n].soff = 0;
+    s[n].start = len;
+    s[n].len = P;
+    len += P;
+    n++;
+  }
+  ARCLE_BIG_DEV void add_sc(int off, int k) {
+    s[n].plane = -1;
+    s[n].soff = (int16_t)off;
+    s[n].start = len;
+    s[n].len = k;
+    len += k;
+    n++;
+  }
+};
+ARCLE_BIG_DEV Layout flat_layout(const BigParams& p, int filtered) {
+  Layout L;
+  L.n = 0;
+  L.len = 0;
+  const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
+  const int P = p.P;
+  if (filtered) {
+    L.add_sc(ARCLE_REC_ACTIVE, 1);
+    L.add_plane(ARCLE_PL_CLIP, P);
+    L.add_sc(ARCLE_REC_CLIP_DIM, 2);
+    L.add_plane(ARCLE_PL_GRID, P);
+    L.add_sc(ARCLE_REC_GRID_DIM, 2);
+    L.add_plane(ARCLE_PL_OBJECT, P);
+    L.add_sc(ARCLE_REC_OBJECT_DIM, 2);
+    L.add_sc(ARCLE_REC_OBJECT_POS, 2);
+    L.add_sc(ARCLE_REC_TRIALS, 1);
+    return L;
+  }
+  if (clip) {
+    L.add_plane(ARCLE_PL_CLIP, P);
+    L.add_sc(ARCLE_REC_CLIP_DIM, 2);
+  }
+  L.add_plane(ARCLE_PL_GRID, P);
+  L.add_sc(ARCLE_REC_GRID_DIM, 2);
+  L.add_plane(ARCLE_PL_INPUT, P);
+  L.add_sc(ARCLE_REC_INPUT_DIM, 2);
+  if (o2) {
+    L.add_sc(ARCLE_REC_ACTIVE, 1);
+    L.add_plane(ARCLE_PL_BACKGROUND, P);
+    L.add_plane(ARCLE_PL_OBJECT, P);
+    L.add_sc(ARCLE_REC_OBJECT_DIM, 2);
+    L.add_sc(ARCLE_REC_OBJECT_POS, 2);
+    L.add_plane(ARCLE_PL_OBJECT_SEL, P);
+    L.add_sc(ARCLE_REC_PARITY, 1);
+    L.add_plane(ARCLE_PL_SELECTED, P);
+  }
+  L.add_sc(ARCLE_REC_TERMINATED, 1);
+  L.add_sc(ARCLE_REC_TRIALS, 1);
+  return L;
+}
+ARCLE_BIG_DEV Layout packed_layout(const BigParams& p) {
+  Layout L;
+  L.n = 0;
+  L.len = 0;
+  L.add_plane(ARCLE_PL_GRID, p.P);
+  L.add_sc(ARCLE_REC_GRID_DIM, 2);
+  L.add_sc(16, 4);
+  L.add_sc(20, 1);
+  return L;
+}
+
+// writes bytes [0, limit) of the row at `dst` (16-byte aligned, limit a multiple of 16): the layout's bytes, zeros behind them.  A plane
+// segment lands at an arbitrary byte offset of the row, so each thread assembles whole 16-byte units of the row (one aligned store —
+// rows may live in pinned host memory) from the bytes of the segments that cross it.
+ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, int8_t* dst, int limit) {
+  const int nu = limit >> 4;
+  for (int u = x.tid; u < nu; u += x.NT) {
+    const int b0 = 16 * u;
+    Chunk v = zero_chunk();
+    if (b0 < L.len) {
+      int si = 0;  // the segment holding byte b0 (segments are in row order)
+      while (si + 1 < L.n && L.s[si + 1].start <= b0) si++;
+      const Seg s0 = L.s[si];
+      if (s0.plane >= 0 && b0 + 16 <= s0.start + s0.len) {
+        // the unit lies inside one plane segment: 16 consecutive bytes of the plane
+        const int8_t* src = x.p.plane[s0.plane] + x.po + (b0 - s0.start);
+#pragma unroll
+        for (int k = 0; k < 16; k++) v.b[k] = src[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int b = b0 + k;
+          while (si + 1 < L.n && L.s[si + 1].start <= b) si++;
+          if (b < L.len) {
+            const Seg& s = L.s[si];
+            const int o = b - s.start;
+            v.b[k] = s.plane < 0 ? sc[s.soff + o] : x.p.plane[s.plane][x.po + o];
+          }
+        }
+      }
+    }
+    stg(dst, u, v);
+  }
+}
+
+// the FLAT_OBS / PACK_OBS epilogue of a step (and the stand-alone flatten / pack kernels): rows of the env's CURRENT state
+ARCLE_BIG_DEV void emit_rows(const Ctx& x, const int8_t* r, uint32_t flags, int reward, int term, int cnt0, int cnt1, bool truncated,
+                             uint32_t st) {
+  const BigParams& p = x.p;
+  int8_t sc[24];
+#pragma unroll
+  for (int k = 0; k < 16; k++) sc[k] = r[k];
+  sc[16] = (int8_t)(reward & 0xff);
+  sc[17] = (int8_t)((reward >> 8) & 0xff);
+  sc[18] = (int8_t)((reward >> 16) & 0xff);
+  sc[19] = (int8_t)((reward >> 24) & 0xff);
+  sc[20] = (int8_t)term;
+  sc[21] = sc[22] = sc[23] = 0;
+  if ((flags & ARCLE_STEP_PACK_OBS) && p.pack_out) {
+    const Layout L = packed_layout(p);
+    const int stride = packed_stride(p.P);
+    write_row(x, L, sc, reinterpret_cast<int8_t*>(p.pack_out) + (size_t)x.env * stride, stride);
+  }
+  if ((flags & ARCLE_STEP_FLAT_OBS) && p.flat_out) {
+    const Layout L = flat_layout(p, p.flat_filter);
+    int8_t* const row = p.flat_out + (size_t)x.env * p.flat_stride;
+    write_row(x, L, sc, row, p.flat_stride - (p.flat_tail ? 16 : 0));
+    if (p.flat_tail) {
+      // int32 reward | int32 action_steps | int32 submit_count | uint8 terminated | uint8 truncated | uint8 status | seq
+      // (arcle_set_flat_output_ex / arcle_set_flat_seq: the last word behind a system-scope release, after every row store of the
+      // workgroup — hence the barrier)
+      bx::sync_release();
+      if (x.tid == 0) {
+        uint32_t* const t = reinterpret_cast<uint32_t*>(row + (p.flat_stride - 16));
+        const uint32_t last = (uint32_t)term | ((uint32_t)truncated << 8) | ((st & 0xffu) << 16);
+        t[0] = (uint32_t)reward;
+        t[1] = (uint32_t)cnt0;
+        t[2] = (uint32_t)cnt1;
+        if (p.flat_seq) bx::release_store_system(t + 3, last | ((uint32_t)p.flat_seq << 24));
+        else t[3] = last;
+      }
+    }
+  }
+}
+
+// ---- FloodFill (color.py:88-100, dfs :8-30): 4-connected region of (sx, sy) among the cells of the gh x gw grid that hold its colour.
+// The grid is staged in A.  Iterative propagation is equivalent to the reference's DFS (the visited set does not depend on the order).
+ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int colour) {
+  const int W = x.W, H = x.H;
+  const int col = x.A[sx * W + sy];
+  B128* const E = reinterpret_cast<B128*>(x.Eb);
+  B128* const F = reinterpret_cast<B128*>(x.Fb);
+  for (int i = x.tid; i < H; i += x.NT) {
+    B128 e;
+    e.lo = e.hi = 0;
+    if (i < gh) {
+      const int8_t* row = x.A + i * W;
+      for (int j = 0; j < gw; j++)
+        if (row[j] == col) {
+          if (j < 64) e.lo |= 1ull << j;
+          else e.hi |= 1ull << (j - 64);
+        }
+    }
+    B128 f;
+    f.lo = f.hi = 0;
+    if (i == sx) {
+      if (sy < 64) f.lo = 1ull << sy;
+      else f.hi = 1ull << (sy - 64);
+      f = spread(e, f);
+    }
+    E[i] = e;
+    F[i] = f;
+  }
+  if (x.tid == 0) x.red->flag[0] = x.red->flag[1] = 0;
+  bx::sync();
+  for (int pass = 0;; pass++) {
+    // phase A: every row pulls the fill from its neighbours' boards of the previous pass
+    B128 nf[MAX_ROWS_PER_THREAD];  // a thread owns at most ceil(127 / NT) rows: 1 with the shipped 256 threads, 4 with 32 (emulator)
+    bool ch[MAX_ROWS_PER_THREAD];
+    int nrows = 0;
+    for (int i = x.tid; i < H; i += x.NT) {
+      const B128 cur = F[i], e = E[i];
+      B128 s = cur;
+      if (i > 0) {
+        s.lo |= F[i - 1].lo;
+        s.hi |= F[i - 1].hi;
+      }
+      if (i + 1 < H) {
+        s.lo |= F[i + 1].lo;
+        s.hi |= F[i + 1].hi;
+      }
+      s.lo &= e.lo;
+      s.hi &= e.hi;
+      B128 n = cur;
+      if (s.lo != cur.lo || s.hi != cur.hi) n = spread(e, s);
+      nf[nrows] = n;
+      ch[nrows] = n.lo != cur.lo || n.hi != cur.hi;
+      nrows++;
+    }
+    bx::sync();
+    // phase B: publish
+    nrows = 0;
+    for (int i = x.tid; i < H; i += x.NT) {
+      if (ch[nrows]) {
+        F[i] = nf[nrows];
+        x.red->flag[pass & 1] = 1;
+      }
+      nrows++;
+    }
+    if (x.tid == 0) x.red->flag[(pass + 1) & 1] = 0;
+    bx::sync();
+    if (!x.red->flag[pass & 1]) break;
+  }
+  // the region takes the colour: chunks of the staged grid, rewritten where the board has a bit
+  for (int c = x.tid; c < x.nch; c += x.NT) {
+    bool any = false;
+    const Chunk o = build_chunk(c, W, x.P, [&](int f, int i, int j) {
+      const B128 fr = F[i];
+      const bool in = j < 64 ? ((fr.lo >> j) & 1ull) != 0 : ((fr.hi >> (j - 64)) & 1ull) != 0;
+      any |= in;
+      return in ? (int8_t)colour : x.A[f];
+    });
+    if (any) stg(x.g(ARCLE_PL_GRID), c, o);
+  }
+}
+
+// _apply_patch (object.py:113-138) + _apply_sel (object.py:140-165): grid := background, selected := 0, then the object tile `O`
+// (LDS, tile origin at cell 0) is drawn at object_pos wherever it is > 0 and `Q` becomes the selection there; clipped to grid_dim.
+ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const int8_t* O, const int8_t* Q) {
+  const int W = x.W;
+  const int px = r[ARCLE_REC_OBJECT_POS], py = r[ARCLE_REC_OBJECT_POS + 1];
+  const int h = r[ARCLE_REC_OBJECT_DIM], w = r[ARCLE_REC_OBJECT_DIM + 1];
+  const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1];
+  const int xh = i8w(px + h), yw = i8w(py + w);  // int8 + int8
+  const bool draw = xh > 0 && px < gh && yw > 0 && py < gw;
+  const int stx = imax(px, 0), edx = imin(gh, xh), sty = imax(py, 0), edy = imin(gw, yw);
+  for (int c = x.tid; c < x.nch; c += x.NT) {
+    Chunk sel = zero_chunk();
+    const Chunk grid = build_chunk(c, W, x.P, [&](int f, int i, int j) {
+      int8_t gv = bg[f];
+      if (draw && i >= stx && i < edx && j >= sty && j < edy) {
+        const int t = (i - px) * W + (j - py);
+        const int8_t pv = O[t];
+        if (pv > 0) gv = pv;        // :138 where=(p > 0)
+        sel.b[f & 15] = Q[t];       // :165
+      }
+      return gv;
+    });
+    stg(x.g(ARCLE_PL_GRID), c, grid);
+    stg(x.g(ARCLE_PL_SELECTED), c, sel);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// one step() of one env: O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step (arcenv.py:155-172) / RawARCEnv.step (arcenv.py:60-76)
+// ------------------------------------------------------------------------------------------------------------------------------------
+ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
+  const Ctx x(p, env, lds);
+  const int tid = x.tid, NT = x.NT, H = x.H, W = x.W, P = x.P, nch = x.nch;
+  Chunk rc = ldg(p.rec, env);
+  int8_t* const r = rc.b;
+  int cnt0 = p.cnt[2 * (size_t)env], cnt1 = p.cnt[2 * (size_t)env + 1];
+  const uint32_t flags = p.flags;
+  int reward = 0, submit_inc = 0;
+  uint32_t st = 0;
+  bool counted = false;  // the step happened: action_steps += 1
+  int opi = 0;
+  // ---- the action's scalars ----
+  int pay[5] = {0, 0, 0, 0, 0};
+  if (p.ingress == ING_BBOX) {
+    for (int k = 0; k < 4; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[4 * (size_t)env + k];
+  } else if (p.ingress == ING_POINT) {
+    for (int k = 0; k < 2; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[2 * (size_t)env + k];
+  } else if (p.ingress == ING_BBOX5) {
+    for (int k = 0; k < 5; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[5 * (size_t)env + k];
+  }
+  opi = p.ingress == ING_BBOX5 ? pay[4] : p.op[env];
+  if (tid == 0) {
+    Red* q = x.red;
+    q->any_nz = q->any_pos = q->sum = 0;
+    q->amax = 0u;
+    q->x0 = q->y0 = 1 << 20;
+    q->x1 = q->y1 = -1;
+    q->neq = 0;
+  }
+  bx::sync();  // every thread holds the record / counters; the reduction block is clear
+
+  do {
+    if (flags & (ARCLE_STEP_AUTORESET | ARCLE_STEP_RESAMPLE)) {
+      // next-step autoreset (see ARCLE_STEP_AUTORESET): an env whose episode ended is re-initialised instead of executing the action
+      const bool ended = r[ARCLE_REC_TERMINATED] != 0 || ((flags & ARCLE_STEP_TRUNCATE) && cnt0 >= p.step_limit);
+      if (ended) {
+        if (flags & ARCLE_STEP_RESAMPLE) {  // ... on a new task drawn on the device (no augmentation on this path)
+          const uint32_t ep = (uint32_t)p.episode[env];
+          const int t = draw_task_entry(p, env, ep);
+          r[ARCLE_REC_INPUT_DIM] = p.tbl_in_dim[2 * (size_t)t];
+          r[ARCLE_REC_INPUT_DIM + 1] = p.tbl_in_dim[2 * (size_t)t + 1];
+          r[ARCLE_REC_ANSWER_DIM] = p.tbl_ans_dim[2 * (size_t)t];
+          r[ARCLE_REC_ANSWER_DIM + 1] = p.tbl_ans_dim[2 * (size_t)t + 1];
+          for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(p.tbl_ans + (size_t)t * x.PS, c));
+          init_planes(x, p.tbl_in + (size_t)t * x.PS, true);
+          bx::sync();  // (every thread has read episode[env])
+          if (tid == 0) {
+            p.episode[env] = (int32_t)(ep + 1u);
+            if (p.cur_task) p.cur_task[env] = t;
+          }
+        } else {
+          init_planes(x, x.g(ARCLE_PL_INPUT), false);
+        }
+        init_rec(r, p.max_trial);
+        cnt0 = cnt1 = 0;
+        break;
+      }
+    }
+    // an index past the table reads slot n_ops, which is always empty
+    const uint32_t slot = (uint32_t)opi < (uint32_t)p.n_ops ? (uint32_t)opi : (uint32_t)p.n_ops;
+    const uint32_t desc = p.d_ops[slot];
+    const int kind = (int)ARCLE_OP_KIND(desc), arg = (int)ARCLE_OP_ARG(desc);
+    const uint32_t oflags = ARCLE_OP_FLAGS(desc);
+    if (kind == ARCLE_OP_NONE) {  // reference: IndexError / TypeError before any mutation
+      st |= ARCLE_ST_BAD_OP;
+      break;
+    }
+
+    // ---- selection -> S (bytes in LDS) + its reductions -------------------------------------------------------------------------
+    bool any_nz, any_pos;
+    int ssum, x0, x1, y0, y1, amax_cell;
+    if (p.ingress == ING_MASK) {
+      const int8_t* const src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)env * (size_t)P;
+      const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+      int l_nz = 0, l_pos = 0, l_sum = 0, lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
+      uint32_t l_amax = 0;
+      for (int c = tid; c < nch; c += NT) {
+        Chunk v = zero_chunk();
+        const int f0 = 16 * c;
+        if (aligned && f0 + 16 <= P) {
+          v = ldg(src, c);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            if (f0 + k < P) v.b[k] = src[f0 + k];
+        }
+        stg(x.S, c, v);
+        if (v.w[0] | v.w[1] | v.w[2] | v.w[3]) {
+          int i = f0 / W, j = f0 - i * W;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            const int s = v.b[k];
+            if (s != 0) {
+              l_nz = 1;
+              l_pos |= s > 0;
+              lx0 = imin(lx0, i);
+              lx1 = imax(lx1, i);
+              ly0 = imin(ly0, j);
+              ly1 = imax(ly1, j);
+            }
+            l_sum += s;
+            const uint32_t key = ((uint32_t)(s + 128) << 16) | (uint32_t)(0xffff - (f0 + k));
+            if (f0 + k < P && key > l_amax) l_amax = key;
+            if (++j == W) {
+              j = 0;
+              ++i;
+            }
+          }
+        } else {
+          const uint32_t key = (128u << 16) | (uint32_t)(0xffff - f0);  // a chunk of zeros: its first cell stands for it in the arg-max
+          if (f0 < P && key > l_amax) l_amax = key;
+        }
+      }
+      Red* q = x.red;
+      if (l_nz) {
+        bx::lds_or(&q->any_nz, 1);
+        if (l_pos) bx::lds_or(&q->any_pos, 1);
+        bx::lds_min(&q->x0, lx0);
+        bx::lds_max(&q->x1, lx1);
+        bx::lds_min(&q->y0, ly0);
+        bx::lds_max(&q->y1, ly1);
+      }
+      if (l_sum) bx::lds_add(&q->sum, l_sum);
+      bx::lds_umax(&q->amax, l_amax);
+      bx::sync();
+      any_nz = q->any_nz != 0;
+      any_pos = q->any_pos != 0;
+      ssum = q->sum;
+      x0 = q->x0;
+      x1 = q->x1;
+      y0 = q->y0;
+      y1 = q->y1;
+      amax_cell = 0xffff - (int)(q->amax & 0xffffu);
+      if ((flags & ARCLE_STEP_CONTINUE_RULE) && (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
+        // the O2ARC trace harness (tests/o2arc_check.py:169-170): an object op whose logged selection equals the env's current
+        // `selected` plane continues the active object, i.e. is sent with an empty selection
+        bool differs = false;
+        for (int c = tid; c < nch; c += NT) {
+          const Chunk a = ldg(x.g(ARCLE_PL_SELECTED), c), b = ldg(x.S, c);
+          differs |= ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) != 0;
+        }
+        if (differs) q->neq = 1;
+        bx::sync();
+        const bool same = q->neq == 0;
+        bx::sync();
+        if (tid == 0) q->neq = 0;
+        if (same) {
+          x.fill(x.S, zero_chunk());
+          any_nz = any_pos = false;
+          ssum = 0;
+          amax_cell = 0;
+        }
+        bx::sync();
+      }
+    } else {
+      // BBoxWrapper.action (bbox.py:22-30): sorted corners, slices clip at H, W / PointWrapper.action (bbox.py:43-49).  Coordinates
+      // outside the wrappers' action space select nothing and raise ARCLE_ST_BAD_SELECTION.
+      int xa, xb, ya, yb;
+      bool any;
+      if (p.ingress == ING_POINT) {
+        xa = xb = pay[0];
+        ya = yb = pay[1];
+        any = (uint32_t)xa < (uint32_t)H && (uint32_t)ya < (uint32_t)W;
+        if (!any) st |= ARCLE_ST_BAD_SELECTION;
+      } else {
+        xa = imin(pay[0], pay[2]);
+        xb = imin(imax(pay[0], pay[2]), H - 1);
+        ya = imin(pay[1], pay[3]);
+        yb = imin(imax(pay[1], pay[3]), W - 1);
+        any = (uint32_t)xa < (uint32_t)H && (uint32_t)ya < (uint32_t)W;
+        if (!any && (xa | ya) < 0) st |= ARCLE_ST_BAD_SELECTION;
+      }
+      for (int c = tid; c < nch; c += NT)
+        stg(x.S, c, build_chunk(c, W, P, [&](int, int i, int j) { return (any && i >= xa && i <= xb && j >= ya && j <= yb) ? 1 : 0; }));
+      any_nz = any_pos = any;
+      ssum = any ? (xb - xa + 1) * (yb - ya + 1) : 0;
+      x0 = xa;
+      x1 = xb;
+      y0 = ya;
+      y1 = yb;
+      amax_cell = any ? xa * W + ya : 0;
+      bx::sync();
+    }
+
+    // ---- reset_sel / keep_sel (object.py:10-41): scalar part first — an object op reads `active` after the wrapper ran ----
+    const int8_t active_before = r[ARCLE_REC_ACTIVE];
+    if (oflags & ARCLE_OPF_RESET_SEL) r[ARCLE_REC_ACTIVE] = 0;
+
+    // ---- Rotate / Flip: the geometry first, so that a transform the reference raises in skips the whole step ----
+    bool fresh = false, obj_go = false, new_geom = false;
+    int oh = 0, ow = 0, nx = 0, ny = 0, nh = 0, nw = 0, npar = 0, ai = 0, bj = 0, c0 = 0;
+    if (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP) {
+      // _init_objsel, object.py:60-111: a fresh selection, or the stored object when active, or a total no-op (:110-111)
+      int ox, oy, bx0, bx1, by0, by1;
+      fresh = any_nz;
+      if (fresh) {
+        bx0 = x0; bx1 = x1; by0 = y0; by1 = y1;
+        oh = x1 - x0 + 1; ow = y1 - y0 + 1; ox = x0; oy = y0;
+        obj_go = true;
+      } else if (r[ARCLE_REC_ACTIVE]) {
+        oh = r[ARCLE_REC_OBJECT_DIM]; ow = r[ARCLE_REC_OBJECT_DIM + 1];
+        ox = r[ARCLE_REC_OBJECT_POS]; oy = r[ARCLE_REC_OBJECT_POS + 1];
+        bx0 = ox; bx1 = i8w(i8w(ox + oh) - 1); by0 = oy; by1 = i8w(i8w(oy + ow) - 1);  // :102-107, int8 arithmetic
+        obj_go = true;
+      } else {
+        ox = oy = bx0 = bx1 = by0 = by1 = 0;
+      }
+      nx = ox; ny = oy; nh = oh; nw = ow;
+      npar = fresh ? 0 : r[ARCLE_REC_PARITY];
+      bool domain_error = false;
+      if (obj_go && kind == ARCLE_OP_ROTATE) {  // gen_rotate(k), object.py:177-213 — the float centre arithmetic on doubled integers
+        const int k = arg;
+        if (k & 1) {
+          const int sx2 = fresh ? bx1 + bx0 : i8w(bx1 + bx0);
+          const int sy2 = fresh ? by1 + by0 : i8w(by1 + by0);
+          if ((oh & 1) == (ow & 1)) {
+            nx = floordiv2(sx2 - sy2 + 2 * oy);
+            ny = floordiv2(sy2 - sx2 + 2 * ox);
+          } else {
+            npar = (npar + k) % 2;
+            const int sig = (k + 2) % 4 - 2, mod = 1 - npar;
+            nx = floordiv2(sx2 + imin(sig * (sy2 - 2 * by0), sig * (sy2 - 2 * by1)) + 2 * mod);
+            ny = floordiv2(sy2 + imin(-sig * (sx2 - 2 * bx0), -sig * (sx2 - 2 * bx1)) + 2 * mod);
+          }
+          nh = ow;
+          nw = oh;
+          new_geom = true;
+          if (ow > H || oh > W || nx < -128 || nx > 127 || ny < -128 || ny > 127) domain_error = true;
+        }
+        if (k == 1) { ai = -1; bj = W; c0 = ow - 1; }                          // rot90:  new[i,j] = old[j, w-1-i]
+        else if (k == 2) { ai = -W; bj = -1; c0 = (oh - 1) * W + (ow - 1); }   // rot180: old[h-1-i, w-1-j]
+        else { ai = 1; bj = -W; c0 = (oh - 1) * W; }                           // rot270: old[h-1-j, i]
+      } else if (obj_go && kind == ARCLE_OP_FLIP) {  // gen_flip(axis), object.py:265-276; object_dim is NOT updated (:270-273)
+        if (arg == 0) { ai = W; bj = -1; c0 = ow - 1; }                        // fliplr: old[i, w-1-j]
+        else if (arg == 1) { ai = -W; bj = 1; c0 = (oh - 1) * W; }             // flipud: old[h-1-i, j]
+        else if (arg == 2) { ai = 1; bj = W; c0 = 0; nh = ow; nw = oh; }       // D0 transpose: old[j, i]
+        else { ai = -1; bj = -W; c0 = (oh - 1) * W + (ow - 1); nh = ow; nw = oh; }  // D1: old[h-1-j, w-1-i]
+        if (arg >= 2 && (ow > H || oh > W)) domain_error = true;
+      }
+      if (domain_error) {  // the reference raised inside the op (ValueError at object.py:45 / int8 overflow): the step did not happen
+        st |= ARCLE_ST_ROTATE_DOMAIN;
+        r[ARCLE_REC_ACTIVE] = active_before;
+        break;
+      }
+    }
+
+    // ---- the wrappers' plane writes ----
+    if (oflags & ARCLE_OPF_KEEP_SEL) {
+      for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_SELECTED), c, ldg(x.S, c));
+    } else if ((oflags & ARCLE_OPF_RESET_SEL) && !((flags & ARCLE_STEP_ELIDE_SELECTED) && active_before == 0)) {
+      for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_SELECTED), c, zero_chunk());
+    }
+
+    int eq = -1;  // grid == answer, evaluated at most once
+    bool grid_moved = true;  // (conservative: every op below that stores the grid plane ends with a barrier before the compare)
+    switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
+      case ARCLE_OP_COLOR: {  // color.py:70-74 — whole H x W plane, grid_dim ignored
+        if (!any_nz) break;
+        for (int c = tid; c < nch; c += NT) {
+          const Chunk s = ldg(x.S, c);
+          if (!(s.w[0] | s.w[1] | s.w[2] | s.w[3])) continue;
+          Chunk gr = ldg(x.g(ARCLE_PL_GRID), c);
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            if (s.b[k] != 0) gr.b[k] = (int8_t)arg;
+          stg(x.g(ARCLE_PL_GRID), c, gr);
+        }
+        break;
+      }
+      case ARCLE_OP_FLOODFILL: {  // color.py:88-100
+        if (ssum != 1) break;
+        const int sx = amax_cell / W, sy = amax_cell - sx * W;
+        const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1];
+        if (sx >= gh || sy >= gw) break;
+        x.stage(x.A, x.g(ARCLE_PL_GRID));
+        bx::sync();
+        flood_fill(x, gh, gw, sx, sy, arg);
+        break;
+      }
+      case ARCLE_OP_MOVE:
+      case ARCLE_OP_ROTATE:
+      case ARCLE_OP_FLIP: {
+        if (!obj_go) break;
+        int8_t *O = x.B, *Q = x.C;  // object / object_sel tiles
+        if (fresh) {  // object.py:67-99
+          x.stage(x.A, x.g(ARCLE_PL_GRID));
+          bx::sync();
+          for (int c = tid; c < nch; c += NT) {
+            Chunk qs = zero_chunk();
+            const Chunk ob = build_chunk(c, W, P, [&](int f, int i, int j) {
+              int8_t v = 0;
+              if (i < oh && j < ow) {
+                const int s = (x0 + i) * W + (y0 + j);
+                if (x.S[s] > 0) {  // :78 sel > 0
+                  v = x.A[s];      // :81
+                  qs.b[f & 15] = 1;  // :84
+                }
+              }
+              return v;
+            });
+            stg(x.B, c, ob);
+            stg(x.C, c, qs);
+          }
+          bx::sync();
+          for (int c = tid; c < nch; c += NT) {  // background = where(sel > 0, 0, grid)  :87-88
+            Chunk gr = ldg(x.A, c);
+            const Chunk s = ldg(x.S, c);
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+              if (s.b[k] > 0) gr.b[k] = 0;
+            stg(x.A, c, gr);
+            stg(x.g(ARCLE_PL_BACKGROUND), c, gr);
+          }
+          r[ARCLE_REC_OBJECT_DIM] = (int8_t)oh;
+          r[ARCLE_REC_OBJECT_DIM + 1] = (int8_t)ow;
+          r[ARCLE_REC_OBJECT_POS] = (int8_t)x0;
+          r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)y0;
+          r[ARCLE_REC_ACTIVE] = 1;
+          r[ARCLE_REC_PARITY] = 0;
+          // (selected = sel, :96 — place() below rewrites the whole plane)
+        } else {  // :102-107 the stored object continues
+          x.stage(x.A, x.g(ARCLE_PL_BACKGROUND));
+          x.stage(x.B, x.g(ARCLE_PL_OBJECT));
+          x.stage(x.C, x.g(ARCLE_PL_OBJECT_SEL));
+        }
+        bx::sync();
+        if (kind == ARCLE_OP_MOVE) {  // gen_move(d), object.py:230-240
+          const int dx = (arg == 0) ? -1 : (arg == 1) ? 1 : 0;
+          const int dy = (arg == 2) ? 1 : (arg == 3) ? -1 : 0;
+          r[ARCLE_REC_OBJECT_POS] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS] + dx);  // :238, int8 wrap
+          r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS + 1] + dy);
+          if (fresh) {
+            for (int c = tid; c < nch; c += NT) {
+              stg(x.g(ARCLE_PL_OBJECT), c, ldg(x.B, c));
+              stg(x.g(ARCLE_PL_OBJECT_SEL), c, ldg(x.C, c));
+            }
+          }
+        } else {
+          // dst[:nh,:nw] = T(src[:h,:w]), rest 0 (_pad_assign, object.py:43-47): object B -> S, then object_sel C -> B
+          for (int c = tid; c < nch; c += NT) {
+            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) { return (i < nh && j < nw) ? x.B[c0 + ai * i + bj * j] : (int8_t)0; });
+            stg(x.S, c, t);
+            stg(x.g(ARCLE_PL_OBJECT), c, t);
+          }
+          bx::sync();
+          for (int c = tid; c < nch; c += NT) {
+            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) { return (i < nh && j < nw) ? x.C[c0 + ai * i + bj * j] : (int8_t)0; });
+            stg(x.B, c, t);
+            stg(x.g(ARCLE_PL_OBJECT_SEL), c, t);
+          }
+          O = x.S;
+          Q = x.B;
+          if (new_geom) {
+            r[ARCLE_REC_OBJECT_POS] = (int8_t)nx;
+            r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)ny;
+            r[ARCLE_REC_OBJECT_DIM] = (int8_t)nh;
+            r[ARCLE_REC_OBJECT_DIM + 1] = (int8_t)nw;
+            r[ARCLE_REC_PARITY] = (int8_t)npar;
+          }
+          bx::sync();
+        }
+        place(x, r, x.A, O, Q);
+        break;
+      }
+      case ARCLE_OP_COPY: {  // gen_copy(source), object.py:291-312
+        if (!any_pos) break;
+        const int so = arg ? ARCLE_REC_GRID_DIM : ARCLE_REC_INPUT_DIM;
+        const int ss_h = r[so], ss_w = r[so + 1];
+        if (x1 > ss_h || y1 > ss_w) break;  // :301 (sic: > not >=)
+        const int h = x1 - x0 + 1, w = y1 - y0 + 1;
+        x.stage(x.A, x.g(arg ? ARCLE_PL_GRID : ARCLE_PL_INPUT));
+        bx::sync();
+        for (int c = tid; c < nch; c += NT)
+          stg(x.g(ARCLE_PL_CLIP), c, build_chunk(c, W, P, [&](int, int i, int j) {
+                int8_t v = 0;
+                if (i < h && j < w) {
+                  const int s = (x0 + i) * W + (y0 + j);
+                  if (x.S[s] != 0) v = x.A[s];  // :310-312 where=logical_and(src, sel)
+                }
+                return v;
+              }));
+        r[ARCLE_REC_CLIP_DIM] = (int8_t)h;
+        r[ARCLE_REC_CLIP_DIM + 1] = (int8_t)w;
+        break;
+      }
+      case ARCLE_OP_PASTE: {  // gen_paste(paste_blank), object.py:317-348
+        if (!any_pos) break;
+        const int h = r[ARCLE_REC_CLIP_DIM], w = r[ARCLE_REC_CLIP_DIM + 1];
+        if (h == 0 || w == 0) break;  // :334
+        const int ex = imin(x0 + h, H), ey = imin(y0 + w, W);  // :340-341 clipped to H x W, not grid_dim
+        x.stage(x.A, x.g(ARCLE_PL_CLIP));
+        bx::sync();
+        const int c_first = (x0 * W) >> 4, c_last = imin(nch - 1, (ex * W) >> 4);
+        for (int c = c_first + tid; c <= c_last; c += NT) {
+          const Chunk gr = ldg(x.g(ARCLE_PL_GRID), c);
+          stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int f, int i, int j) {
+                int8_t v = gr.b[f & 15];
+                if (i >= x0 && i < ex && j >= y0 && j < ey) {
+                  const int8_t pv = x.A[(i - x0) * W + (j - y0)];
+                  if (arg || pv > 0) v = pv;  // :345-348
+                }
+                return v;
+              }));
+        }
+        break;
+      }
+      case ARCLE_OP_COPY_FROM_INPUT: {  // critical.py:28-29
+        for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_GRID), c, ldg(x.g(ARCLE_PL_INPUT), c));
+        r[ARCLE_REC_GRID_DIM] = r[ARCLE_REC_INPUT_DIM];
+        r[ARCLE_REC_GRID_DIM + 1] = r[ARCLE_REC_INPUT_DIM + 1];
+        break;
+      }
+      case ARCLE_OP_RESET_GRID: {  // critical.py:17
+        for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_GRID), c, zero_chunk());
+        break;
+      }
+      case ARCLE_OP_RESIZE_GRID: {  // critical.py:39-46
+        if (!any_nz) break;
+        for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_GRID), c, zero_chunk());
+        r[ARCLE_REC_GRID_DIM] = (int8_t)(x1 - x0 + 1);
+        r[ARCLE_REC_GRID_DIM + 1] = (int8_t)(y1 - y0 + 1);
+        break;
+      }
+      case ARCLE_OP_CROP_GRID: {  // critical.py:56-66
+        if (!any_nz) break;
+        const int h = x1 - x0 + 1, w = y1 - y0 + 1;
+        x.stage(x.A, x.g(ARCLE_PL_GRID));
+        bx::sync();
+        for (int c = tid; c < nch; c += NT)
+          stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int, int i, int j) {
+                int8_t v = 0;
+                if (i < h && j < w) {
+                  const int s = (x0 + i) * W + (y0 + j);
+                  if (x.S[s] != 0) v = x.A[s];
+                }
+                return v;
+              }));
+        r[ARCLE_REC_GRID_DIM] = (int8_t)h;
+        r[ARCLE_REC_GRID_DIM + 1] = (int8_t)w;
+        break;
+      }
+      case ARCLE_OP_RESIZE_TO_ANSWER: {  // arcenv.py:31-35
+        const int ah = r[ARCLE_REC_ANSWER_DIM], aw = r[ARCLE_REC_ANSWER_DIM + 1];
+        r[ARCLE_REC_GRID_DIM] = (int8_t)ah;
+        r[ARCLE_REC_GRID_DIM + 1] = (int8_t)aw;
+        for (int c = tid; c < nch; c += NT) {
+          const Chunk gr = ldg(x.g(ARCLE_PL_GRID), c);
+          stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int f, int i, int j) { return (i < ah && j < aw) ? gr.b[f & 15] : (int8_t)0; }));
+        }
+        break;
+      }
+      case ARCLE_OP_SUBMIT: {  // base.py:172-183
+        grid_moved = false;
+        int trials = r[ARCLE_REC_TRIALS];
+        if (trials != 0) {
+          trials = i8w(trials - 1);  // :174 int8 wrap
+          r[ARCLE_REC_TRIALS] = (int8_t)trials;
+          submit_inc = 1;
+          if (flags & ARCLE_STEP_RESET_ON_SUBMIT) {
+            // base.py:179-180: init_state() rebinds current_state inside submit — the decrement, the `terminated` of a correct
+            // answer and the trials-exhausted check all land on the discarded dict; the caller sees the
+            // re-initialised state, reward() is evaluated on it, and the env's counters go on
+            init_planes(x, x.g(ARCLE_PL_INPUT), false);
+            init_rec(r, p.max_trial);
+            grid_moved = true;
+            break;
+          }
+          eq = grid_equals_answer(x, r) ? 1 : 0;
+          if (eq) r[ARCLE_REC_TERMINATED] = 1;
+        }
+        if (trials == 0) r[ARCLE_REC_TERMINATED] = 1;
+        break;
+      }
+      default:  // ARCLE_OP_HOST: a device no-op, the step is counted
+        break;
+    }
+
+    // reward(): only the LAST op of the table can be rewarded (o2arcenv.py:121-128)
+    if (opi == p.n_ops - 1) {
+      if (eq < 0) {
+        if (grid_moved) bx::sync();  // the grid plane this workgroup just stored
+        eq = grid_equals_answer(x, r) ? 1 : 0;
+      }
+      reward = eq;
+    }
+    counted = true;
+  } while (0);
+
+  if (counted) {
+    cnt0 += 1;  // o2arcenv.py:142
+    cnt1 += submit_inc;
+  }
+  const int term = r[ARCLE_REC_TERMINATED] != 0;
+  const bool truncated = (flags & ARCLE_STEP_TRUNCATE) && cnt0 >= p.step_limit;
+  if (tid == 0) {
+    stg(p.rec, env, rc);
+    p.cnt[2 * (size_t)env] = cnt0;
+    p.cnt[2 * (size_t)env + 1] = cnt1;
+    p.reward[env] = reward;
+    p.term[env] = (uint8_t)term;
+    if ((flags & ARCLE_STEP_TRUNCATE) && p.trunc) p.trunc[env] = (uint8_t)truncated;
+    if (st) bx::status_or(p.status, st);
+  }
+  if (flags & (ARCLE_STEP_FLAT_OBS | ARCLE_STEP_PACK_OBS)) {
+    bx::sync();  // every plane store of the step is visible to the workgroup
+    emit_rows(x, r, flags, reward, term, cnt0, cnt1, truncated, st);
+  }
+}
+
+// ---- reset kernels (one workgroup per env) ---------------------------------------------------------------------------------------------
+// mode 0: arcle_reset (init_state from PL_INPUT / REC_INPUT_DIM); 1: arcle_reset_from_table (task_idx); 2: arcle_reset_sampled
+ARCLE_BIG_DEV void reset_env(const BigParams& p, int env, int mode, int8_t* lds) {
+  if (p.rmask && !p.rmask[env]) return;
+  const Ctx x(p, env, lds);
+  Chunk rc;
+  if (mode == 0) {
+    rc = ldg(p.rec, env);
+    bx::sync();
+    init_planes(x, x.g(ARCLE_PL_INPUT), false);
+  } else {
+    rc = zero_chunk();
+    int t;
+    uint32_t ep = 0;
+    if (mode == 1) {
+      t = p.task_idx[env];
+      if (t < 0 || t >= p.n_tasks) {
+        if (x.tid == 0) bx::status_or(p.status, ARCLE_ST_BAD_TASK);
+        return;
+      }
+    } else {
+      ep = (uint32_t)p.episode[env];
+      t = draw_task_entry(p, env, ep);
+      bx::sync();
+    }
+    rc.b[ARCLE_REC_INPUT_DIM] = p.tbl_in_dim[2 * (size_t)t];
+    rc.b[ARCLE_REC_INPUT_DIM + 1] = p.tbl_in_dim[2 * (size_t)t + 1];
+    rc.b[ARCLE_REC_ANSWER_DIM] = p.tbl_ans_dim[2 * (size_t)t];
+    rc.b[ARCLE_REC_ANSWER_DIM + 1] = p.tbl_ans_dim[2 * (size_t)t + 1];
+    for (int c = x.tid; c < x.nch; c += x.NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(p.tbl_ans + (size_t)t * x.PS, c));
+    init_planes(x, p.tbl_in + (size_t)t * x.PS, true);
+    if (x.tid == 0) {
+      if (mode == 2) p.episode[env] = (int32_t)(ep + 1u);
+      if (p.cur_task) p.cur_task[env] = t;
+    }
+  }
+  init_rec(rc.b, p.max_trial);
+  if (x.tid == 0) {
+    stg(p.rec, env, rc);
+    p.cnt[2 * (size_t)env] = 0;
+    p.cnt[2 * (size_t)env + 1] = 0;
+  }
+}
+
+// ---- stand-alone row kernels -----------------------------------------------------------------------------------------------------------
+// mode 0: arcle_flatten_obs / arcle_get_state_rows (rows of the resident state, no tail); 1: arcle_pack_obs (reward / term arrays given)
+ARCLE_BIG_DEV void rows_env(const BigParams& p, int env, int mode, int8_t* lds) {
+  const Ctx x(p, env, lds);
+  const Chunk rc = ldg(p.rec, env);
+  if (mode == 0) emit_rows(x, rc.b, ARCLE_STEP_FLAT_OBS, 0, 0, 0, 0, false, 0);
+  else emit_rows(x, rc.b, ARCLE_STEP_PACK_OBS, p.reward[env], p.term[env], 0, 0, false, 0);
+}
+
+// arcle_set_state_rows: the inverse of the full (unfiltered) flat row — planes and the record's state fields from row `env` of rows_in
+// (any alignment / stride); the task side (answer, answer_dim) and the counters stay
+ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
+  if (p.rmask && !p.rmask[env]) return;
+  const Ctx x(p, env, lds);
+  const Layout L = flat_layout(p, 0);
+  const int8_t* const row = p.rows_in + (size_t)env * p.rows_in_stride;
+  Chunk rc = ldg(p.rec, env);
+  bx::sync();
+  for (int s = 0; s < L.n; s++) {
+    const Seg& sg = L.s[s];
+    if (sg.plane < 0) {
+      for (int k = 0; k < sg.len; k++) rc.b[sg.soff + k] = row[sg.start + k];
+    } else {
+      const int8_t* const src = row + sg.start;
+      for (int c = x.tid; c < x.nch; c += x.NT) {
+        Chunk v = zero_chunk();
+        const int f0 = 16 * c;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (f0 + k < x.P) v.b[k] = src[f0 + k];
+        stg(x.g(sg.plane), c, v);
+      }
+    }
+  }
+  if (x.tid == 0) stg(p.rec, env, rc);
+}
+
+}  // namespace arcle_big

@@ -1,0 +1,66 @@
+// arcle_big_params.h — the kernel-argument block of the workgroup-per-env kernels (arcle_big.h) and the host-side entry points of
+// arcle_big.hip; shared with arcle_hip.hip, which routes handles of more than ARCLE_MAX_CELLS cells here.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/arcle_hip.h"
+
+#ifndef ARCLE_BIG_HD
+#define ARCLE_BIG_HD
+#endif
+
+namespace arcle_big {
+
+enum { ING_MASK = 0, ING_BBOX = 1, ING_POINT = 2, ING_BBOX5 = 3 };
+enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 32, MAX_ROWS_PER_THREAD = 4 };
+
+struct BigParams {
+  int8_t* plane[ARCLE_N_PLANES];
+  int8_t* rec;
+  int32_t* cnt;
+  const int32_t* op;
+  const void* sel;  // int8 [N][P] | int32 [N][4] | int32 [N][2] | int32 [N][5]
+  int32_t* reward;
+  uint8_t* term;
+  int32_t n_envs, H, W, P, PS;
+  int32_t n_ops, max_trial, ingress;
+  uint32_t flags;
+  int32_t step_limit;
+  uint32_t* status;
+  const uint32_t* d_ops;  // ARCLE_MAX_OPS + 1 entries, slot n_ops empty
+  uint8_t* trunc;
+  int8_t* flat_out;
+  int32_t flat_stride, flat_filter, flat_tail, flat_seq;
+  uint8_t* pack_out;
+  // reset kernels
+  const uint8_t* rmask;
+  const int32_t* task_idx;
+  const int8_t *tbl_in, *tbl_ans, *tbl_in_dim, *tbl_ans_dim;
+  int32_t n_tasks;
+  uint64_t seed;
+  int64_t env_base;
+  int32_t* episode;
+  int32_t* cur_task;
+  const int32_t *pair_off, *pair_cnt;
+  int32_t n_problems;
+  // state rows in
+  const int8_t* rows_in;
+  int32_t rows_in_stride;
+};
+
+// bytes of LDS one workgroup needs: four staging planes + the reduction block + two row boards of 128 x 128 bits
+ARCLE_BIG_HD inline int lds_bytes(int PS) { return 4 * PS + 64 + 2 * 128 * 16; }  // 69 184 at 127 x 127 (gfx950: 160 KB per workgroup)
+
+ARCLE_BIG_HD inline int flat_len(int P, bool o2, bool clip, int filtered) {
+  if (filtered) return 3 * P + 10;
+  return 2 * P + 6 + (clip ? P + 2 : 0) + (o2 ? 4 * P + 6 : 0);
+}
+ARCLE_BIG_HD inline int packed_stride(int P) { return (P + 7 + 15) & ~15; }
+
+// host side (arcle_big.hip): one workgroup of 256 threads per env on `stream`; return a hipError_t as int (0 = success)
+int launch_step(const BigParams& p, void* stream);
+int launch_reset(const BigParams& p, int mode, void* stream);     // 0 arcle_reset, 1 arcle_reset_from_table, 2 arcle_reset_sampled
+int launch_rows(const BigParams& p, int mode, void* stream);      // 0 flat rows of the resident state, 1 packed rows
+int launch_set_rows(const BigParams& p, void* stream);
+
+}  // namespace arcle_big

@@ -222,6 +222,7 @@ __device__ __forceinline__ void sink_v(uint32_t v) { asm volatile("" ::"v"(v)); 
 }  // namespace xl
 
 #include "arcle_wave.h"
+#include "arcle_big_params.h"  // grids beyond ARCLE_MAX_CELLS: one workgroup per env (arcle_big.hip)
 
 using arcle::StepParams;
 using arcle::WaveLDS;
@@ -562,6 +563,7 @@ struct LaunchPlan {  // how a step launch runs (see plan_launch)
 };
 
 struct arcle_env {
+  int big;  // H * W > ARCLE_MAX_CELLS: every launch of this handle goes to the workgroup-per-env kernels of arcle_big.hip
   arcle_config cfg;
   arcle_buffers bufs;
   bool owns_bufs;
@@ -631,9 +633,12 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   if (!cfg || !out) return ARCLE_ERR_ARG;
   *out = nullptr;
   if (cfg->n_envs <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->H > 127 || cfg->W > 127 ||
-      cfg->H * cfg->W > ARCLE_MAX_CELLS || cfg->max_trial < -128 || cfg->max_trial > 127 ||
-      (uint64_t)cfg->n_envs * (uint64_t)ARCLE_MAX_CELLS >= (1ull << 32))  // 32-bit plane offsets
+      cfg->max_trial < -128 || cfg->max_trial > 127 ||
+      (uint64_t)cfg->n_envs * (uint64_t)ARCLE_MAX_CELLS >= (1ull << 32))  // 32-bit plane offsets (one-wavefront kernels)
     return ARCLE_ERR_CONFIG;
+  // more than ARCLE_MAX_CELLS cells (the reference takes any max_grid_size, base.py:37-49; dims are int8 there, hence <= 127): the
+  // handle is served by the workgroup-per-env kernels (arcle_big.hip) — same ABI, the entry points below say which they do not have
+  const bool big = cfg->H * cfg->W > ARCLE_MAX_CELLS;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ARCLE_ERR_NO_DEVICE;
   arcle_env* e = new (std::nothrow) arcle_env();
@@ -663,6 +668,7 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
     if (v == 1 || v == 2 || v == 4 || v == 8) e->wpw_override = v;
   }
   e->cfg = *cfg;
+  e->big = big ? 1 : 0;
   int caller_dev = 0;
   (void)hipGetDevice(&caller_dev);
   e->device = cfg->device >= 0 ? cfg->device : caller_dev;
@@ -677,13 +683,13 @@ extern "C" int arcle_create(const arcle_config* cfg, const arcle_buffers* bufs, 
   b.W = cfg->W;
   b.P = cfg->H * cfg->W;
   b.PS = cfg->plane_stride ? cfg->plane_stride : ARCLE_DEFAULT_PLANE_STRIDE(b.P);
-  if ((b.PS & 15) || b.PS < b.P || b.PS > ARCLE_MAX_CELLS) {
+  if ((b.PS & 15) || b.PS < b.P || b.PS > (big ? (int)arcle_big::MAX_PS : ARCLE_MAX_CELLS)) {
     delete e;
     return ARCLE_ERR_CONFIG;
   }
   b.max_trial = cfg->max_trial;
   b.div_magic = 65536u / (uint32_t)cfg->W + 1u;
-  for (uint32_t n = 0; n < ARCLE_MAX_CELLS + 16; n++)  // flat cell indices the kernel divides
+  for (uint32_t n = 0; !big && n < ARCLE_MAX_CELLS + 16; n++)  // flat cell indices the kernel divides
     if (((n * b.div_magic) >> 16) != n / (uint32_t)cfg->W) {
       delete e;
       return ARCLE_ERR_CONFIG;
@@ -764,6 +770,51 @@ extern "C" int arcle_get_buffers(const arcle_env* e, arcle_buffers* out) {
   *out = e->bufs;
   return ARCLE_OK;
 }
+
+// ---- handles of more than ARCLE_MAX_CELLS cells --------------------------------------------------------------------------------------
+static arcle_big::BigParams big_params(const arcle_env* e) {
+  const StepParams& b = e->base;
+  arcle_big::BigParams q;
+  memset(&q, 0, sizeof(q));
+  for (int i = 0; i < ARCLE_N_PLANES; i++) q.plane[i] = b.plane[i];
+  q.rec = b.rec;
+  q.cnt = b.cnt;
+  q.n_envs = b.n_envs;
+  q.H = b.H;
+  q.W = b.W;
+  q.P = b.P;
+  q.PS = b.PS;
+  q.n_ops = b.n_ops;
+  q.max_trial = b.max_trial;
+  q.step_limit = b.step_limit;
+  q.status = b.status;
+  q.d_ops = b.d_ops;
+  q.trunc = b.trunc;
+  q.tbl_in = b.tbl_in;
+  q.tbl_ans = b.tbl_ans;
+  q.tbl_in_dim = b.tbl_in_dim;
+  q.tbl_ans_dim = b.tbl_ans_dim;
+  q.n_tasks = b.n_tasks;
+  q.seed = b.seed;
+  q.env_base = b.env_base;
+  q.episode = b.episode;
+  q.cur_task = b.cur_task;
+  q.pair_off = b.pair_off;
+  q.pair_cnt = b.pair_cnt;
+  q.n_problems = b.n_problems;
+  return q;
+}
+static int big_done(arcle_env* e, int hip_rc, const char* what) {
+  if (hip_rc != 0) {
+    snprintf(e->err, sizeof(e->err), "%s failed: %s", what, hipGetErrorString((hipError_t)hip_rc));
+    return ARCLE_ERR_HIP;
+  }
+  return ARCLE_OK;
+}
+#define BIG_REFUSE(e, what)                                                                                                      \
+  do {                                                                                                                           \
+    if ((e)->big) return fail((e), ARCLE_ERR_CONFIG, what " is not available for grids of more than ARCLE_MAX_CELLS (1024) cells"); \
+  } while (0)
 
 extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n_ops) {
   if (!e || !descs) return ARCLE_ERR_ARG;
@@ -857,6 +908,12 @@ extern "C" int arcle_reset_from_table(arcle_env* e, const int32_t* task_idx, con
   if (!e || !task_idx) return ARCLE_ERR_ARG;
   DeviceGuard guard(e->device);
   if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
+  if (e->big) {
+    arcle_big::BigParams q = big_params(e);
+    q.rmask = mask;
+    q.task_idx = task_idx;
+    return big_done(e, arcle_big::launch_reset(q, 1, stream), "arcle_reset_from_table");
+  }
   StepParams p = e->base;
   p.rmask = mask;
   p.task_idx = task_idx;
@@ -874,6 +931,11 @@ static dim3 grid_for(int n_envs, int waves_per_wg) {
 extern "C" int arcle_reset(arcle_env* e, const uint8_t* mask, void* stream) {
   if (!e) return ARCLE_ERR_ARG;
   DeviceGuard guard(e->device);
+  if (e->big) {
+    arcle_big::BigParams q = big_params(e);
+    q.rmask = mask;
+    return big_done(e, arcle_big::launch_reset(q, 0, stream), "arcle_reset");
+  }
   StepParams p = e->base;
   p.rmask = mask;
   hipLaunchKernelGGL(arcle_reset_kernel, grid_for(p.n_envs), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, p);
@@ -1116,6 +1178,33 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if (flags & ~0x3ffu) return fail(e, ARCLE_ERR_ARG, "unknown step flag");
   if ((flags & ARCLE_STEP_ROWS_INCREMENTAL) && !(flags & ARCLE_STEP_FLAT_OBS)) return fail(e, ARCLE_ERR_ARG, "ARCLE_STEP_ROWS_INCREMENTAL without ARCLE_STEP_FLAT_OBS");
   DeviceGuard guard(e->device);
+  if (e->big) {
+    // one workgroup per env (arcle_big.hip).  Flags: AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE (without augmentation), CONTINUE_RULE,
+    // RESET_ON_SUBMIT, FLAT_OBS (+ tail / completion signal), PACK_OBS; ROWS_INCREMENTAL rewrites the rows in full (identical bytes)
+    if (ingress == arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_CONFIG, "bit-packed masks (rows of ARCLE_MAX_CELLS / 8 bytes) are not available for grids of more than ARCLE_MAX_CELLS cells");
+    if (flags & ARCLE_STEP_DENSE) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_DENSE is not available for grids of more than ARCLE_MAX_CELLS cells");
+    if ((flags & ARCLE_STEP_RESAMPLE) && e->base.aug_flags) return fail(e, ARCLE_ERR_CONFIG, "task augmentation is not available for grids of more than ARCLE_MAX_CELLS cells");
+    arcle_big::BigParams q = big_params(e);
+    q.ingress = ingress;
+    q.sel = sel;
+    q.op = op;
+    q.reward = reward;
+    q.term = term;
+    q.flags = flags;
+    if (flags & ARCLE_STEP_FLAT_OBS) {
+      if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
+      q.flat_out = e->flat_out;
+      q.flat_stride = e->flat_stride;
+      q.flat_filter = e->flat_filtered ? 1 : 0;
+      q.flat_tail = e->flat_tail ? 1 : 0;
+      q.flat_seq = e->flat_tail ? e->flat_seq : 0;
+    }
+    if (flags & ARCLE_STEP_PACK_OBS) {
+      if (!e->pack_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output");
+      q.pack_out = reinterpret_cast<uint8_t*>(e->pack_out);
+    }
+    return big_done(e, arcle_big::launch_step(q, stream), "arcle_step");
+  }
   // A step without ARCLE_STEP_DENSE on a handle that keeps dense pairs may move grids the cache still describes: drop the entries first
   // (stream-ordered; handles that always step with the flag never get here).  Only needed while the cache may hold pairs: a host flag,
   // set by dense steps — and stuck at "always" once a dense step was captured into a hipGraph, whose replays fill the cache unseen.
@@ -1191,6 +1280,13 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
 static size_t payload_bytes(const arcle_env* e, int ingress);
 
 extern "C" int arcle_launch_info(arcle_env* e, int ingress, uint32_t flags, int32_t* out4) {
+  if (e && out4 && e->big) {  // one workgroup of four wavefronts per env: no plan to choose
+    out4[0] = 0;
+    out4[1] = 0;
+    out4[2] = 4;
+    out4[3] = 0;
+    return ARCLE_OK;
+  }
   if (!e || !out4) return ARCLE_ERR_ARG;
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
   flags = effective_flags(e, flags);
@@ -1215,6 +1311,7 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, cons
   if (!e || !sel || (!op && ingress != arcle::INGRESS_BBOX5)) return ARCLE_ERR_ARG;
   if (ingress < 0 || ingress > arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_ARG, "unknown ingress form");
   if (n_batches <= 0) return fail(e, ARCLE_ERR_ARG, "arcle_autotune: n_batches must be positive");
+  if (e->big) return 0;  // (no candidates: the workgroup-per-env launch has one plan)
   if (flags & ~(uint32_t)(ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_PACK_OBS))
     return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: ARCLE_STEP_AUTORESET | _ELIDE_SELECTED | _PACK_OBS only (other flags keep per-env side state it does not save)");
   if (e->d_acct) return fail(e, ARCLE_ERR_CONFIG, "arcle_autotune: not with byte accounting enabled");
@@ -1362,7 +1459,7 @@ extern "C" int arcle_step_many(arcle_env* e, int ingress, int32_t n_steps, const
   // workgroups of launch t-1 filled from pinned host memory while that launch ran; only step 0 reads across PCIe itself.
   bool prefetch = false;
   // (only where the lean instantiation that carries the copy workgroups applies: the standard 30 x 30 batch with ARCVecEnv's flags)
-  const bool pf_kernel = width_class(e->base) == arcle::FW_FULL && e->base.H == 30 && e->base.W == 30 && flags == (uint32_t)HOT_FLAGS &&
+  const bool pf_kernel = !e->big && width_class(e->base) == arcle::FW_FULL && e->base.H == 30 && e->base.W == 30 && flags == (uint32_t)HOT_FLAGS &&
                          !e->d_acct && launch_wpw(e) == WAVES_PER_WG;
   if (pf_kernel && ingress == arcle::INGRESS_BBOX5 && n_steps > 1 && (n & 3) == 0 && sel) {
     hipPointerAttribute_t attr;
@@ -1420,6 +1517,7 @@ extern "C" int arcle_set_dispatch_order(arcle_env* e, int enable) {
 extern "C" int arcle_pack_mask_bits(arcle_env* e, const int8_t* sel, uint8_t* bits, void* stream) {
   if (!e || !sel || !bits) return ARCLE_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(bits) & 1) return fail(e, ARCLE_ERR_ARG, "bit-packed mask rows must be 2-byte aligned");
+  BIG_REFUSE(e, "arcle_pack_mask_bits (rows of ARCLE_MAX_CELLS / 8 bytes)");
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.sel = sel;
@@ -1473,6 +1571,19 @@ static int launch_rollout(arcle_env* e, int ingress, int32_t n_steps, const void
     return fail(e, ARCLE_ERR_CONFIG, "the rollout kernels take ARCLE_STEP_CONTINUE_RULE / _RESET_ON_SUBMIT with mask ingress only");
   if ((flags & ARCLE_STEP_PACK_OBS) && !e->pack_out)
     return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_PACK_OBS without arcle_set_packed_output (rollouts: uint8 [n_steps][n_envs][arcle_packed_obs_size()])");
+  if (e->big) {
+    // "semantically identical to n_steps calls of arcle_step_*": for the workgroup-per-env kernels that is what a rollout is (the state does
+    // not fit a wavefront's registers); with ARCLE_STEP_PACK_OBS every step's rows go to its own slice of the installed buffer
+    const size_t n = (size_t)e->cfg.n_envs, pb = payload_bytes(e, ingress);
+    int8_t* const pack0 = e->pack_out;
+    int rc = ARCLE_OK;
+    for (int32_t t = 0; t < n_steps && rc == ARCLE_OK; t++) {
+      if (pack0) e->pack_out = pack0 + (size_t)t * n * (size_t)arcle_big::packed_stride(e->base.P);
+      rc = launch_step(e, ingress, (const char*)sel + (size_t)t * pb, op + (size_t)t * n, reward + (size_t)t * n, term + (size_t)t * n, flags, stream);
+    }
+    e->pack_out = pack0;
+    return rc;
+  }
   DeviceGuard guard(e->device);
   if (e->d_dense_cache) HIP_TRY(e, hipMemsetAsync(e->d_dense_cache, 0, (size_t)e->cfg.n_envs * 8, (hipStream_t)stream));  // (rollouts move grids, keep no pairs)
   StepParams p = e->base;
@@ -1517,6 +1628,7 @@ extern "C" int arcle_set_sampler(arcle_env* e, const int32_t* pair_off, const in
   if (n_problems <= 0) return fail(e, ARCLE_ERR_CONFIG, "the sampler needs at least one problem with a pair");
   if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
   if (aug_flags & ~(ARCLE_AUG_PERMUTE | ARCLE_AUG_ROT90)) return fail(e, ARCLE_ERR_ARG, "unknown augmentation flag");
+  if (aug_flags) BIG_REFUSE(e, "task augmentation");
   e->base.pair_off = pair_off;
   e->base.pair_cnt = pair_cnt;
   e->base.n_problems = n_problems;
@@ -1532,6 +1644,11 @@ extern "C" int arcle_reset_sampled(arcle_env* e, const uint8_t* mask, void* stre
   if (!e) return ARCLE_ERR_ARG;
   if (e->base.n_problems <= 0) return fail(e, ARCLE_ERR_CONFIG, "no sampler installed (arcle_set_sampler)");
   DeviceGuard guard(e->device);
+  if (e->big) {
+    arcle_big::BigParams q = big_params(e);
+    q.rmask = mask;
+    return big_done(e, arcle_big::launch_reset(q, 2, stream), "arcle_reset_sampled");
+  }
   StepParams p = e->base;
   p.rmask = mask;
   p.task_idx = nullptr;
@@ -1544,6 +1661,10 @@ extern "C" int arcle_reset_from_table_aug(arcle_env* e, const int32_t* task_idx,
                                           const uint8_t* aug_perm, void* stream) {
   if (!e || !task_idx) return ARCLE_ERR_ARG;
   if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
+  if (e->big) {
+    if (aug_k || aug_perm) BIG_REFUSE(e, "task augmentation");
+    return arcle_reset_from_table(e, task_idx, mask, stream);
+  }
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.rmask = mask;
@@ -1557,6 +1678,7 @@ extern "C" int arcle_reset_from_table_aug(arcle_env* e, const int32_t* task_idx,
 
 extern "C" int arcle_set_dense_output(arcle_env* e, int32_t* dense_out) {
   if (!e) return ARCLE_ERR_ARG;
+  if (dense_out) BIG_REFUSE(e, "the dense reward pair (ARCLE_STEP_DENSE)");
   if (dense_out && !e->d_dense_cache) {  // the per-env cache of the current grid's pair; (0, 0) = unknown
     DeviceGuard guard(e->device);
     HIP_TRY(e, hipMalloc((void**)&e->d_dense_cache, (size_t)e->cfg.n_envs * 8));
@@ -1587,7 +1709,7 @@ extern "C" int arcle_set_truncation(arcle_env* e, uint8_t* trunc_out, int32_t st
 extern "C" int arcle_flat_obs_size(const arcle_env* e, int filtered) {
   if (!e) return ARCLE_ERR_ARG;
   if (filtered && !(e->bufs.plane[ARCLE_PL_SELECTED] && e->bufs.plane[ARCLE_PL_CLIP])) return ARCLE_ERR_CONFIG;
-  return arcle::flat_obs_len(e->base, filtered);
+  return arcle::flat_obs_len(e->base, filtered);  // (the same formula for any H x W)
 }
 
 static int launch_flatten(arcle_env* e, int8_t* out, int32_t out_stride, int filtered, hipStream_t st) {
@@ -1595,6 +1717,13 @@ static int launch_flatten(arcle_env* e, int8_t* out, int32_t out_stride, int fil
   if (len < 0) return fail(e, ARCLE_ERR_CONFIG, "the FilterO2ARC subset needs the O2ARCv2Env state planes");
   if (out_stride < len || (out_stride & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
     return fail(e, ARCLE_ERR_ARG, "flat observation rows: 16-byte aligned, stride a multiple of 16 >= arcle_flat_obs_size()");
+  if (e->big) {
+    arcle_big::BigParams q = big_params(e);
+    q.flat_out = out;
+    q.flat_stride = out_stride;
+    q.flat_filter = filtered ? 1 : 0;
+    return big_done(e, arcle_big::launch_rows(q, 0, st), "arcle_flatten_obs");
+  }
   StepParams p = e->base;
   p.flat_out = out;
   p.flat_stride = out_stride;
@@ -1657,6 +1786,13 @@ extern "C" int arcle_set_state_rows(arcle_env* e, const int8_t* rows, int32_t st
   if (!e) return ARCLE_ERR_ARG;
   if (int rc = check_rows(e, rows, stride, 0)) return rc;
   DeviceGuard guard(e->device);
+  if (e->big) {
+    arcle_big::BigParams q = big_params(e);
+    q.rows_in = rows;
+    q.rows_in_stride = stride;
+    q.rmask = mask;
+    return big_done(e, arcle_big::launch_set_rows(q, stream), "arcle_set_state_rows");
+  }
   StepParams p = e->base;
   p.rows_in = rows;
   p.rows_in_stride = stride;
@@ -1684,6 +1820,7 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
                                      int32_t out_stride, int tail, int32_t* reward, uint8_t* term, uint32_t flags, void* stream) {
   if (!e || !sel || !op || !reward || !term || !rows_out) return ARCLE_ERR_ARG;
   if (n_rows <= 0) return fail(e, ARCLE_ERR_ARG, "n_rows must be positive");
+  BIG_REFUSE(e, "arcle_transition_rows (use arcle_set_state_rows + a step + arcle_get_state_rows)");
   if (!src_env && n_rows > e->cfg.n_envs) return fail(e, ARCLE_ERR_ARG, "more rows than envs: pass src_env (which env's answer every row uses)");
   if ((uint64_t)n_rows * ARCLE_MAX_CELLS >= (1ull << 32)) return fail(e, ARCLE_ERR_ARG, "too many rows");
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
@@ -1758,6 +1895,13 @@ extern "C" int arcle_pack_obs(arcle_env* e, const int32_t* reward, const uint8_t
   if (!e || !reward || !term || !out) return ARCLE_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(out) & 15) return fail(e, ARCLE_ERR_ARG, "packed observation rows must be 16-byte aligned");
   DeviceGuard guard(e->device);
+  if (e->big) {
+    arcle_big::BigParams q = big_params(e);
+    q.reward = const_cast<int32_t*>(reward);
+    q.term = const_cast<uint8_t*>(term);
+    q.pack_out = out;
+    return big_done(e, arcle_big::launch_rows(q, 1, stream), "arcle_pack_obs");
+  }
   StepParams p = e->base;
   p.reward = const_cast<int32_t*>(reward);
   p.term = const_cast<uint8_t*>(term);
@@ -1791,6 +1935,7 @@ extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void*
 
 extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   if (!e) return ARCLE_ERR_ARG;
+  if (on) BIG_REFUSE(e, "byte accounting");
   DeviceGuard guard(e->device);
   if (on && !e->d_acct) {
     HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 64));

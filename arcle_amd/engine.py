@@ -38,20 +38,26 @@ STEP_ROWS_INCREMENTAL = 512
 AUG_PERMUTE, AUG_ROT90 = 1, 2
 ST_BAD_OP, ST_ROTATE_DOMAIN, ST_BAD_TASK, ST_BAD_SELECTION, ST_AUG_DOMAIN = 1, 2, 4, 8, 16
 ROW_TAIL = 16  # bytes of the optional step-output tail of a flat row (arcle_set_flat_output_ex)
-MAX_CELLS = 1024  # ARCLE_MAX_CELLS: one 64-lane wavefront x 16 cells per lane holds a whole H x W plane
-MAX_SIDE = 127    # dims travel as int8 in the per-env record
+MAX_CELLS = 1024  # ARCLE_MAX_CELLS: one 64-lane wavefront x 16 cells per lane holds a whole H x W plane (the one-wavefront-per-env kernels)
+MAX_SIDE = 127    # dims travel as int8 in the per-env record (and in the reference's state dict, base.py:162-166)
+
+
+def is_big_grid(H, W):
+    """More than ARCLE_MAX_CELLS cells: the handle is served by the workgroup-per-env kernels (arcle_amd/csrc/arcle_big.hip)."""
+    return int(H) * int(W) > MAX_CELLS
 
 
 def check_grid_size(H, W):
-    """The one narrowing of the reference's constructor contract (base.py:37-49 takes any max_grid_size): the HIP path keeps a
-    whole plane in one wavefront, so H * W <= 1024 and H, W <= 127 (ARC grids are at most 30 x 30).  Raised here — before any device
-    is touched — with the limit in the message; arcle_create reports the same as ARCLE_ERR_CONFIG."""
+    """The reference's constructor takes any max_grid_size (base.py:37-49) and stores the dims as int8 (base.py:162-166), so sides up to
+    127 are meaningful.  H * W <= 1024 runs on the one-wavefront-per-env kernels (ARC grids are at most 30 x 30: the headline path);
+    larger planes on the workgroup-per-env kernels — the same API minus what `EnvBatch.BIG_UNSUPPORTED` lists.  A side beyond 127 is
+    refused here, before any device is touched; arcle_create reports the same as ARCLE_ERR_CONFIG."""
     H, W = int(H), int(W)
     if H <= 0 or W <= 0:
         raise ValueError(f"max_grid_size must be positive, got ({H}, {W})")
-    if H * W > MAX_CELLS or H > MAX_SIDE or W > MAX_SIDE:
-        raise ValueError(f"max_grid_size ({H}, {W}) is outside what the HIP path supports: H * W <= {MAX_CELLS} cells "
-                         f"(ARCLE_MAX_CELLS: one wavefront holds a plane) and H, W <= {MAX_SIDE}; ARC grids are at most 30 x 30")
+    if H > MAX_SIDE or W > MAX_SIDE:
+        raise ValueError(f"max_grid_size ({H}, {W}) is outside what the HIP path supports: H, W <= {MAX_SIDE} (grid dims are int8 in the "
+                         f"state dict, as in the reference); ARC grids are at most 30 x 30")
 
 
 _hip = None
@@ -63,6 +69,9 @@ def _ptr(t):
 
 class EnvBatch:
     """n_envs envs of one kind on one GPU."""
+    # what a batch of more than 1024 cells per plane (`self.big`) does not offer — the library refuses these calls with ARCLE_ERR_CONFIG
+    BIG_UNSUPPORTED = ("step_bits / pack_mask_bits", "dense reward pairs (STEP_DENSE)", "task augmentation", "transition_rows",
+                       "byte accounting", "autotune (one launch plan)")
 
     def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None, plane_stride=None):
         check_grid_size(H, W)
@@ -74,6 +83,7 @@ class EnvBatch:
         if self.device.index is None:  # "cuda" means torch's CURRENT device, not ordinal 0 (multi-GPU ranks)
             self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
         self.N, self.H, self.W, self.P = int(n_envs), int(H), int(W), int(H) * int(W)
+        self.big = is_big_grid(H, W)
         if plane_stride is None:
             plane_stride = int(os.environ.get("ARCLE_PLANE_STRIDE", "0")) or ((self.P + 127) & ~127)  # ARCLE_DEFAULT_PLANE_STRIDE
         self.PS = int(plane_stride)  # plane stride: one aligned dwordx4 per lane

@@ -33,7 +33,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             raise NotImplementedError("rendering is outside the ported hot path (SURVEY.md §2 row 1)")
         self.loader = data_loader
         self.H, self.W = int(max_grid_size[0]), int(max_grid_size[1])
-        check_grid_size(self.H, self.W)  # (H * W <= 1024: the documented limit of the HIP path, raised before any device work)
+        check_grid_size(self.H, self.W)  # (sides <= 127; planes of more than 1024 cells run on the workgroup-per-env kernels)
         self.colors = colors
         self.max_trial = max_trial
         self.render_mode = render_mode

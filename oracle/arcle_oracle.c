@@ -26,6 +26,10 @@
 
 #include "../include/arcle_hip.h"
 
+/* The oracle's own bound: any H x W with H, W <= 127 (grid dims are int8 in the reference's state dict, base.py:162-166), i.e. also
+ * the grids beyond ARCLE_MAX_CELLS that the HIP library steps with one workgroup per env (arcle_big.hip). */
+#define ORACLE_MAX_CELLS (127 * 127)
+
 typedef struct oracle_env {
   int32_t n_envs, H, W;
   int32_t max_trial;
@@ -137,9 +141,9 @@ static void op_floodfill(view* v, const int8_t* sel, int c) {
   int x = best / v->W, y = best % v->W;
   int gh = v->rec[ARCLE_REC_GRID_DIM], gw = v->rec[ARCLE_REC_GRID_DIM + 1];
   if (x >= gh || y >= gw) return;
-  uint8_t visit[ARCLE_MAX_CELLS];
-  int16_t stack[ARCLE_MAX_CELLS * 4 + 4];
-  memset(visit, 0, sizeof visit);
+  uint8_t visit[ORACLE_MAX_CELLS];
+  int16_t stack[ORACLE_MAX_CELLS * 4 + 4];
+  memset(visit, 0, (size_t)v->H * v->W);
   int8_t col = AT(v->grid, x, y);
   int sp = 0;
   stack[sp++] = (int16_t)(x * v->W + y);
@@ -225,7 +229,7 @@ static void apply_patch_and_sel(view* v) {
 /* tile transform used by Rotate / Flip: dst[:nh,:nw] = f(src[:h,:w]), rest 0 (_pad_assign :43-47) */
 enum { T_ROT90 = 1, T_ROT180 = 2, T_ROT270 = 3, T_FLIPH = 4, T_FLIPV = 5, T_D0 = 6, T_D1 = 7 };
 static int tile_transform(view* v, int8_t* plane, int h, int w, int t) {
-  int8_t tmp[ARCLE_MAX_CELLS];
+  int8_t tmp[ORACLE_MAX_CELLS];
   int transposing = (t == T_ROT90 || t == T_ROT270 || t == T_D0 || t == T_D1);
   int nh = transposing ? w : h, nw = transposing ? h : w;
   if (nh > v->H || nw > v->W) return -1; /* reference: ValueError at object.py:45 */
@@ -253,7 +257,7 @@ static int imin(int a, int b) { return a < b ? a : b; }
 
 /* snapshot / restore of one env, used where the reference raises half-way through an op */
 typedef struct snap {
-  int8_t planes[4][ARCLE_MAX_CELLS];
+  int8_t planes[4][ORACLE_MAX_CELLS];
   int8_t rec[ARCLE_REC_BYTES];
 } snap;
 static void snap_take(const view* v, snap* s) {
@@ -357,7 +361,7 @@ static void op_copy(view* v, const int8_t* sel, int src_is_grid) {
   if (xmax > ss_h || ymax > ss_w) return; /* :301 (sic: > not >=) */
   int h = xmax - xmin + 1, w = ymax - ymin + 1;
   const int8_t* src = src_is_grid ? v->grid : v->input;
-  int8_t tmp[ARCLE_MAX_CELLS];
+  int8_t tmp[ORACLE_MAX_CELLS];
   memset(tmp, 0, (size_t)v->H * v->W); /* :307 */
   for (int i = 0; i < h; i++)
     for (int j = 0; j < w; j++) {
@@ -410,7 +414,7 @@ static void op_crop_grid(view* v, const int8_t* sel) { /* critical.py:56-66 */
   int xmin, xmax, ymin, ymax;
   get_bbox(v, sel, &xmin, &xmax, &ymin, &ymax);
   int h = xmax - xmin + 1, w = ymax - ymin + 1;
-  int8_t tmp[ARCLE_MAX_CELLS];
+  int8_t tmp[ORACLE_MAX_CELLS];
   memset(tmp, 0, (size_t)v->H * v->W);
   for (int i = 0; i < h; i++)
     for (int j = 0; j < w; j++) {
@@ -478,7 +482,7 @@ static void init_state(const oracle_env* e, view* v) {
 /* ---- public entry points (called through ctypes by oracle/oracle.py) -------------------- */
 
 oracle_env* oracle_create(int n_envs, int H, int W, int max_trial) {
-  if (n_envs <= 0 || H <= 0 || W <= 0 || H * W > ARCLE_MAX_CELLS || H > 127 || W > 127) return NULL;
+  if (n_envs <= 0 || H <= 0 || W <= 0 || H * W > ORACLE_MAX_CELLS || H > 127 || W > 127) return NULL;
   oracle_env* e = (oracle_env*)calloc(1, sizeof *e);
   e->n_envs = n_envs;
   e->H = H;
@@ -602,7 +606,7 @@ int oracle_step_bbox(oracle_env* e, const int32_t* bbox, const int32_t* op, int3
                      uint32_t flags) {
 #pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (int n = 0; n < e->n_envs; n++) {
-    int8_t sel[ARCLE_MAX_CELLS];
+    int8_t sel[ORACLE_MAX_CELLS];
     int x1 = bbox[4 * n], y1 = bbox[4 * n + 1], x2 = bbox[4 * n + 2], y2 = bbox[4 * n + 3];
     if (x1 > x2) { int t = x1; x1 = x2; x2 = t; }
     if (y1 > y2) { int t = y1; y1 = y2; y2 = t; }
@@ -620,7 +624,7 @@ int oracle_step_point(oracle_env* e, const int32_t* xy, const int32_t* op, int32
                       uint32_t flags) {
 #pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
   for (int n = 0; n < e->n_envs; n++) {
-    int8_t sel[ARCLE_MAX_CELLS];
+    int8_t sel[ORACLE_MAX_CELLS];
     int x = xy[2 * n], y = xy[2 * n + 1];
     memset(sel, 0, (size_t)e->H * e->W);
     if (x >= 0 && x < e->H && y >= 0 && y < e->W) sel[x * e->W + y] = 1;

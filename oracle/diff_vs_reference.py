@@ -6,7 +6,11 @@ This is pin (1) of the oracle (see arcle_oracle.c header): every op of every env
 stepped in lock-step in the reference (one Python env) and in the C restatement, and EVERY state
 field, the reward, `terminated`, `steps` and `submit_count` are compared after every step.
 
-    python oracle/diff_vs_reference.py [--traces 400] [--steps 120] [--seed 1]
+    python oracle/diff_vs_reference.py [--traces 400] [--steps 120] [--seed 1] [--big]
+
+--big: max_grid_size beyond 1024 cells (40x40 ... 127x127; the grids libarcle_hip.so steps with one workgroup per env,
+arcle_big.hip).  The reference's flood fill recurses once per cell (color.py:16-28), so the run raises Python's recursion
+limit and runs on a thread with a large stack — harness settings, the reference itself is untouched.
 
 Exit code 0 iff there was no mismatch.  Where the reference raises (IndexError for a bad op,
 ValueError/OverflowError inside Rotate out of its domain) the oracle must have flagged the step
@@ -54,10 +58,13 @@ def sync_reference_from_oracle(ref_env, orc):
             st[k] = v
 
 
-def run_trace(tid, seed, steps, verbose=False):
+BIG_SIZES = [(40, 40), (33, 48), (48, 33), (64, 64), (127, 127), (100, 20), (20, 100), (45, 45)]
+
+
+def run_trace(tid, seed, steps, verbose=False, big=False):
     rng = RD.SplitMix64(seed * 1000003 + tid)
     variant = ["o2arc", "o2arc", "o2arc", "o2arc_crop", "o2arc_exotic", "arc", "raw"][rng.below(7)]
-    size = [(5, 5), (10, 10), (12, 12), (30, 30), (30, 30), (7, 12), (12, 7), (3, 3)][rng.below(8)]
+    size = (BIG_SIZES if big else [(5, 5), (10, 10), (12, 12), (30, 30), (30, 30), (7, 12), (12, 7), (3, 3)])[rng.below(8)]
     H, W = size
     max_trial = [-1, -1, 3, 127, 1][rng.below(5)]
     use_bool = rng.chance(1, 3) and variant != "o2arc_exotic"  # keep_sel + bool mask: see compare()
@@ -146,11 +153,12 @@ def main():
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--big", action="store_true")
     a = ap.parse_args()
     RD.import_reference()
     total = exc = 0
     for tid in range(a.traces):
-        e, x = run_trace(tid, a.seed, a.steps, a.verbose)
+        e, x = run_trace(tid, a.seed, a.steps, a.verbose, a.big)
         total += e
         exc += x
     print(f"{a.traces} traces x {a.steps} steps: {total} mismatching steps, {exc} steps where the reference raised")
@@ -158,4 +166,13 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--big" in sys.argv:
+        import threading
+        sys.setrecursionlimit(200000)
+        threading.stack_size(1 << 30)
+        rc = []
+        t = threading.Thread(target=lambda: rc.append(main()))
+        t.start()
+        t.join()
+        sys.exit(rc[0] if rc else 2)
     sys.exit(main())

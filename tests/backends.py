@@ -40,7 +40,7 @@ def _splitmix_weights(n, seed=0xC0FFEE):
     return np.array(out, np.uint64)
 
 
-_W = _splitmix_weights(1024)
+_W = _splitmix_weights(16384)  # (fixtures of at most 1024 cells use the first 1024: the stream is a prefix)
 
 
 def checksum(a):
@@ -421,6 +421,154 @@ class EmuBackend:
         return s
 
 
+# ---- emulator of the workgroup-per-env kernels for grids beyond 1024 cells (tests/emu/big_emu.cpp runs arcle_big.h on host threads) ----
+class _BigParams(ctypes.Structure):  # mirror of arcle_big::BigParams (arcle_amd/csrc/arcle_big.h)
+    _fields_ = [("plane", ctypes.c_void_p * 8), ("rec", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
+                ("op", ctypes.c_void_p), ("sel", ctypes.c_void_p), ("reward", ctypes.c_void_p), ("term", ctypes.c_void_p),
+                ("n_envs", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("PS", ctypes.c_int32), ("n_ops", ctypes.c_int32), ("max_trial", ctypes.c_int32), ("ingress", ctypes.c_int32),
+                ("flags", ctypes.c_uint32), ("step_limit", ctypes.c_int32), ("status", ctypes.c_void_p),
+                ("d_ops", ctypes.c_void_p), ("trunc", ctypes.c_void_p), ("flat_out", ctypes.c_void_p),
+                ("flat_stride", ctypes.c_int32), ("flat_filter", ctypes.c_int32), ("flat_tail", ctypes.c_int32),
+                ("flat_seq", ctypes.c_int32), ("pack_out", ctypes.c_void_p), ("rmask", ctypes.c_void_p),
+                ("task_idx", ctypes.c_void_p), ("tbl_in", ctypes.c_void_p), ("tbl_ans", ctypes.c_void_p),
+                ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p), ("n_tasks", ctypes.c_int32),
+                ("seed", ctypes.c_uint64), ("env_base", ctypes.c_int64), ("episode", ctypes.c_void_p),
+                ("cur_task", ctypes.c_void_p), ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p),
+                ("n_problems", ctypes.c_int32), ("rows_in", ctypes.c_void_p), ("rows_in_stride", ctypes.c_int32)]
+
+
+_big_emu = None
+
+
+def big_emu_lib():
+    global _big_emu
+    if _big_emu is None:
+        d = os.path.join(ROOT, "tests", "emu")
+        so, src = os.path.join(d, "libbig_emu.so"), os.path.join(d, "big_emu.cpp")
+        hdr = os.path.join(ROOT, "arcle_amd", "csrc", "arcle_big.h")
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-o", so, src])
+        _big_emu = ctypes.CDLL(so)
+        _big_emu.big_emu_run.argtypes = [ctypes.c_int, ctypes.POINTER(_BigParams), ctypes.c_int, ctypes.c_int]
+        assert _big_emu.big_emu_params_size() == ctypes.sizeof(_BigParams), "BigParams layout drifted"
+    return _big_emu
+
+
+class BigEmuBackend(EmuBackend):
+    """arcle_big.h (one workgroup per env; H * W > 1024) on host threads.  Same surface as EmuBackend where the big path has the feature."""
+    name = "bigemu"
+    THREADS = 32  # the emulated workgroup (the product launches 256: every loop of the body is strided by the thread count)
+
+    def _params(self):
+        p = _BigParams()
+        for i, k in enumerate(PLANES):
+            p.plane[i] = self.buf[k].ctypes.data if k in self.buf else None
+        p.rec, p.cnt = self.rec.ctypes.data, self.cnt.ctypes.data
+        p.reward, p.term, p.status = self.reward.ctypes.data, self.term.ctypes.data, self.stat.ctypes.data
+        p.n_envs, p.H, p.W, p.P, p.PS = self.N, self.H, self.W, self.P, self.PS
+        p.max_trial, p.n_ops = self.max_trial, len(self.ops)
+        self._ops_arr = np.zeros(65, np.uint32)
+        self._ops_arr[:len(self.ops)] = self.ops
+        p.d_ops = self._ops_arr.ctypes.data
+        return p
+
+    def _extras(self, p):
+        for name in ("trunc", "episode", "cur_task"):
+            arr = getattr(self, name, None)
+            if arr is not None:
+                setattr(p, name, arr.ctypes.data)
+        p.step_limit = getattr(self, "step_limit", 0)
+        if getattr(self, "_sampler", None):
+            off, cnt, seed, base, aug = self._sampler
+            assert aug == 0, "no augmentation on the big-grid path"
+            p.pair_off, p.pair_cnt, p.n_problems = off.ctypes.data, cnt.ctypes.data, len(cnt)
+            p.seed, p.env_base = seed, base
+        if getattr(self, "tbl", None) is not None:
+            p.tbl_in, p.tbl_in_dim, p.tbl_ans, p.tbl_ans_dim = [t.ctypes.data for t in self.tbl]
+            p.n_tasks = len(self.tbl[0])
+        if getattr(self, "_pack", None) is not None:
+            p.pack_out = self._pack.ctypes.data
+        if getattr(self, "_flat", None) is not None:
+            out, L, filtered = self._flat
+            p.flat_out, p.flat_stride, p.flat_filter = out.ctypes.data, out.shape[1], int(filtered)
+            p.flat_tail = int(getattr(self, "_flat_tail", False))
+            p.flat_seq = int(getattr(self, "_flat_seq", 0))
+
+    def _run(self, what, p, mode=0):
+        rc = big_emu_lib().big_emu_run(what, ctypes.byref(p), mode, self.THREADS)
+        assert rc == 0, f"big-grid emulator reported error {rc}"
+
+    def reset(self, mask=None):
+        p = self._params()
+        self._extras(p)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rmask = None if m is None else m.ctypes.data
+        self._run(1, p, 0)
+
+    def reset_from_table(self, idx, mask=None, aug_k=None, aug_perm=None):
+        assert aug_k is None and aug_perm is None
+        p = self._params()
+        self._extras(p)
+        idx = np.ascontiguousarray(idx, np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rmask = None if m is None else m.ctypes.data
+        p.task_idx = idx.ctypes.data
+        self._run(1, p, 1)
+
+    def set_sampler(self, pair_off, pair_cnt, seed, env_base=0, aug_flags=0):
+        self._sampler = (np.ascontiguousarray(pair_off, np.int32), np.ascontiguousarray(pair_cnt, np.int32), seed, env_base, aug_flags)
+        self.episode = np.zeros(self.N, np.int32)
+        self.cur_task = np.full(self.N, -1, np.int32)
+
+    def reset_sampled(self, mask=None):
+        p = self._params()
+        self._extras(p)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rmask = None if m is None else m.ctypes.data
+        self._run(1, p, 2)
+
+    def set_truncation(self, limit):
+        self.trunc = np.zeros(self.N, np.uint8)
+        self.step_limit = int(limit)
+
+    def step(self, ingress, payload, op, flags=0):
+        p = self._params()
+        self._extras(p)
+        if ingress == "mask":
+            pay = np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(self.N, self.P)
+        else:
+            pay = np.ascontiguousarray(payload, np.int32)
+        opa = np.ascontiguousarray(op if op is not None else np.zeros(self.N), np.int32)
+        p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
+        self._run(0, p)
+        return self.reward.copy(), self.term.copy()
+
+    def flat_obs(self, filtered=False):
+        L = self._flat_len(filtered)
+        out = np.full((self.N, (L + 15) & ~15), 0x55, np.int8)
+        p = self._params()
+        p.flat_out, p.flat_stride, p.flat_filter = out.ctypes.data, out.shape[1], int(filtered)
+        self._run(2, p, 0)
+        assert not out[:, L:].any()
+        return out[:, :L].copy()
+
+    def packed_obs(self):
+        out = np.full((self.N, (self.P + 7 + 15) & ~15), 0x55, np.uint8)
+        p = self._params()
+        p.pack_out = out.ctypes.data
+        self._run(2, p, 1)
+        return out
+
+    def set_state_rows(self, rows, mask=None):
+        p = self._params()
+        rows = np.ascontiguousarray(rows, np.int8)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p.rows_in, p.rows_in_stride = rows.ctypes.data, rows.shape[1]
+        p.rmask = None if m is None else m.ctypes.data
+        self._run(3, p)
+
+
 # ---- HIP (the product, through arcle_amd.engine -> libarcle_hip.so C ABI) ------------------------------
 class HipBackend:
     name = "hip"
@@ -581,7 +729,12 @@ BACKENDS = {"oracle": OracleBackend, "emu": EmuBackend, "hip": HipBackend}
 # ---- golden fixtures ------------------------------------------------------------------------------------
 def fixture_names():
     """Trace fixtures of tests/golden/make_golden.py (research.npz has its own layout, tests/features.py)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "research.npz")
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "research.npz" and not f.startswith("big_"))
+
+
+def big_fixture_names():
+    """Trace fixtures of tests/golden/make_golden_big.py: max_grid_size beyond 1024 cells (the workgroup-per-env kernels)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("big_"))
 
 
 def load_fixture(name):

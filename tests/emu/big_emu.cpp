@@ -1,0 +1,83 @@
+// big_emu.cpp — TEST INFRASTRUCTURE: runs the workgroup-per-env kernel bodies of arcle_amd/csrc/arcle_big.h on the CPU, so that their
+// logic can be checked against the oracle without a GPU.  A "workgroup" is `nthreads` host threads (>= 32) that walk the envs together;
+// the workgroup barrier is a pthread barrier, LDS is one shared buffer, LDS atomics are GCC atomics.  Never part of the product.
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#define ARCLE_BIG_DEV inline
+#define ARCLE_BIG_HD
+
+namespace bx {
+static thread_local int t_tid;
+static int g_nt;
+static pthread_barrier_t g_bar;
+inline int tid() { return t_tid; }
+inline int nt() { return g_nt; }
+inline void sync() { pthread_barrier_wait(&g_bar); }
+inline void sync_release() { sync(); }
+inline void lds_or(int32_t* a, int v) { __atomic_fetch_or(a, v, __ATOMIC_RELAXED); }
+inline void lds_add(int32_t* a, int v) { __atomic_fetch_add(a, v, __ATOMIC_RELAXED); }
+inline void lds_min(int32_t* a, int v) {
+  int32_t cur = __atomic_load_n(a, __ATOMIC_RELAXED);
+  while (v < cur && !__atomic_compare_exchange_n(a, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+}
+inline void lds_max(int32_t* a, int v) {
+  int32_t cur = __atomic_load_n(a, __ATOMIC_RELAXED);
+  while (v > cur && !__atomic_compare_exchange_n(a, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+}
+inline void lds_umax(uint32_t* a, uint32_t v) {
+  uint32_t cur = __atomic_load_n(a, __ATOMIC_RELAXED);
+  while (v > cur && !__atomic_compare_exchange_n(a, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+}
+inline void status_or(uint32_t* g, uint32_t v) { __atomic_fetch_or(g, v, __ATOMIC_RELAXED); }
+inline uint64_t brev64(uint64_t x) {
+  x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+  return __builtin_bswap64(x);
+}
+inline void release_store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+}  // namespace bx
+
+#include "../../arcle_amd/csrc/arcle_big.h"
+
+using arcle_big::BigParams;
+
+extern "C" int big_emu_params_size(void) { return (int)sizeof(BigParams); }
+extern "C" int big_emu_lds_bytes(int PS) { return arcle_big::lds_bytes(PS); }
+
+// what: 0 step, 1 reset (mode 0 / 1 / 2), 2 rows out (mode 0 flat / 1 packed), 3 state rows in
+extern "C" int big_emu_run(int what, const BigParams* p, int mode, int nthreads) {
+  if (nthreads < arcle_big::MIN_THREADS || p->PS > arcle_big::MAX_PS) return -1;
+  void* lds = nullptr;
+  if (posix_memalign(&lds, 64, (size_t)arcle_big::lds_bytes(p->PS))) return -2;
+  memset(lds, 0x5a, (size_t)arcle_big::lds_bytes(p->PS));  // LDS is not zero at kernel start
+  bx::g_nt = nthreads;
+  pthread_barrier_init(&bx::g_bar, nullptr, (unsigned)nthreads);
+  std::vector<std::thread> th;
+  for (int k = 0; k < nthreads; k++)
+    th.emplace_back([=]() {
+      bx::t_tid = k;
+      for (int env = 0; env < p->n_envs; env++) {
+        switch (what) {
+          case 0: arcle_big::step_env(*p, env, (int8_t*)lds); break;
+          case 1: arcle_big::reset_env(*p, env, mode, (int8_t*)lds); break;
+          case 2: arcle_big::rows_env(*p, env, mode, (int8_t*)lds); break;
+          default: arcle_big::set_rows_env(*p, env, (int8_t*)lds); break;
+        }
+        bx::sync();  // the next env's "workgroup" starts after this one has finished
+      }
+    });
+  for (auto& t : th) t.join();
+  pthread_barrier_destroy(&bx::g_bar);
+  free(lds);
+  return 0;
+}

@@ -42,7 +42,7 @@ def weights(n):
     return np.array([r.next() | 1 for _ in range(n)], np.uint64)
 
 
-_W = weights(1024)
+_W = weights(16384)  # (a prefix of the same stream: fixtures of at most 1024 cells are unchanged)
 
 
 def checksum(a):

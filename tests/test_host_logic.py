@@ -209,10 +209,11 @@ def test_augmentation_draw_mirror_matches_the_scalar_mirror():
             assert kk == int(k[i]) and pp == perm[i].tolist()
 
 
-@pytest.mark.parametrize("size", [(33, 32), (32, 33), (1, 1025), (128, 4), (40, 40)])
-def test_grid_larger_than_one_wavefront_is_refused_by_name(size):
-    """The reference takes any max_grid_size (base.py:37-49); the HIP path keeps a plane in ONE wavefront: H * W <= 1024, H, W <= 127.
-    Every constructor refuses a larger grid with a ValueError that names the limit — before it touches a device (this runs on CPU)."""
+@pytest.mark.parametrize("size", [(128, 4), (4, 128), (200, 200)])
+def test_grid_side_beyond_int8_is_refused_by_name(size):
+    """The reference takes any max_grid_size (base.py:37-49) but stores the dims as int8 (base.py:162-166): sides up to 127 are served (planes of
+    more than 1024 cells by the workgroup-per-env kernels, tests/test_big_*.py); a longer side is refused by every constructor with a
+    ValueError that names the limit — before it touches a device (this runs on CPU)."""
     from arcle_amd.engine import EnvBatch
     from arcle_amd.envs import ARCEnv, ARCVecEnv, O2ARCv2Env, RawARCEnv
     from arcle_amd.loaders import SyntheticLoader
@@ -220,13 +221,18 @@ def test_grid_larger_than_one_wavefront_is_refused_by_name(size):
     for make in (lambda: EnvBatch(4, *size), lambda: O2ARCv2Env(data_loader=loader, max_grid_size=size),
                  lambda: ARCEnv(data_loader=loader, max_grid_size=size), lambda: RawARCEnv(data_loader=loader, max_grid_size=size),
                  lambda: ARCVecEnv(O2ARCv2Env, 4, loader, max_grid_size=size)):
-        with pytest.raises(ValueError, match=r"H \* W <= 1024"):
+        with pytest.raises(ValueError, match=r"H, W <= 127"):
             make()
 
 
 def test_largest_supported_grids_pass_the_size_check():
     from arcle_amd.engine import check_grid_size
+    from arcle_amd.engine import is_big_grid
     for size in ((32, 32), (30, 30), (8, 127), (127, 8), (1, 127), (1, 1)):
         check_grid_size(*size)
+        assert not is_big_grid(*size)
+    for size in ((33, 32), (40, 40), (127, 127), (9, 127)):
+        check_grid_size(*size)
+        assert is_big_grid(*size)
     with pytest.raises(ValueError):
         check_grid_size(0, 5)
