@@ -1,0 +1,162 @@
+"""Grids beyond 1024 cells on the GPU: the workgroup-per-env kernels (arcle_amd/csrc/arcle_big.hip) through the C ABI, against the golden
+vectors captured from the reference at those sizes and against the oracle.  The reference takes any max_grid_size (base.py:37-49)."""
+import numpy as np
+import pytest
+
+import backends as B
+import bigcases as C
+from oracle import oracle as O
+from oracle import refdriver as RD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", B.big_fixture_names())
+def test_hip_reproduces_big_golden(name):
+    errs = B.replay_fixture(B.HipBackend, name)
+    assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("H,W", [(40, 40), (33, 48), (48, 33), (64, 64), (127, 127), (127, 9), (9, 127), (100, 20)])
+@pytest.mark.parametrize("kind,flags,max_trial", [("o2arc", 0, -1), ("o2arc", 3, 3), ("arc", 1, 3), ("raw", 0, 2)])
+def test_hip_big_random_traces_vs_oracle(H, W, kind, flags, max_trial):
+    O.set_threads(16)
+    try:
+        errs = B.random_trace_compare(B.HipBackend, kind, O.KIND_OPS[kind](), H, W, N=48, S=48, seed=H * 131 + W + flags, max_trial=max_trial,
+                                      flags=flags, bad_ops=True)
+    finally:
+        O.set_threads(1)
+    assert not errs, "\n".join(errs[:10])
+
+
+def test_hip_big_batch_of_2048_envs_50x50():
+    """every env of a 2048-env batch against the oracle (the workgroup count exceeds the chip's resident workgroups several times over)"""
+    O.set_threads(16)
+    try:
+        errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), 50, 50, N=2048, S=24, seed=77, max_trial=3, flags=3, new_forms=False)
+    finally:
+        O.set_threads(1)
+    assert not errs, "\n".join(errs[:10])
+
+
+def test_hip_big_record_form():
+    """BBoxWrapper 5-tuples as ONE record per env (arcle_step_bbox5); bit-packed masks are refused by name"""
+    import torch
+    from arcle_amd._lib import ArcleHipError
+    errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), 40, 40, N=16, S=0, seed=1)
+    be = B.HipBackend(16, 40, 40, 3, "o2arc", O.o2arc_ops())
+    orc = B.OracleBackend(16, 40, 40, 3, "o2arc", O.o2arc_ops())
+    rng = np.random.default_rng(5)
+    inp = rng.integers(0, 10, (16, 40, 40)).astype(np.int8)
+    dims = np.full((16, 2), 40, np.int8)
+    for b_ in (be, orc):
+        b_.set_tasks(inp, dims, inp, dims)
+        b_.reset()
+    for s in range(30):
+        act = np.stack([rng.integers(0, 40, 16), rng.integers(0, 40, 16), rng.integers(0, 40, 16), rng.integers(0, 40, 16), rng.integers(0, 35, 16)], 1)
+        r1, t1 = be.step("bbox5", act, None, 3)
+        r2, t2 = orc.step("bbox5", act, None, 3)
+        assert np.array_equal(r1, r2) and np.array_equal(t1, t2)
+        for f in ("grid", "selected", "object", "clip", "background", "object_sel"):
+            assert np.array_equal(be.get(f), orc.get(f)), (s, f)
+    with pytest.raises(ArcleHipError, match="ARCLE_MAX_CELLS"):
+        be.b.step_bits(torch.zeros((16, 128), dtype=torch.uint8, device=be.b.device), torch.zeros(16, dtype=torch.int32, device=be.b.device), 0)
+    assert not errs
+
+
+@pytest.mark.parametrize("variant", ["o2arc_exotic", "o2arc_crop"])
+@pytest.mark.parametrize("size", [45, 127])
+def test_hip_big_exotic_tables(variant, size):
+    kind, ops = RD.variant_table(variant)
+    w = [1] * 35
+    for k in range(20, 28):
+        w[k] = 4
+    errs = B.random_trace_compare(B.HipBackend, kind, ops, size, size, N=32, S=100, seed=len(variant) + size, op_weights=w, bad_ops=True)
+    assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("H,W", [(40, 40), (64, 64), (127, 127), (33, 100)])
+def test_hip_big_floodfill_worst_case(H, W):
+    errs = B.floodfill_worst_case_compare(B.HipBackend, H, W)
+    assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("kind", ["o2arc", "arc", "raw"])
+def test_hip_big_rows(kind):
+    C.rows_case(B.HipBackend, kind)
+
+
+def test_hip_big_truncation_and_autoreset():
+    C.truncation_case(B.HipBackend)
+
+
+def test_hip_big_task_table_and_device_draw():
+    C.task_table_case(B.HipBackend)
+
+
+def test_hip_big_rollout_is_n_step_launches():
+    """arcle_rollout_bbox on a big handle = n_steps step launches (the state does not fit a wavefront): same results as stepping"""
+    H = W = 40
+    N, T = 24, 12
+    rng = np.random.default_rng(8)
+    a = B.HipBackend(N, H, W, 3, "o2arc", O.o2arc_ops())
+    b_ = B.HipBackend(N, H, W, 3, "o2arc", O.o2arc_ops())
+    inp = rng.integers(0, 10, (N, H, W)).astype(np.int8)
+    dims = np.full((N, 2), H, np.int8)
+    for be in (a, b_):
+        be.set_tasks(inp, dims, inp, dims)
+        be.reset()
+    bbox = np.stack([rng.integers(0, H, (T, N)), rng.integers(0, W, (T, N)), rng.integers(0, H, (T, N)), rng.integers(0, W, (T, N))], 2)
+    op = rng.integers(0, 35, (T, N))
+    r, t = a.rollout("bbox", bbox, op, 3)
+    for s in range(T):
+        r1, t1 = b_.step("bbox", bbox[s], op[s], 3)
+        assert np.array_equal(r[s], r1) and np.array_equal(t[s], t1)
+    for f in ("grid", "selected", "object", "clip"):
+        assert np.array_equal(a.get(f), b_.get(f))
+
+
+def test_hip_big_vec_env_and_single_env_api():
+    """ARCVecEnv and the Gymnasium single-env class at max_grid_size (40, 40): reset, steps, observations against the oracle"""
+    import torch
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    loader = SyntheticLoader(n_tasks=8, seed=3, max_size=(40, 40))
+    venv = ARCVecEnv(O2ARCv2Env, 64, loader, max_grid_size=(40, 40), autoreset=True, rng=np.random.default_rng(0), seed=5)
+    obs, info = venv.reset()
+    assert obs["grid"].shape == (64, 40, 40)
+    orc = B.OracleBackend(64, 40, 40, -1, "o2arc", O.o2arc_ops())
+    orc.set_tasks(venv.batch.plane("input").cpu().numpy(), venv.batch.field("input_dim").cpu().numpy(),
+                  venv.batch.plane("answer").cpu().numpy(), venv.batch.field("answer_dim").cpu().numpy())
+    orc.reset()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for _ in range(16):
+        bbox = torch.randint(0, 40, (64, 4), generator=g, dtype=torch.int32)
+        op = torch.randint(0, 35, (64,), generator=g, dtype=torch.int32)
+        obs, reward, term, trunc, info = venv.step_bbox(bbox.cuda(), op.cuda())
+        r2, t2 = orc.step("bbox", bbox.numpy(), op.numpy(), 1)
+        assert np.array_equal(reward.cpu().numpy(), r2) and np.array_equal(term.cpu().numpy().astype(np.uint8), t2)
+        assert np.array_equal(obs["grid"].cpu().numpy(), orc.get("grid"))
+        assert np.array_equal(obs["selected"].cpu().numpy(), orc.get("selected"))
+    venv.check_errors()
+    env = O2ARCv2Env(data_loader=loader, max_grid_size=(40, 40), colors=10)
+    obs, info = env.reset(options={"prob_index": 1, "subprob_index": 0})
+    o1 = B.OracleBackend(1, 40, 40, -1, "o2arc", O.o2arc_ops())
+    inp = np.zeros((1, 40, 40), np.int8)
+    ans = np.zeros((1, 40, 40), np.int8)
+    inp[0, :env.input_.shape[0], :env.input_.shape[1]] = env.input_
+    ans[0, :env.answer.shape[0], :env.answer.shape[1]] = env.answer
+    o1.set_tasks(inp, np.array([env.input_.shape], np.int8), ans, np.array([env.answer.shape], np.int8))
+    o1.reset()
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        sel = np.zeros((40, 40), np.int8)
+        x, y = rng.integers(0, 36), rng.integers(0, 36)
+        sel[x:x + rng.integers(1, 5), y:y + rng.integers(1, 5)] = 1
+        op = int(rng.integers(0, 35))
+        obs, reward, term, trunc, info = env.step({"selection": sel, "operation": op})
+        r2, t2 = o1.step("mask", sel[None], np.array([op], np.int32), 0)
+        assert reward == int(r2[0]) and term == bool(t2[0])
+        assert np.array_equal(obs["grid"], o1.get("grid")[0]) and np.array_equal(obs["selected"], o1.get("selected")[0])
+        assert np.array_equal(obs["object_states"]["object"], o1.get("object")[0])
+        assert info["steps"] == int(o1.counters()[0, 0])
