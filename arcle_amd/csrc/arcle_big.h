@@ -451,7 +451,8 @@ ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int 
 
 // _apply_patch (object.py:113-138) + _apply_sel (object.py:140-165): grid := background, selected := 0, then the object tile `O`
 // (LDS, tile origin at cell 0) is drawn at object_pos wherever it is > 0 and `Q` becomes the selection there; clipped to grid_dim.
-ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const int8_t* O, const int8_t* Q) {
+// `cut`: nullptr when `bg` is the background itself; else `bg` is the grid and the background is where(cut > 0, 0, grid) (object.py:87-88).
+ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q) {
   const int W = x.W;
   const int px = r[ARCLE_REC_OBJECT_POS], py = r[ARCLE_REC_OBJECT_POS + 1];
   const int h = r[ARCLE_REC_OBJECT_DIM], w = r[ARCLE_REC_OBJECT_DIM + 1];
@@ -461,14 +462,16 @@ ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const 
   const int stx = imax(px, 0), edx = imin(gh, xh), sty = imax(py, 0), edy = imin(gw, yw);
   for (int c = x.tid; c < x.nch; c += x.NT) {
     Chunk sel = zero_chunk();
+    const Chunk bgc = ldg(bg, c);
+    const Chunk cutc = cut ? ldg(cut, c) : zero_chunk();
     const Chunk grid = build_chunk(c, W, x.P, [&](int f, int i, int j) {
-      int8_t gv = bg[f];
-      if (draw && i >= stx && i < edx && j >= sty && j < edy) {
-        const int t = (i - px) * W + (j - py);
-        const int8_t pv = O[t];
-        if (pv > 0) gv = pv;        // :138 where=(p > 0)
-        sel.b[f & 15] = Q[t];       // :165
-      }
+      const int k = f & 15;
+      const bool in = draw && i >= stx && i < edx && j >= sty && j < edy;
+      const int t = in ? (i - px) * W + (j - py) : 0;
+      const int8_t pv = O[t], qv = Q[t];  // (unconditional reads at a clamped index, see the lift)
+      int8_t gv = cutc.b[k] > 0 ? (int8_t)0 : bgc.b[k];
+      if (in && pv > 0) gv = pv;              // :138 where=(p > 0)
+      sel.b[k] = in ? qv : (int8_t)0;         // :165
       return gv;
     });
     stg(x.g(ARCLE_PL_GRID), c, grid);
@@ -545,6 +548,40 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     if (kind == ARCLE_OP_NONE) {  // reference: IndexError / TypeError before any mutation
       st |= ARCLE_ST_BAD_OP;
       break;
+    }
+
+    // ---- the plane the op will gather from, requested into A NOW: its round trip overlaps the selection's (one dependent memory phase
+    // fewer per step).  For an object op under mask ingress whether the selection is fresh is only known after the reduction: the grid
+    // is the guess (a continuing object restages its background below); tuple selections know at once. ----
+    int staged = -1;  // the plane A holds (arcle_plane) once the ingest barrier has passed
+    bool staged_obj = false;  // ... and B / C hold the stored object / object_sel
+    {
+      const bool tuple = p.ingress != ING_MASK;
+      bool tuple_any = false;
+      if (p.ingress == ING_POINT) tuple_any = (uint32_t)pay[0] < (uint32_t)H && (uint32_t)pay[1] < (uint32_t)W;
+      else if (tuple) tuple_any = (uint32_t)imin(pay[0], pay[2]) < (uint32_t)H && (uint32_t)imin(pay[1], pay[3]) < (uint32_t)W;
+      const bool will_be_active = (oflags & ARCLE_OPF_RESET_SEL) ? false : r[ARCLE_REC_ACTIVE] != 0;
+      switch (kind) {
+        case ARCLE_OP_FLOODFILL:
+        case ARCLE_OP_CROP_GRID: staged = ARCLE_PL_GRID; break;
+        case ARCLE_OP_COPY: staged = arg ? ARCLE_PL_GRID : ARCLE_PL_INPUT; break;
+        case ARCLE_OP_PASTE: staged = ARCLE_PL_CLIP; break;
+        case ARCLE_OP_MOVE:
+        case ARCLE_OP_ROTATE:
+        case ARCLE_OP_FLIP:
+          if (!tuple || tuple_any) staged = ARCLE_PL_GRID;
+          else if (will_be_active) {
+            staged = ARCLE_PL_BACKGROUND;
+            staged_obj = true;
+          }
+          break;
+        default: break;
+      }
+      if (staged >= 0) x.stage(x.A, x.g(staged));
+      if (staged_obj) {
+        x.stage(x.B, x.g(ARCLE_PL_OBJECT));
+        x.stage(x.C, x.g(ARCLE_PL_OBJECT_SEL));
+      }
     }
 
     // ---- selection -> S (bytes in LDS) + its reductions -------------------------------------------------------------------------
@@ -753,9 +790,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const int sx = amax_cell / W, sy = amax_cell - sx * W;
         const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1];
         if (sx >= gh || sy >= gw) break;
-        x.stage(x.A, x.g(ARCLE_PL_GRID));
-        bx::sync();
-        flood_fill(x, gh, gw, sx, sy, arg);
+        flood_fill(x, gh, gw, sx, sy, arg);  // (the grid is in A)
         break;
       }
       case ARCLE_OP_MOVE:
@@ -763,34 +798,38 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       case ARCLE_OP_FLIP: {
         if (!obj_go) break;
         int8_t *O = x.B, *Q = x.C;  // object / object_sel tiles
+        bool bg_in_A = false;        // A holds the background itself (else: the grid, and the background is where(sel > 0, 0, grid))
+        const bool transform = kind != ARCLE_OP_MOVE;
         if (fresh) {  // object.py:67-99
-          x.stage(x.A, x.g(ARCLE_PL_GRID));
-          bx::sync();
+          if (staged != ARCLE_PL_GRID) {
+            x.stage(x.A, x.g(ARCLE_PL_GRID));
+            bx::sync();
+          }
           for (int c = tid; c < nch; c += NT) {
             Chunk qs = zero_chunk();
+            // (every gather below reads LDS UNCONDITIONALLY at a clamped index and selects afterwards: the 16 cells' reads are then
+            // independent and issue back to back — reads under a branch wait for one another, profiles/round5_experiments.txt §15)
             const Chunk ob = build_chunk(c, W, P, [&](int f, int i, int j) {
-              int8_t v = 0;
-              if (i < oh && j < ow) {
-                const int s = (x0 + i) * W + (y0 + j);
-                if (x.S[s] > 0) {  // :78 sel > 0
-                  v = x.A[s];      // :81
-                  qs.b[f & 15] = 1;  // :84
-                }
-              }
-              return v;
+              const bool in = i < oh && j < ow;
+              const int s = in ? (x0 + i) * W + (y0 + j) : 0;
+              const int8_t sv = x.S[s], av = x.A[s];
+              const bool part = in && sv > 0;          // :78 sel > 0
+              qs.b[f & 15] = part ? (int8_t)1 : (int8_t)0;  // :84
+              return part ? av : (int8_t)0;            // :81
             });
             stg(x.B, c, ob);
             stg(x.C, c, qs);
-          }
-          bx::sync();
-          for (int c = tid; c < nch; c += NT) {  // background = where(sel > 0, 0, grid)  :87-88
-            Chunk gr = ldg(x.A, c);
-            const Chunk s = ldg(x.S, c);
+            if (!transform) {  // Move: the lifted tiles are final
+              stg(x.g(ARCLE_PL_OBJECT), c, ob);
+              stg(x.g(ARCLE_PL_OBJECT_SEL), c, qs);
+              // background = where(sel > 0, 0, grid)  :87-88 — this thread's own chunk; place() forms it again from A and S
+              Chunk gr = ldg(x.A, c);
+              const Chunk sm = ldg(x.S, c);
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-              if (s.b[k] > 0) gr.b[k] = 0;
-            stg(x.A, c, gr);
-            stg(x.g(ARCLE_PL_BACKGROUND), c, gr);
+              for (int k = 0; k < 16; k++)
+                if (sm.b[k] > 0) gr.b[k] = 0;
+              stg(x.g(ARCLE_PL_BACKGROUND), c, gr);
+            }
           }
           r[ARCLE_REC_OBJECT_DIM] = (int8_t)oh;
           r[ARCLE_REC_OBJECT_DIM + 1] = (int8_t)ow;
@@ -799,33 +838,50 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           r[ARCLE_REC_ACTIVE] = 1;
           r[ARCLE_REC_PARITY] = 0;
           // (selected = sel, :96 — place() below rewrites the whole plane)
-        } else {  // :102-107 the stored object continues
-          x.stage(x.A, x.g(ARCLE_PL_BACKGROUND));
-          x.stage(x.B, x.g(ARCLE_PL_OBJECT));
-          x.stage(x.C, x.g(ARCLE_PL_OBJECT_SEL));
+        } else {  // :102-107 the stored object continues (the selection is empty: S is all zero)
+          if (!staged_obj) {
+            if (staged >= 0) bx::sync();  // (a mask selection that turned out empty: every thread is done with the guessed plane)
+            x.stage(x.A, x.g(ARCLE_PL_BACKGROUND));
+            x.stage(x.B, x.g(ARCLE_PL_OBJECT));
+            x.stage(x.C, x.g(ARCLE_PL_OBJECT_SEL));
+          }
+          bg_in_A = true;
         }
         bx::sync();
-        if (kind == ARCLE_OP_MOVE) {  // gen_move(d), object.py:230-240
+        if (!transform) {  // gen_move(d), object.py:230-240
           const int dx = (arg == 0) ? -1 : (arg == 1) ? 1 : 0;
           const int dy = (arg == 2) ? 1 : (arg == 3) ? -1 : 0;
           r[ARCLE_REC_OBJECT_POS] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS] + dx);  // :238, int8 wrap
           r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS + 1] + dy);
-          if (fresh) {
-            for (int c = tid; c < nch; c += NT) {
-              stg(x.g(ARCLE_PL_OBJECT), c, ldg(x.B, c));
-              stg(x.g(ARCLE_PL_OBJECT_SEL), c, ldg(x.C, c));
-            }
-          }
         } else {
-          // dst[:nh,:nw] = T(src[:h,:w]), rest 0 (_pad_assign, object.py:43-47): object B -> S, then object_sel C -> B
+          // dst[:nh,:nw] = T(src[:h,:w]), rest 0 (_pad_assign, object.py:43-47): object B -> S, then object_sel C -> B.  A thread
+          // overwrites S only at its OWN chunks, after it has formed the background of those chunks from them (fresh selections).
           for (int c = tid; c < nch; c += NT) {
-            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) { return (i < nh && j < nw) ? x.B[c0 + ai * i + bj * j] : (int8_t)0; });
+            if (fresh) {  // background = where(sel > 0, 0, grid)  :87-88, into A in place (the lift is done with the grid)
+              Chunk gr = ldg(x.A, c);
+              const Chunk sm = ldg(x.S, c);
+#pragma unroll
+              for (int k = 0; k < 16; k++)
+                if (sm.b[k] > 0) gr.b[k] = 0;
+              stg(x.A, c, gr);
+              stg(x.g(ARCLE_PL_BACKGROUND), c, gr);
+            }
+            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) {
+              const bool in = i < nh && j < nw;
+              const int8_t v = x.B[in ? c0 + ai * i + bj * j : 0];
+              return in ? v : (int8_t)0;
+            });
             stg(x.S, c, t);
             stg(x.g(ARCLE_PL_OBJECT), c, t);
           }
+          bg_in_A = true;
           bx::sync();
           for (int c = tid; c < nch; c += NT) {
-            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) { return (i < nh && j < nw) ? x.C[c0 + ai * i + bj * j] : (int8_t)0; });
+            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) {
+              const bool in = i < nh && j < nw;
+              const int8_t v = x.C[in ? c0 + ai * i + bj * j : 0];
+              return in ? v : (int8_t)0;
+            });
             stg(x.B, c, t);
             stg(x.g(ARCLE_PL_OBJECT_SEL), c, t);
           }
@@ -840,7 +896,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           }
           bx::sync();
         }
-        place(x, r, x.A, O, Q);
+        place(x, r, x.A, bg_in_A ? nullptr : x.S, O, Q);
         break;
       }
       case ARCLE_OP_COPY: {  // gen_copy(source), object.py:291-312
@@ -849,16 +905,13 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const int ss_h = r[so], ss_w = r[so + 1];
         if (x1 > ss_h || y1 > ss_w) break;  // :301 (sic: > not >=)
         const int h = x1 - x0 + 1, w = y1 - y0 + 1;
-        x.stage(x.A, x.g(arg ? ARCLE_PL_GRID : ARCLE_PL_INPUT));
-        bx::sync();
+        // (the source plane is in A)
         for (int c = tid; c < nch; c += NT)
           stg(x.g(ARCLE_PL_CLIP), c, build_chunk(c, W, P, [&](int, int i, int j) {
-                int8_t v = 0;
-                if (i < h && j < w) {
-                  const int s = (x0 + i) * W + (y0 + j);
-                  if (x.S[s] != 0) v = x.A[s];  // :310-312 where=logical_and(src, sel)
-                }
-                return v;
+                const bool in = i < h && j < w;
+                const int s = in ? (x0 + i) * W + (y0 + j) : 0;
+                const int8_t sv = x.S[s], av = x.A[s];
+                return (in && sv != 0) ? av : (int8_t)0;  // :310-312 where=logical_and(src, sel)
               }));
         r[ARCLE_REC_CLIP_DIM] = (int8_t)h;
         r[ARCLE_REC_CLIP_DIM + 1] = (int8_t)w;
@@ -869,18 +922,14 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const int h = r[ARCLE_REC_CLIP_DIM], w = r[ARCLE_REC_CLIP_DIM + 1];
         if (h == 0 || w == 0) break;  // :334
         const int ex = imin(x0 + h, H), ey = imin(y0 + w, W);  // :340-341 clipped to H x W, not grid_dim
-        x.stage(x.A, x.g(ARCLE_PL_CLIP));
-        bx::sync();
+        // (the clip plane is in A)
         const int c_first = (x0 * W) >> 4, c_last = imin(nch - 1, (ex * W) >> 4);
         for (int c = c_first + tid; c <= c_last; c += NT) {
           const Chunk gr = ldg(x.g(ARCLE_PL_GRID), c);
           stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int f, int i, int j) {
-                int8_t v = gr.b[f & 15];
-                if (i >= x0 && i < ex && j >= y0 && j < ey) {
-                  const int8_t pv = x.A[(i - x0) * W + (j - y0)];
-                  if (arg || pv > 0) v = pv;  // :345-348
-                }
-                return v;
+                const bool in = i >= x0 && i < ex && j >= y0 && j < ey;
+                const int8_t pv = x.A[in ? (i - x0) * W + (j - y0) : 0];
+                return (in && (arg || pv > 0)) ? pv : gr.b[f & 15];  // :345-348
               }));
         }
         break;
@@ -904,17 +953,13 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       }
       case ARCLE_OP_CROP_GRID: {  // critical.py:56-66
         if (!any_nz) break;
-        const int h = x1 - x0 + 1, w = y1 - y0 + 1;
-        x.stage(x.A, x.g(ARCLE_PL_GRID));
-        bx::sync();
+        const int h = x1 - x0 + 1, w = y1 - y0 + 1;  // (the grid is in A)
         for (int c = tid; c < nch; c += NT)
           stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int, int i, int j) {
-                int8_t v = 0;
-                if (i < h && j < w) {
-                  const int s = (x0 + i) * W + (y0 + j);
-                  if (x.S[s] != 0) v = x.A[s];
-                }
-                return v;
+                const bool in = i < h && j < w;
+                const int s = in ? (x0 + i) * W + (y0 + j) : 0;
+                const int8_t sv = x.S[s], av = x.A[s];
+                return (in && sv != 0) ? av : (int8_t)0;
               }));
         r[ARCLE_REC_GRID_DIM] = (int8_t)h;
         r[ARCLE_REC_GRID_DIM + 1] = (int8_t)w;

@@ -4,6 +4,7 @@
 // libarcle_hip.so (arcle_amd/_lib.py compiles both and links them).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define ARCLE_BIG_DEV __device__ __forceinline__
 #define ARCLE_BIG_HD __host__ __device__
@@ -31,7 +32,7 @@ ARCLE_BIG_DEV void release_store_system(uint32_t* p, uint32_t v) { __hip_atomic_
 
 using arcle_big::BigParams;
 
-#define BIG_THREADS 256
+#define BIG_THREADS 1024  // the largest workgroup a launch may be given (ARCLE_BIG_THREADS; the library itself asks for at most 512)
 
 extern __shared__ __attribute__((aligned(16))) int8_t arcle_big_lds[];
 
@@ -51,34 +52,57 @@ __global__ __launch_bounds__(BIG_THREADS) void arcle_big_set_rows_kernel(const B
 namespace arcle_big {
 
 // the dynamic LDS of a launch: up to 69 KB (127 x 127) — beyond the 64 KB a kernel gets without asking
-template <class K>
+template <int ID, class K>
 static int allow_lds(K kernel, int bytes) {
   if (bytes <= 65536) return 0;
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  static uint64_t done = 0;  // per kernel (ID) and device: the attribute is set once, for the largest plane
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (done & (1ull << (dev & 63))) return 0;
+  const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(MAX_PS));
+  if (rc == 0) done |= 1ull << (dev & 63);
+  return rc;
+}
+
+// Threads per workgroup: a thread owns the chunks t, t + NT, ... of a plane.  Measured on MI355X (profiles/round5_experiments.txt §15): the
+// kernel is bound by the per-chunk instruction chain of a thread (a chunk is 16 cells built one by one), not by barriers — one chunk per
+// thread is fastest at every size tried, so: the chunk count rounded up to whole wavefronts (128 threads at 40 x 40, 256 at 64 x 64,
+// 1024 at 127 x 127).  ARCLE_BIG_THREADS overrides (tuning runs).
+static unsigned threads_for(int PS) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* s = getenv("ARCLE_BIG_THREADS");
+    const int v = s ? atoi(s) : 0;
+    forced = (v >= 64 && v <= BIG_THREADS && (v & 63) == 0) ? v : 0;
+  }
+  if (forced) return (unsigned)forced;
+  const int nch = PS >> 4;
+  const int t = (nch + 63) & ~63;
+  return (unsigned)(t < 64 ? 64 : t > 512 ? 512 : t);  // (127 x 127, 1016 chunks: 512 threads 36.7 us, 1024 threads 41.5, 256 threads 51.0 per 1024 envs)
 }
 
 int launch_step(const BigParams& p, void* stream) {
   const int lds = lds_bytes(p.PS);
-  if (int rc = allow_lds(arcle_big_step_kernel, lds)) return rc;
-  hipLaunchKernelGGL(arcle_big_step_kernel, dim3((unsigned)p.n_envs), dim3(BIG_THREADS), (size_t)lds, (hipStream_t)stream, p);
+  if (int rc = allow_lds<0>(arcle_big_step_kernel, lds)) return rc;
+  hipLaunchKernelGGL(arcle_big_step_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 int launch_reset(const BigParams& p, int mode, void* stream) {
   const int lds = lds_bytes(p.PS);
-  if (int rc = allow_lds(arcle_big_reset_kernel, lds)) return rc;
-  hipLaunchKernelGGL(arcle_big_reset_kernel, dim3((unsigned)p.n_envs), dim3(BIG_THREADS), (size_t)lds, (hipStream_t)stream, p, mode);
+  if (int rc = allow_lds<1>(arcle_big_reset_kernel, lds)) return rc;
+  hipLaunchKernelGGL(arcle_big_reset_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p, mode);
   return (int)hipGetLastError();
 }
 int launch_rows(const BigParams& p, int mode, void* stream) {
   const int lds = lds_bytes(p.PS);
-  if (int rc = allow_lds(arcle_big_rows_kernel, lds)) return rc;
-  hipLaunchKernelGGL(arcle_big_rows_kernel, dim3((unsigned)p.n_envs), dim3(BIG_THREADS), (size_t)lds, (hipStream_t)stream, p, mode);
+  if (int rc = allow_lds<2>(arcle_big_rows_kernel, lds)) return rc;
+  hipLaunchKernelGGL(arcle_big_rows_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p, mode);
   return (int)hipGetLastError();
 }
 int launch_set_rows(const BigParams& p, void* stream) {
   const int lds = lds_bytes(p.PS);
-  if (int rc = allow_lds(arcle_big_set_rows_kernel, lds)) return rc;
-  hipLaunchKernelGGL(arcle_big_set_rows_kernel, dim3((unsigned)p.n_envs), dim3(BIG_THREADS), (size_t)lds, (hipStream_t)stream, p);
+  if (int rc = allow_lds<3>(arcle_big_set_rows_kernel, lds)) return rc;
+  hipLaunchKernelGGL(arcle_big_set_rows_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 

@@ -903,6 +903,46 @@ def other_configs_leg(dev, K=100):
     return out
 
 
+# planes a step of each op kind moves (reads + writes of whole PS-byte planes) on the workgroup-per-env path, the C3 table: the per-op
+# model behind the big-grid leg's byte figure — an op that turns out to be a no-op (empty selection, inactive object) moves less
+_BIG_PLANES = {"color": 3, "flood": 3, "move": 6, "rotflip": 8, "copy": 3, "paste": 4, "copy_from_input": 3, "reset_grid": 2, "resize_grid": 2, "submit": 2}
+
+
+def _big_model_bytes(op, PS):
+    k = np.select([op < 10, op < 20, op < 24, op < 28, op < 30, op == 30, op == 31, op == 32, op == 33],
+                  [_BIG_PLANES["color"], _BIG_PLANES["flood"], _BIG_PLANES["move"], _BIG_PLANES["rotflip"], _BIG_PLANES["copy"],
+                   _BIG_PLANES["paste"], _BIG_PLANES["copy_from_input"], _BIG_PLANES["reset_grid"], _BIG_PLANES["resize_grid"]], _BIG_PLANES["submit"])
+    return float(k.sum()) * PS / op.shape[0] + 56.0 * op.shape[1]  # + record in / out, counters, action, outputs per env
+
+
+def big_grid_case(dev, H, W, n, K=24, ops=None):
+    """One max_grid_size beyond 1024 cells: K graph-replayed step launches of the C3 action mix (one workgroup per env)."""
+    batch = make_batch(dev, n, 1000, "o2arc", H, W)
+    bb, oo = make_actions(K, n, 2000, H, W)
+    if ops is not None:  # (tools/bigbench.py: one class of operations only)
+        oo = (ops[0] + oo % (ops[1] - ops[0] + 1)).astype(np.int32)
+    bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
+    FL = batch.elide_flag | STEP_AUTORESET
+
+    def enqueue(sh):
+        for i in range(K):
+            batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), FL, sh)
+    sec, _ = graph_time(dev, enqueue, K)
+    alg = _big_model_bytes(oo, batch.PS)
+    rl = {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK, "traffic": None,
+          "kernel": "arcle_big_step_kernel", "avg_launch_us": sec * 1e6, "algorithmic_bytes_per_launch": alg,
+          "note": "bytes MODELLED per op kind (planes read + written x plane stride; the workgroup-per-env kernels carry no byte counter); "
+                  "state = 8 planes x envs x PS"}
+    return {"workload": f"O2ARCv2Env {H}x{W}, {n} envs, C3 action mix (max_grid_size beyond one wavefront: one workgroup per env)", "envs": n,
+            "plane_stride": batch.PS, "us_per_step_batch": sec * 1e6, "value": n / sec, "unit": "env-steps/s", "roofline": rl}
+
+
+def big_grid_leg(dev):
+    """Grids of more than 1024 cells (the reference takes any max_grid_size, base.py:37-49): the workgroup-per-env kernels, timed like the
+    other legs.  Not the headline and not ARC's regime (30 x 30) — the completeness path."""
+    return {"64x64_4096": big_grid_case(dev, 64, 64, 4096), "127x127_1024": big_grid_case(dev, 127, 127, 1024)}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def _spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per rank)."""
@@ -1264,7 +1304,7 @@ def main():
                               ("transition_rows", lambda: transition_leg(dev, n, bbox, op)),
                               ("rollout", lambda: rollout_leg(batch, bbox, op, dev)),
                               ("batch_sweep", lambda: batch_sweep_leg(dev, bbox, op)),
-                              ("other_configs", lambda: other_configs_leg(dev))):
+                              ("other_configs", lambda: other_configs_leg(dev)), ("big_grid", lambda: big_grid_leg(dev))):
                 try:
                     ex[name] = leg()
                 except Exception as exc:  # an extra must never cost the headline line

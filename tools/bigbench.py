@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Grids beyond 1024 cells (the workgroup-per-env kernels, arcle_amd/csrc/arcle_big.hip): us per step of a batch, graph-replayed, HIP events.
+    python tools/bigbench.py [--sizes 40x40,64x64,127x127] [--envs 1024,4096] [--steps 24]
+The C3 action mix (35 ops uniform, BBox tuples uniform over the plane) on O2ARCv2Env tasks of the given max_grid_size; next to the time, the
+plane traffic a step of that op would move by the per-op model of bench.py's big_grid leg."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as BN  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sizes", default="40x40,64x64,127x127")
+    ap.add_argument("--envs", default="1024,4096")
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--ops", default="", help="restrict the op indices drawn, e.g. 10-19 (FloodFill) or 20-23 (Move); default: all 35")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for size in a.sizes.split(","):
+        H, W = (int(v) for v in size.split("x"))
+        for n in (int(v) for v in a.envs.split(",")):
+            ops = None
+            if a.ops:
+                lo, hi = (int(v) for v in a.ops.split("-"))
+                ops = (lo, hi)
+            leg = BN.big_grid_case(dev, H, W, n, a.steps, ops=ops)
+            print(f"{H}x{W} envs {n}{' ops ' + a.ops if a.ops else ''}: {leg['us_per_step_batch']:.1f} us per step = {leg['value'] / 1e6:.1f} M env-steps/s; modelled plane traffic "
+                  f"{leg['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch -> {leg['roofline']['frac']:.3f} of 8 TB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
