@@ -514,6 +514,13 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
   bx::sync();  // every thread holds the record / counters; the reduction block is clear
 
   do {
+    if (p.res_rec) {  // arcle_transition_rows: a row whose src_env names no resident env is passed through untouched
+      const int src = p.src_env ? p.src_env[env] : env;
+      if (src < 0 || src >= p.n_resident) {
+        st |= ARCLE_ST_BAD_TASK;
+        break;
+      }
+    }
     if (flags & (ARCLE_STEP_AUTORESET | ARCLE_STEP_RESAMPLE)) {
       // next-step autoreset (see ARCLE_STEP_AUTORESET): an env whose episode ended is re-initialised instead of executing the action
       const bool ended = r[ARCLE_REC_TERMINATED] != 0 || ((flags & ARCLE_STEP_TRUNCATE) && cnt0 >= p.step_limit);
@@ -1094,6 +1101,13 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
   const Layout L = flat_layout(p, 0);
   const int8_t* const row = p.rows_in + (size_t)env * p.rows_in_stride;
   Chunk rc = ldg(p.rec, env);
+  if (p.res_rec) {  // a scratch env of arcle_transition_rows: the task side comes from a resident env, the counters start at zero
+    int src = p.src_env ? p.src_env[env] : env;
+    if (src < 0 || src >= p.n_resident) src = 0;  // (the step launch flags the row and skips it)
+    rc = ldg(p.res_rec, src);
+    for (int c = x.tid; c < x.nch; c += x.NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(p.res_answer + (size_t)src * x.PS, c));
+    if (x.tid == 0) p.cnt[2 * (size_t)env] = p.cnt[2 * (size_t)env + 1] = 0;
+  }
   bx::sync();
   for (int s = 0; s < L.n; s++) {
     const Seg& sg = L.s[s];

@@ -46,6 +46,12 @@ struct BigParams {
   // state rows in
   const int8_t* rows_in;
   int32_t rows_in_stride;
+  // arcle_transition_rows: the launch works on SCRATCH envs (one per row); the task side of row r — answer plane, answer_dim — is that of
+  // resident env src_env[r] (NULL = env r)
+  int32_t n_resident;
+  const int32_t* src_env;
+  const int8_t* res_answer;  // the handle's own answer plane / records
+  const int8_t* res_rec;
 };
 
 // bytes of LDS one workgroup needs: four staging planes + the reduction block + two row boards of 128 x 128 bits

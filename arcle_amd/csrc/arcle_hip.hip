@@ -564,6 +564,8 @@ struct LaunchPlan {  // how a step launch runs (see plan_launch)
 
 struct arcle_env {
   int big;  // H * W > ARCLE_MAX_CELLS: every launch of this handle goes to the workgroup-per-env kernels of arcle_big.hip
+  int8_t* big_scratch;      // ... arcle_transition_rows of such a handle: scratch envs (planes, records, counters) for big_scratch_rows rows
+  int32_t big_scratch_rows;
   arcle_config cfg;
   arcle_buffers bufs;
   bool owns_bufs;
@@ -761,6 +763,7 @@ extern "C" int arcle_destroy(arcle_env* e) {
   if (e->d_dense_cache) (void)hipFree(e->d_dense_cache);
   if (e->d_stage) (void)hipFree(e->d_stage);
   if (e->d_acct) (void)hipFree(e->d_acct);
+  if (e->big_scratch) (void)hipFree(e->big_scratch);
   delete e;
   return ARCLE_OK;
 }
@@ -1820,7 +1823,7 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
                                      int32_t out_stride, int tail, int32_t* reward, uint8_t* term, uint32_t flags, void* stream) {
   if (!e || !sel || !op || !reward || !term || !rows_out) return ARCLE_ERR_ARG;
   if (n_rows <= 0) return fail(e, ARCLE_ERR_ARG, "n_rows must be positive");
-  BIG_REFUSE(e, "arcle_transition_rows (use arcle_set_state_rows + a step + arcle_get_state_rows)");
+  if (e->big && (flags & ARCLE_STEP_DENSE)) BIG_REFUSE(e, "the dense reward pair (ARCLE_STEP_DENSE)");
   if (!src_env && n_rows > e->cfg.n_envs) return fail(e, ARCLE_ERR_ARG, "more rows than envs: pass src_env (which env's answer every row uses)");
   if ((uint64_t)n_rows * ARCLE_MAX_CELLS >= (1ull << 32)) return fail(e, ARCLE_ERR_ARG, "too many rows");
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
@@ -1834,6 +1837,55 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
   if ((out_stride & 15) || (reinterpret_cast<uintptr_t>(rows_out) & 15) || out_stride < ((len + 15) & ~15) + (tail ? 16 : 0))
     return fail(e, ARCLE_ERR_ARG, "output rows: 16-byte aligned, stride a multiple of 16 >= the row length (+16 with a tail)");
   DeviceGuard guard(e->device);
+  if (e->big) {
+    // the state does not fit a wavefront, so the stateless transition is three launches over SCRATCH envs (one per row): rows -> scratch
+    // planes / records (+ the answer of resident env src_env[r]), one step() of the scratch envs with the fused row writer, i.e.
+    // row r of rows_out = FlattenObservation of the stepped state (+ tail).  The resident envs are not touched.  The scratch (8 planes +
+    // record + counters per row) is allocated — or grown — here: not inside a stream capture.
+    const size_t PS = (size_t)e->base.PS, per_row = ARCLE_N_PLANES * PS + ARCLE_REC_BYTES + 8;
+    if (n_rows > e->big_scratch_rows) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return fail(e, ARCLE_ERR_CONFIG, "arcle_transition_rows of a big-grid handle allocates its scratch envs on first use: call it once outside the stream capture");
+      }
+      if (e->big_scratch) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        (void)hipFree(e->big_scratch);
+        e->big_scratch = nullptr;
+        e->big_scratch_rows = 0;
+      }
+      HIP_TRY(e, hipMalloc((void**)&e->big_scratch, per_row * (size_t)n_rows));
+      e->big_scratch_rows = n_rows;
+    }
+    arcle_big::BigParams q = big_params(e);
+    const size_t R = (size_t)e->big_scratch_rows;
+    for (int i = 0; i < ARCLE_N_PLANES; i++) q.plane[i] = e->bufs.plane[i] ? e->big_scratch + (size_t)i * R * PS : nullptr;
+    q.rec = e->big_scratch + ARCLE_N_PLANES * R * PS;
+    q.cnt = reinterpret_cast<int32_t*>(e->big_scratch + ARCLE_N_PLANES * R * PS + R * ARCLE_REC_BYTES);
+    q.n_envs = n_rows;
+    q.n_resident = e->cfg.n_envs;
+    q.src_env = src_env;
+    q.res_answer = e->bufs.plane[ARCLE_PL_ANSWER];
+    q.res_rec = e->bufs.rec;
+    q.rows_in = rows_in;
+    q.rows_in_stride = in_stride;
+    if (int rc = big_done(e, arcle_big::launch_set_rows(q, stream), "arcle_transition_rows (rows in)")) return rc;
+    q.ingress = ingress;
+    q.sel = sel;
+    q.op = op;
+    q.reward = reward;
+    q.term = term;
+    q.flags = flags | ARCLE_STEP_FLAT_OBS;
+    q.flat_out = rows_out;
+    q.flat_stride = out_stride;
+    q.flat_filter = 0;
+    q.flat_tail = tail ? 1 : 0;
+    q.flat_seq = tail ? e->flat_seq : 0;
+    if (ingress != arcle::INGRESS_MASK && ingress != arcle::INGRESS_BBOX && ingress != arcle::INGRESS_POINT)
+      return fail(e, ARCLE_ERR_ARG, "arcle_transition_rows takes mask, bbox or point selections");
+    return big_done(e, arcle_big::launch_step(q, stream), "arcle_transition_rows");
+  }
   StepParams p = e->base;
   p.n_resident = p.n_envs;
   p.n_envs = n_rows;

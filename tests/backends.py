@@ -435,7 +435,8 @@ class _BigParams(ctypes.Structure):  # mirror of arcle_big::BigParams (arcle_amd
                 ("tbl_in_dim", ctypes.c_void_p), ("tbl_ans_dim", ctypes.c_void_p), ("n_tasks", ctypes.c_int32),
                 ("seed", ctypes.c_uint64), ("env_base", ctypes.c_int64), ("episode", ctypes.c_void_p),
                 ("cur_task", ctypes.c_void_p), ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p),
-                ("n_problems", ctypes.c_int32), ("rows_in", ctypes.c_void_p), ("rows_in_stride", ctypes.c_int32)]
+                ("n_problems", ctypes.c_int32), ("rows_in", ctypes.c_void_p), ("rows_in_stride", ctypes.c_int32),
+                ("n_resident", ctypes.c_int32), ("src_env", ctypes.c_void_p), ("res_answer", ctypes.c_void_p), ("res_rec", ctypes.c_void_p)]
 
 
 _big_emu = None
@@ -567,6 +568,36 @@ class BigEmuBackend(EmuBackend):
         p.rows_in, p.rows_in_stride = rows.ctypes.data, rows.shape[1]
         p.rmask = None if m is None else m.ctypes.data
         self._run(3, p)
+
+    def transition_rows(self, rows, ingress, payload, op, src_env=None, tail=False, flags=0, in_place=False):
+        """What arcle_transition_rows does for a big-grid handle (arcle_hip.hip): rows -> scratch envs (+ the answer of resident env
+        src_env[r]), one step of the scratch envs with the fused row writer."""
+        rows = np.ascontiguousarray(rows, np.int8)
+        M, L = rows.shape[0], self._flat_len(False)
+        out = np.full((M, ((L + 15) & ~15) + (16 if tail else 0)), 0x55, np.int8)
+        if in_place:
+            out[:, :L] = rows[:, :L]
+            rows = out
+        scratch = {k: np.full((M, self.PS), 0x33, np.int8) for k in self.buf}
+        rec, cnt = np.full((M, 16), 0x33, np.int8), np.full((M, 2), 0x33, np.int32)
+        reward, term = np.zeros(M, np.int32), np.zeros(M, np.uint8)
+        p = self._params()
+        for i, k in enumerate(PLANES):
+            p.plane[i] = scratch[k].ctypes.data if k in scratch else None
+        p.rec, p.cnt, p.n_envs = rec.ctypes.data, cnt.ctypes.data, M
+        p.reward, p.term = reward.ctypes.data, term.ctypes.data
+        p.n_resident, p.res_answer, p.res_rec = self.N, self.buf["answer"].ctypes.data, self.rec.ctypes.data
+        src = None if src_env is None else np.ascontiguousarray(src_env, np.int32)
+        p.src_env = None if src is None else src.ctypes.data
+        p.rows_in, p.rows_in_stride = rows.ctypes.data, rows.shape[1]
+        self._run(3, p)
+        pay = (np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(M, self.P) if ingress == "mask"
+               else np.ascontiguousarray(payload, np.int32))
+        opa = np.ascontiguousarray(op, np.int32)
+        p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags | 128
+        p.flat_out, p.flat_stride, p.flat_filter, p.flat_tail = out.ctypes.data, out.shape[1], 0, int(tail)
+        self._run(0, p)
+        return out, reward, term
 
 
 # ---- HIP (the product, through arcle_amd.engine -> libarcle_hip.so C ABI) ------------------------------

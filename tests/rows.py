@@ -144,11 +144,11 @@ def state_rows_roundtrip(cls):
     return errs
 
 
-def transition_rows(cls):
+def transition_rows(cls, cases=(("o2arc", 30, 30, 3), ("o2arc", 7, 12, -1), ("o2arc", 12, 12, 1), ("arc", 30, 30, 3), ("raw", 5, 5, 2))):
     """arcle_transition_rows(rows, actions) == oracle.step on the same states, for every ingress form; the resident envs stay
     untouched; src_env picks the answer; the tail carries (reward, 1, submit counted, terminated, status)."""
     errs = []
-    for kind, H, W, mt in (("o2arc", 30, 30, 3), ("o2arc", 7, 12, -1), ("o2arc", 12, 12, 1), ("arc", 30, 30, 3), ("raw", 5, 5, 2)):
+    for kind, H, W, mt in cases:
         N = 8
         be, orc, rng, ops = _pair(cls, N, H, W, seed=H * W + mt, max_trial=mt, kind=kind, warm=12)
         L = sum(n for _, n in B.row_layout(kind, H * W))

@@ -71,3 +71,10 @@ def test_big_emulator_truncation_and_autoreset():
 
 def test_big_emulator_task_table_and_device_draw():
     C.task_table_case(B.BigEmuBackend)
+
+
+def test_big_emulator_transition_rows():
+    """the stateless batched transition (o2arcenv.py:149-151) on grids of more than 1024 cells: rows in, scratch envs, rows out"""
+    import rows as R
+    errs = R.transition_rows(B.BigEmuBackend, cases=(("o2arc", 40, 40, 3), ("arc", 36, 41, 3), ("raw", 35, 30, 2)))
+    assert not errs, "\n".join(errs[:10])

@@ -94,6 +94,13 @@ def test_hip_big_task_table_and_device_draw():
     C.task_table_case(B.HipBackend)
 
 
+def test_hip_big_transition_rows():
+    """the stateless batched transition (o2arcenv.py:149-151) on grids of more than 1024 cells: rows in, scratch envs, rows out"""
+    import rows as R
+    errs = R.transition_rows(B.HipBackend, cases=(("o2arc", 40, 40, 3), ("arc", 36, 41, 3), ("raw", 35, 30, 2), ("o2arc", 127, 127, -1)))
+    assert not errs, "\n".join(errs[:10])
+
+
 def test_hip_big_rollout_is_n_step_launches():
     """arcle_rollout_bbox on a big handle = n_steps step launches (the state does not fit a wavefront): same results as stepping"""
     H = W = 40
@@ -160,3 +167,14 @@ def test_hip_big_vec_env_and_single_env_api():
         assert np.array_equal(obs["grid"], o1.get("grid")[0]) and np.array_equal(obs["selected"], o1.get("selected")[0])
         assert np.array_equal(obs["object_states"]["object"], o1.get("object")[0])
         assert info["steps"] == int(o1.counters()[0, 0])
+    # transition(state, action) (o2arcenv.py:149-151; README: env.transition(deepcopy(state), action)): the env itself stays where it is
+    import copy
+    st = copy.deepcopy(env.current_state)
+    steps_before = env.action_steps
+    sel = np.zeros((40, 40), np.int8)
+    sel[2:9, 3:11] = 1
+    env.transition(st, {"selection": sel, "operation": 22})  # MoveR of a fresh selection
+    r2, t2 = o1.step("mask", sel[None], np.array([22], np.int32), 0)
+    assert np.array_equal(st["grid"], o1.get("grid")[0]) and np.array_equal(st["selected"], o1.get("selected")[0])
+    assert np.array_equal(st["object_states"]["object_pos"], o1.get("object_pos")[0]) and env.action_steps == steps_before
+    assert not np.array_equal(env.current_state["grid"], st["grid"]) or not sel.any()
