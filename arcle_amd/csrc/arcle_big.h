@@ -45,8 +45,8 @@ struct Red {  // reduction block in LDS (64 bytes)
   uint32_t amax;  // (value + 128) << 16 | (0xffff - cell): max value, first occurrence (np.argmax)
   int32_t x0, x1, y0, y1;
   int32_t neq;      // grid != answer somewhere / selection != selected somewhere
-  int32_t flag[2];  // FloodFill: some row changed in pass k (slot k & 1)
-  int32_t pad[5];
+  int32_t flag[3];  // FloodFill: some row changed in pass k (slot k % 3)
+  int32_t pad[4];
 };
 struct B128 {
   uint64_t lo, hi;
@@ -396,45 +396,53 @@ ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int 
     E[i] = e;
     F[i] = f;
   }
-  if (x.tid == 0) x.red->flag[0] = x.red->flag[1] = 0;
+  if (x.tid == 0) x.red->flag[0] = x.red->flag[1] = x.red->flag[2] = 0;
   bx::sync();
+  // Chaotic relaxation: inside a pass a thread re-reads its neighbours' boards LIVE (volatile LDS reads, no barrier) FILL_INNER times
+  // and publishes its own row as soon as it grows — rows of one wavefront advance in lock-step, so the fill climbs FILL_INNER rows of a
+  // vertical corridor per pass instead of one (one barrier per pass instead of two per row).  Every intermediate board is a subset of
+  // the region (the update is monotone), so whatever the interleaving the fixpoint is the reference's region; a pass in which NO thread
+  // changed anything evaluated every row against boards that were constant throughout: the fixpoint.  Flag slots rotate over three
+  // passes: slot (k + 1) % 3 is cleared during pass k — last read at the end of pass k - 2, behind a barrier every thread has passed.
+  volatile uint64_t* const Fv = reinterpret_cast<volatile uint64_t*>(F);
+  B128 mine[MAX_ROWS_PER_THREAD], elig[MAX_ROWS_PER_THREAD];
+  {
+    int k = 0;
+    for (int i = x.tid; i < H; i += x.NT, k++) {
+      mine[k] = F[i];
+      elig[k] = E[i];
+    }
+  }
   for (int pass = 0;; pass++) {
-    // phase A: every row pulls the fill from its neighbours' boards of the previous pass
-    B128 nf[MAX_ROWS_PER_THREAD];  // a thread owns at most ceil(127 / NT) rows: 1 with the shipped 256 threads, 4 with 32 (emulator)
-    bool ch[MAX_ROWS_PER_THREAD];
-    int nrows = 0;
-    for (int i = x.tid; i < H; i += x.NT) {
-      const B128 cur = F[i], e = E[i];
-      B128 s = cur;
-      if (i > 0) {
-        s.lo |= F[i - 1].lo;
-        s.hi |= F[i - 1].hi;
+    bool changed = false;
+    for (int it = 0; it < FILL_INNER; it++) {
+      int k = 0;
+      for (int i = x.tid; i < H; i += x.NT, k++) {
+        const B128 cur = mine[k], e = elig[k];
+        B128 s = cur;
+        if (i > 0) {
+          s.lo |= Fv[2 * (i - 1)];
+          s.hi |= Fv[2 * (i - 1) + 1];
+        }
+        if (i + 1 < H) {
+          s.lo |= Fv[2 * (i + 1)];
+          s.hi |= Fv[2 * (i + 1) + 1];
+        }
+        s.lo &= e.lo;
+        s.hi &= e.hi;
+        if (s.lo != cur.lo || s.hi != cur.hi) {
+          const B128 n = spread(e, s);
+          Fv[2 * i] = n.lo;
+          Fv[2 * i + 1] = n.hi;
+          mine[k] = n;
+          changed = true;
+        }
       }
-      if (i + 1 < H) {
-        s.lo |= F[i + 1].lo;
-        s.hi |= F[i + 1].hi;
-      }
-      s.lo &= e.lo;
-      s.hi &= e.hi;
-      B128 n = cur;
-      if (s.lo != cur.lo || s.hi != cur.hi) n = spread(e, s);
-      nf[nrows] = n;
-      ch[nrows] = n.lo != cur.lo || n.hi != cur.hi;
-      nrows++;
     }
+    if (changed) x.red->flag[pass % 3] = 1;
+    if (x.tid == 0) x.red->flag[(pass + 1) % 3] = 0;
     bx::sync();
-    // phase B: publish
-    nrows = 0;
-    for (int i = x.tid; i < H; i += x.NT) {
-      if (ch[nrows]) {
-        F[i] = nf[nrows];
-        x.red->flag[pass & 1] = 1;
-      }
-      nrows++;
-    }
-    if (x.tid == 0) x.red->flag[(pass + 1) & 1] = 0;
-    bx::sync();
-    if (!x.red->flag[pass & 1]) break;
+    if (!x.red->flag[pass % 3]) break;
   }
   // the region takes the colour: chunks of the staged grid, rewritten where the board has a bit
   for (int c = x.tid; c < x.nch; c += x.NT) {

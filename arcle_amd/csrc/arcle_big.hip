@@ -81,6 +81,8 @@ static unsigned threads_for(int PS) {
   return (unsigned)(t < 64 ? 64 : t > 512 ? 512 : t);  // (127 x 127, 1016 chunks: 512 threads 36.7 us, 1024 threads 41.5, 256 threads 51.0 per 1024 envs)
 }
 
+int workgroup_threads(int PS) { return (int)threads_for(PS); }
+
 int launch_step(const BigParams& p, void* stream) {
   const int lds = lds_bytes(p.PS);
   if (int rc = allow_lds<0>(arcle_big_step_kernel, lds)) return rc;

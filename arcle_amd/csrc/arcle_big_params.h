@@ -12,7 +12,7 @@
 namespace arcle_big {
 
 enum { ING_MASK = 0, ING_BBOX = 1, ING_POINT = 2, ING_BBOX5 = 3 };
-enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 32, MAX_ROWS_PER_THREAD = 4 };
+enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 32, MAX_ROWS_PER_THREAD = 4, FILL_INNER = 8 };
 
 struct BigParams {
   int8_t* plane[ARCLE_N_PLANES];
@@ -68,5 +68,6 @@ int launch_step(const BigParams& p, void* stream);
 int launch_reset(const BigParams& p, int mode, void* stream);     // 0 arcle_reset, 1 arcle_reset_from_table, 2 arcle_reset_sampled
 int launch_rows(const BigParams& p, int mode, void* stream);      // 0 flat rows of the resident state, 1 packed rows
 int launch_set_rows(const BigParams& p, void* stream);
+int workgroup_threads(int PS);  // threads per workgroup the launches above use for a plane stride
 
 }  // namespace arcle_big

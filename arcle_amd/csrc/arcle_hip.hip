@@ -1286,7 +1286,7 @@ extern "C" int arcle_launch_info(arcle_env* e, int ingress, uint32_t flags, int3
   if (e && out4 && e->big) {  // one workgroup of four wavefronts per env: no plan to choose
     out4[0] = 0;
     out4[1] = 0;
-    out4[2] = 4;
+    out4[2] = arcle_big::workgroup_threads(e->base.PS) / 64;
     out4[3] = 0;
     return ARCLE_OK;
   }

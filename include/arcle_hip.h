@@ -40,7 +40,10 @@ extern "C" {
 
 #define ARCLE_ABI_VERSION 5
 #define ARCLE_MAX_OPS 64
-#define ARCLE_MAX_CELLS 1024 /* H*W <= 1024 (one 64-lane wavefront x 16 cells) */
+#define ARCLE_MAX_CELLS 1024 /* H*W <= 1024: one 64-lane wavefront x 16 cells holds a plane (the one-wavefront-per-env kernels);
+                                larger planes (H, W <= 127) are served by the workgroup-per-env kernels — see "Grids beyond
+                                ARCLE_MAX_CELLS" below */
+#define ARCLE_MAX_SIDE 127   /* H, W <= 127: grid dims are int8 in the record (and in the reference's state dict, base.py:162-166) */
 /* default per-env plane stride: H*W rounded up to a whole number of 128-byte lines (30x30 -> 1024 B), so that no two
  * envs share a cache line of a plane and every plane store writes full lines */
 #define ARCLE_DEFAULT_PLANE_STRIDE(P) (((P) + 127) & ~127)
@@ -180,11 +183,11 @@ enum arcle_status {
 
 typedef struct arcle_config {
   int32_t n_envs;    /* envs owned by this handle (this GPU's shard)                     */
-  int32_t H, W;      /* max_grid_size (base.py:49); H*W <= ARCLE_MAX_CELLS               */
+  int32_t H, W;      /* max_grid_size (base.py:49); H, W <= ARCLE_MAX_SIDE (any such size: see "Grids beyond ARCLE_MAX_CELLS") */
   int32_t max_trial; /* base.py:51; stored as int8 in trials_remain                      */
   int32_t device;    /* HIP device ordinal, -1 = current device                          */
   int32_t plane_stride; /* bytes between consecutive envs of a plane (PS): 0 = default (ARCLE_DEFAULT_PLANE_STRIDE(H*W));
-                           otherwise a multiple of 16 with H*W <= PS <= 1024                */
+                           otherwise a multiple of 16 with H*W <= PS <= 1024 (<= 16256 for grids beyond ARCLE_MAX_CELLS) */
 } arcle_config;
 
 typedef struct arcle_buffers {
@@ -194,6 +197,24 @@ typedef struct arcle_buffers {
 } arcle_buffers;
 
 typedef struct arcle_env arcle_env; /* opaque handle */
+
+/* ---- Grids beyond ARCLE_MAX_CELLS -----------------------------------------------------------------------------------------------
+ * The reference takes any max_grid_size (base.py:37-49).  A handle with H * W <= ARCLE_MAX_CELLS runs the one-wavefront-per-env kernels
+ * (ARC's own regime, 30 x 30: everything in this header applies).  A handle with H * W > ARCLE_MAX_CELLS (H, W <= ARCLE_MAX_SIDE) runs one
+ * WORKGROUP per env (arcle_amd/csrc/arcle_big.hip): same layout (PS = H*W rounded up to 128), same entry points, same results bit for
+ * bit against the reference's algorithm — with these differences:
+ *   served      arcle_reset / _reset_from_table / _reset_sampled, arcle_step_mask / _bbox / _point / _bbox5, arcle_step_many, arcle_rollout_*
+ *               (= n_steps step launches: the state does not fit a wavefront's registers), arcle_transition_rows (three launches over
+ *               library-owned scratch envs, allocated on first use: not inside a stream capture), arcle_flatten_obs / _get_state_rows /
+ *               _set_state_rows, arcle_pack_obs, planes, status; step flags AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE, CONTINUE_RULE,
+ *               RESET_ON_SUBMIT, FLAT_OBS (tail and completion signal included), PACK_OBS; ROWS_INCREMENTAL is accepted and rewrites the
+ *               rows in full (identical bytes)
+ *   refused     (ARCLE_ERR_CONFIG, arcle_last_error names the reason) arcle_step_bits / arcle_pack_mask_bits (their rows are
+ *               ARCLE_MAX_CELLS / 8 bytes), ARCLE_STEP_DENSE / arcle_set_dense_output, task augmentation (arcle_set_sampler with
+ *               aug_flags, arcle_reset_from_table_aug with arrays), arcle_enable_accounting
+ *   no-ops      arcle_set_dispatch_order, arcle_hint_next_ops, arcle_autotune (returns 0 candidates: one launch plan), arcle_launch_info
+ *               reports {0, 0, waves per workgroup, 0}
+ * Action arrays and row buffers may be device or pinned host memory as everywhere else. */
 
 /* Creates a handle. `bufs` are caller-owned device buffers (e.g. torch tensors' data_ptr);
  * if bufs == NULL the library allocates all planes itself (hipMalloc) and frees them in
