@@ -21,4 +21,10 @@ python $R/tools/prof_summary.py $O/prof2/ex_results.db > $O/round5_extras_kernel
 echo "== PMC passes"
 bash $R/tools/gpu_pmc.sh 2>&1 | tee $O/round5_pmc_summary.txt | tail -40
 cd $R && python tools/make_pmc_json.py gpurun_out round5 > $O/pmc_json.log 2>&1; cp profiles/pmc_latest.json $O/pmc_latest.json; cat $O/pmc_latest.json
+echo "== big grids (workgroup-per-env kernels): bench + kernel trace"
+(python $R/tools/bigbench.py --envs 1024,4096,16384 2>&1 | grep envs) > $O/round5_big_grid.txt
+rm -rf $O/prof3
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof3 -o big -- python $R/tools/bigbench.py --sizes 64x64 --envs 4096 > $O/rocprof3.log 2>&1; echo "rocprof rc=$?"
+(echo; echo "rocprofv3 --kernel-trace --stats of: python tools/bigbench.py --sizes 64x64 --envs 4096"; python $R/tools/prof_summary.py $O/prof3/big_results.db) >> $O/round5_big_grid.txt 2>&1; tail -12 $O/round5_big_grid.txt
+cd $R
 echo "== soak (6000 steps)"; SOAK_STEPS=6000 timeout 1200 python tools/soak.py > $O/round5_soak.txt 2>&1; tail -12 $O/round5_soak.txt
