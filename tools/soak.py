@@ -19,6 +19,17 @@ for name, H, W, N, flags, mt in (("30x30 flags=0", 30, 30, 1024, 0, 3), ("30x30 
     errs = B.random_trace_compare(BE, "o2arc", ops, H, W, N=N // SCALE, S=S, seed=H * 131 + W + flags, max_trial=mt, flags=flags,
                                   bad_ops=True)
     print(f"{name:40s} N={N} S={S}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
+# round 5: grids beyond 1024 cells (one workgroup per env, arcle_big.hip; SOAK_BACKEND=BigEmuBackend is the CPU dry run of these blocks)
+if BE is not getattr(B, "EmuBackend"):
+    O.set_threads(8)
+    for name, H, W, N, flags, mt in (("40x40 big-grid autoreset|elide", 40, 40, 256, 1 | 2, 3), ("64x64 big-grid flags=0", 64, 64, 128, 0, -1),
+                                     ("127x127 big-grid autoreset", 127, 127, 64, 1, 3), ("33x100 big-grid autoreset|elide", 33, 100, 128, 1 | 2, 2)):
+        errs = B.random_trace_compare(BE, "o2arc", ops, H, W, N=max(N // SCALE, 2), S=max(S // 4, 8), seed=H * 131 + W + flags, max_trial=mt, flags=flags,
+                                      bad_ops=True)
+        print(f"{name:40s} N={N} S={max(S // 4, 8)}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
+    O.set_threads(1)
+if os.environ.get("SOAK_BACKEND") == "BigEmuBackend":
+    sys.exit(0)
 # round 4: batches of at most 2048 envs take the small-batch paths (speculative grid request, 256-thread workgroups) — the blocks above.
 # The plain lean kernel that the headline times (4096 envs: beyond that threshold) and every speculative policy forced onto the same size:
 O.set_threads(8)
