@@ -44,7 +44,8 @@ batches on an evolving state.)  Besides the contract fields the line carries
                 full / incrementally), mask_ingress (int8 / bit-packed masks), host_actions (records of a host-resident policy:
                 zero-copy / one copy node / two), single_env (Gym class: step and transition latency), transition_rows (stateless
                 batched transition), rollout, batch_sweep (32 768 / 65 536 / 131 072 envs: the out-of-cache fraction, library tables vs arcle_autotune), other_configs
-                (c2 / c4 on one rank / c5 with their real bounds);
+                (c2 / c4 on one rank / c5 with their real bounds), big_grid (max_grid_size 64x64 / 127x127: the workgroup-per-env
+                kernels, bytes modelled per op kind);
   cpu_baseline  (N=1) on this box's host, bounded samples of the same workload: the oracle's C restatement (1 thread /
                 ALL host cores) and `numpy_step` = a plain-NumPy one-env-at-a-time step() loop with the reference's call
                 structure (oracle/numpy_env.py; leaner than the reference itself, labelled so), 1 process / all cores;
@@ -400,7 +401,8 @@ def emit(out, a):
                                  "mask_bits": us("mask_ingress", "bits", "us_per_step_batch"), "host_actions": us("host_actions", "us_per_step_batch"),
                                  "single_env_step": us("single_env", "us_per_step"), "transition_rows": us("transition_rows", "us_per_step_batch"),
                                  "rollout": us("rollout", "us_per_step_batch"), "c2": us("other_configs", "c2", "us_per_step_batch"),
-                                 "c4": us("other_configs", "c4", "us_per_step_batch"), "c5": us("other_configs", "c5", "us_per_step_batch")}
+                                 "c4": us("other_configs", "c4", "us_per_step_batch"), "c5": us("other_configs", "c5", "us_per_step_batch"),
+                                 "big_64x64_4096": us("big_grid", "64x64_4096", "us_per_step_batch")}
     cb = out.get("cpu_baseline")
     if cb:
         ns = cb["numpy_step"]
