@@ -93,12 +93,34 @@ ARCLE_BIG_DEV uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 ARCLE_BIG_DEV uint32_t mulhi32(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * (uint64_t)n) >> 32); }
-ARCLE_BIG_DEV int draw_task_entry(const BigParams& p, int env, uint32_t episode) {
+#define ARCLE_BIG_PERM_IDENTITY 0xFEDCBA9876543210ull
+struct Draw {
+  int entry;      // task-table index
+  int rot_k;      // np.rot90 count 0..3
+  uint64_t perm;  // colour permutation, nibble c = perm[c]
+};
+// (z0 -> problem and pair by multiply-shift range reduction; z1 -> the quarter turns and, its high word a 32-bit fraction consumed digit by
+// digit, the Fisher-Yates swaps over the ten colours: the function arcle_wave.h draw_task and arcle_amd/sampling.py compute)
+ARCLE_BIG_DEV Draw draw_task(const BigParams& p, int env, uint32_t episode) {
   const uint64_t G = 0x9E3779B97F4A7C15ull;
   const uint64_t z0 = mix64(p.seed + (uint64_t)(p.env_base + env) * G + (uint64_t)episode * 0xD1B54A32D192ED03ull);
   const int problem = (int)mulhi32((uint32_t)(z0 >> 32), (uint32_t)p.n_problems);
   const int sub = (int)mulhi32((uint32_t)z0, (uint32_t)p.pair_cnt[problem]);
-  return p.pair_off[problem] + sub;
+  Draw d;
+  d.entry = p.pair_off[problem] + sub;
+  const uint64_t z1 = mix64(z0 + G);
+  d.rot_k = (p.aug_flags & ARCLE_AUG_ROT90) ? (int)(z1 & 3u) : 0;
+  d.perm = ARCLE_BIG_PERM_IDENTITY;
+  if (p.aug_flags & ARCLE_AUG_PERMUTE) {
+    uint32_t r = (uint32_t)(z1 >> 32);
+    for (int i = 9; i > 0; i--) {
+      const int j = (int)mulhi32(r, (uint32_t)(i + 1));
+      r *= (uint32_t)(i + 1);
+      const uint64_t a = (d.perm >> (4 * i)) & 15u, b = (d.perm >> (4 * j)) & 15u;
+      d.perm = (d.perm & ~((15ull << (4 * i)) | (15ull << (4 * j)))) | (b << (4 * i)) | (a << (4 * j));
+    }
+  }
+  return d;
 }
 
 // ---- 128-bit row boards ------------------------------------------------------------------------------------------------------------
@@ -182,6 +204,54 @@ ARCLE_BIG_DEV void init_rec(int8_t* r, int max_trial) {
   r[ARCLE_REC_TERMINATED] = 0;
   r[ARCLE_REC_ACTIVE] = 0;
   r[ARCLE_REC_PARITY] = 0;
+}
+
+// Copies task-table entry t — optionally augmented: colours permuted (the un-padded grids only: the padding stays 0), np.rot90(., k) —
+// into the env's input and answer planes and the record's dims, then runs init_state's plane part.  Returns false (nothing written) when
+// a quarter turn does not fit the H x W plane; `soften`: such a turn is dropped (k &= 2) instead — device-drawn augmentations never fail
+// (the rule of arcle_wave.h load_task).  Workgroup-uniform; contains barriers when it augments.
+ARCLE_BIG_DEV bool load_task(const Ctx& x, int8_t* r, int t, int rot_k, uint64_t perm, bool soften) {
+  const BigParams& p = x.p;
+  int ih = p.tbl_in_dim[2 * (size_t)t], iw = p.tbl_in_dim[2 * (size_t)t + 1];
+  int ah = p.tbl_ans_dim[2 * (size_t)t], aw = p.tbl_ans_dim[2 * (size_t)t + 1];
+  if ((rot_k & 1) && (iw > x.H || ih > x.W || aw > x.H || ah > x.W)) {
+    if (!soften) return false;
+    rot_k &= 2;
+  }
+  const int8_t* const tin = p.tbl_in + (size_t)t * x.PS;
+  const int8_t* const tan = p.tbl_ans + (size_t)t * x.PS;
+  if (rot_k == 0 && perm == ARCLE_BIG_PERM_IDENTITY) {
+    for (int c = x.tid; c < x.nch; c += x.NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(tan, c));
+    init_planes(x, tin, true);
+  } else {
+    x.stage(x.A, tin);
+    x.stage(x.B, tan);
+    bx::sync();
+    const int W = x.W;
+    for (int which = 0; which < 2; which++) {
+      const int8_t* const src = which ? x.B : x.A;
+      const int h = which ? ah : ih, w = which ? aw : iw;
+      int nh = h, nw = w, ai = W, bj = 1, c0 = 0;  // identity
+      if (rot_k == 1) { ai = -1; bj = W; c0 = w - 1; nh = w; nw = h; }                // np.rot90(x, 1)[i, j] = x[j, w-1-i]
+      else if (rot_k == 2) { ai = -W; bj = -1; c0 = (h - 1) * W + (w - 1); }          // x[h-1-i, w-1-j]
+      else if (rot_k == 3) { ai = 1; bj = -W; c0 = (h - 1) * W; nh = w; nw = h; }      // x[h-1-j, i]
+      int8_t* const dst = x.g(which ? ARCLE_PL_ANSWER : ARCLE_PL_INPUT);
+      for (int c = x.tid; c < x.nch; c += x.NT)
+        stg(dst, c, build_chunk(c, W, x.P, [&](int, int i, int j) {
+              const bool in = i < nh && j < nw;
+              const int v = (uint8_t)src[in ? c0 + ai * i + bj * j : 0];
+              const int pv = v < 16 ? (int)((perm >> (4 * v)) & 15u) : v;  // (cells beyond the palette keep their value)
+              return in ? (int8_t)pv : (int8_t)0;
+            }));
+      if (which) { ah = nh; aw = nw; } else { ih = nh; iw = nw; }
+    }
+    init_planes(x, x.g(ARCLE_PL_INPUT), false);  // (every thread reads back the chunks it has just written itself)
+  }
+  r[ARCLE_REC_INPUT_DIM] = (int8_t)ih;
+  r[ARCLE_REC_INPUT_DIM + 1] = (int8_t)iw;
+  r[ARCLE_REC_ANSWER_DIM] = (int8_t)ah;
+  r[ARCLE_REC_ANSWER_DIM + 1] = (int8_t)aw;
+  return true;
 }
 
 // answer.shape == grid_dim and grid[:h,:w] == answer (base.py:177, o2arcenv.py:124-127); workgroup-uniform result.
@@ -533,19 +603,14 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       // next-step autoreset (see ARCLE_STEP_AUTORESET): an env whose episode ended is re-initialised instead of executing the action
       const bool ended = r[ARCLE_REC_TERMINATED] != 0 || ((flags & ARCLE_STEP_TRUNCATE) && cnt0 >= p.step_limit);
       if (ended) {
-        if (flags & ARCLE_STEP_RESAMPLE) {  // ... on a new task drawn on the device (no augmentation on this path)
+        if (flags & ARCLE_STEP_RESAMPLE) {  // ... on a new task drawn on the device, augmented as the sampler says
           const uint32_t ep = (uint32_t)p.episode[env];
-          const int t = draw_task_entry(p, env, ep);
-          r[ARCLE_REC_INPUT_DIM] = p.tbl_in_dim[2 * (size_t)t];
-          r[ARCLE_REC_INPUT_DIM + 1] = p.tbl_in_dim[2 * (size_t)t + 1];
-          r[ARCLE_REC_ANSWER_DIM] = p.tbl_ans_dim[2 * (size_t)t];
-          r[ARCLE_REC_ANSWER_DIM + 1] = p.tbl_ans_dim[2 * (size_t)t + 1];
-          for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(p.tbl_ans + (size_t)t * x.PS, c));
-          init_planes(x, p.tbl_in + (size_t)t * x.PS, true);
+          const Draw d = draw_task(p, env, ep);
+          load_task(x, r, d.entry, d.rot_k, d.perm, true);
           bx::sync();  // (every thread has read episode[env])
           if (tid == 0) {
             p.episode[env] = (int32_t)(ep + 1u);
-            if (p.cur_task) p.cur_task[env] = t;
+            if (p.cur_task) p.cur_task[env] = d.entry;
           }
         } else {
           init_planes(x, x.g(ARCLE_PL_INPUT), false);
@@ -1031,6 +1096,44 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     cnt0 += 1;  // o2arcenv.py:142
     cnt1 += submit_inc;
   }
+  if ((flags & ARCLE_STEP_DENSE) && p.dense) {
+    // the research env's dense reward (agents/env.py:44-58) as an exact integer pair (correct cells, total cells) of the state the step
+    // produced; (0, 0) = "no dense term" for a step that executed no action (the auto-reset step of an env, a skipped step).  Computed
+    // from the planes every time (the one-wavefront kernels keep a per-env cache of the pair; here the compare is one pass of a phase-bound
+    // kernel).
+    int correct = 0, total = 0;
+    if (counted) {
+      const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1], ah = r[ARCLE_REC_ANSWER_DIM], aw = r[ARCLE_REC_ANSWER_DIM + 1];
+      const int mh = imin(gh, ah), mw = imin(gw, aw);
+      if (tid == 0) x.red->sum = 0;
+      bx::sync();  // (also: every plane store of the step is visible to the workgroup)
+      int mine = 0;
+      const int lastc = imin(nch, (imax(mh, 0) * W + 15) >> 4);
+      for (int c = tid; c < lastc; c += NT) {
+        const Chunk a = ldg(x.g(ARCLE_PL_GRID), c), b = ldg(x.g(ARCLE_PL_ANSWER), c);
+        int f = 16 * c;
+        int i = f / W, j = f - i * W;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          mine += (i < mh && j < mw && a.b[k] == b.b[k]) ? 1 : 0;
+          if (++j == W) {
+            j = 0;
+            ++i;
+          }
+        }
+      }
+      if (mine) bx::lds_add(&x.red->sum, mine);
+      bx::sync();
+      correct = x.red->sum;
+      total = mh * mw;
+      if ((gh <= ah) == (gw <= aw)) total += ah * aw > gh * gw ? ah * aw - gh * gw : gh * gw - ah * aw;
+      else total += (gh > ah ? gh - ah : ah - gh) * mw + (gw > aw ? gw - aw : aw - gw) * mh;
+    }
+    if (tid == 0) {
+      p.dense[2 * (size_t)env] = correct;
+      p.dense[2 * (size_t)env + 1] = total;
+    }
+  }
   const int term = r[ARCLE_REC_TERMINATED] != 0;
   const bool truncated = (flags & ARCLE_STEP_TRUNCATE) && cnt0 >= p.step_limit;
   if (tid == 0) {
@@ -1060,7 +1163,8 @@ ARCLE_BIG_DEV void reset_env(const BigParams& p, int env, int mode, int8_t* lds)
     init_planes(x, x.g(ARCLE_PL_INPUT), false);
   } else {
     rc = zero_chunk();
-    int t;
+    int t, rot_k = 0;
+    uint64_t perm = ARCLE_BIG_PERM_IDENTITY;
     uint32_t ep = 0;
     if (mode == 1) {
       t = p.task_idx[env];
@@ -1068,17 +1172,23 @@ ARCLE_BIG_DEV void reset_env(const BigParams& p, int env, int mode, int8_t* lds)
         if (x.tid == 0) bx::status_or(p.status, ARCLE_ST_BAD_TASK);
         return;
       }
+      if (p.aug_k) rot_k = p.aug_k[env] & 3;
+      if (p.aug_perm) {
+        perm = ARCLE_BIG_PERM_IDENTITY & ~0xFFFFFFFFFFull;  // (nibbles 10..15 stay the identity)
+        for (int c = 0; c < 10; c++) perm |= (uint64_t)(p.aug_perm[16 * (size_t)env + c] & 15u) << (4 * c);
+      }
     } else {
       ep = (uint32_t)p.episode[env];
-      t = draw_task_entry(p, env, ep);
+      const Draw d = draw_task(p, env, ep);
+      t = d.entry;
+      rot_k = d.rot_k;
+      perm = d.perm;
       bx::sync();
     }
-    rc.b[ARCLE_REC_INPUT_DIM] = p.tbl_in_dim[2 * (size_t)t];
-    rc.b[ARCLE_REC_INPUT_DIM + 1] = p.tbl_in_dim[2 * (size_t)t + 1];
-    rc.b[ARCLE_REC_ANSWER_DIM] = p.tbl_ans_dim[2 * (size_t)t];
-    rc.b[ARCLE_REC_ANSWER_DIM + 1] = p.tbl_ans_dim[2 * (size_t)t + 1];
-    for (int c = x.tid; c < x.nch; c += x.NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(p.tbl_ans + (size_t)t * x.PS, c));
-    init_planes(x, p.tbl_in + (size_t)t * x.PS, true);
+    if (!load_task(x, rc.b, t, rot_k, perm, mode == 2)) {  // an explicit quarter turn that does not fit a non-square plane
+      if (x.tid == 0) bx::status_or(p.status, ARCLE_ST_AUG_DOMAIN);
+      return;
+    }
     if (x.tid == 0) {
       if (mode == 2) p.episode[env] = (int32_t)(ep + 1u);
       if (p.cur_task) p.cur_task[env] = t;

@@ -52,6 +52,11 @@ struct BigParams {
   const int32_t* src_env;
   const int8_t* res_answer;  // the handle's own answer plane / records
   const int8_t* res_rec;
+  // task augmentation at reset (agents/env.py:31-42): ARCLE_AUG_* flags of the device draw, or explicit per-env arrays
+  uint32_t aug_flags;
+  const uint8_t* aug_k;     // uint8 [n_envs]: np.rot90 count
+  const uint8_t* aug_perm;  // uint8 [n_envs][16]: perm[c] for colour c < 10
+  int32_t* dense;  // ARCLE_STEP_DENSE: int32 [n_envs][2] = (cells of the grid that match the answer inside the common rectangle, total cells)
 };
 
 // bytes of LDS one workgroup needs: four staging planes + the reduction block + two row boards of 128 x 128 bits

@@ -805,6 +805,7 @@ static arcle_big::BigParams big_params(const arcle_env* e) {
   q.pair_off = b.pair_off;
   q.pair_cnt = b.pair_cnt;
   q.n_problems = b.n_problems;
+  q.aug_flags = b.aug_flags;
   return q;
 }
 static int big_done(arcle_env* e, int hip_rc, const char* what) {
@@ -1185,8 +1186,6 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     // one workgroup per env (arcle_big.hip).  Flags: AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE (without augmentation), CONTINUE_RULE,
     // RESET_ON_SUBMIT, FLAT_OBS (+ tail / completion signal), PACK_OBS; ROWS_INCREMENTAL rewrites the rows in full (identical bytes)
     if (ingress == arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_CONFIG, "bit-packed masks (rows of ARCLE_MAX_CELLS / 8 bytes) are not available for grids of more than ARCLE_MAX_CELLS cells");
-    if (flags & ARCLE_STEP_DENSE) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_DENSE is not available for grids of more than ARCLE_MAX_CELLS cells");
-    if ((flags & ARCLE_STEP_RESAMPLE) && e->base.aug_flags) return fail(e, ARCLE_ERR_CONFIG, "task augmentation is not available for grids of more than ARCLE_MAX_CELLS cells");
     arcle_big::BigParams q = big_params(e);
     q.ingress = ingress;
     q.sel = sel;
@@ -1194,6 +1193,7 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     q.reward = reward;
     q.term = term;
     q.flags = flags;
+    q.dense = e->base.dense;
     if (flags & ARCLE_STEP_FLAT_OBS) {
       if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
       q.flat_out = e->flat_out;
@@ -1631,7 +1631,6 @@ extern "C" int arcle_set_sampler(arcle_env* e, const int32_t* pair_off, const in
   if (n_problems <= 0) return fail(e, ARCLE_ERR_CONFIG, "the sampler needs at least one problem with a pair");
   if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
   if (aug_flags & ~(ARCLE_AUG_PERMUTE | ARCLE_AUG_ROT90)) return fail(e, ARCLE_ERR_ARG, "unknown augmentation flag");
-  if (aug_flags) BIG_REFUSE(e, "task augmentation");
   e->base.pair_off = pair_off;
   e->base.pair_cnt = pair_cnt;
   e->base.n_problems = n_problems;
@@ -1665,8 +1664,13 @@ extern "C" int arcle_reset_from_table_aug(arcle_env* e, const int32_t* task_idx,
   if (!e || !task_idx) return ARCLE_ERR_ARG;
   if (e->base.n_tasks <= 0) return fail(e, ARCLE_ERR_CONFIG, "no task table installed (arcle_set_task_table)");
   if (e->big) {
-    if (aug_k || aug_perm) BIG_REFUSE(e, "task augmentation");
-    return arcle_reset_from_table(e, task_idx, mask, stream);
+    DeviceGuard guard(e->device);
+    arcle_big::BigParams q = big_params(e);
+    q.rmask = mask;
+    q.task_idx = task_idx;
+    q.aug_k = aug_k;
+    q.aug_perm = aug_perm;
+    return big_done(e, arcle_big::launch_reset(q, 1, stream), "arcle_reset_from_table_aug");
   }
   DeviceGuard guard(e->device);
   StepParams p = e->base;
@@ -1681,7 +1685,10 @@ extern "C" int arcle_reset_from_table_aug(arcle_env* e, const int32_t* task_idx,
 
 extern "C" int arcle_set_dense_output(arcle_env* e, int32_t* dense_out) {
   if (!e) return ARCLE_ERR_ARG;
-  if (dense_out) BIG_REFUSE(e, "the dense reward pair (ARCLE_STEP_DENSE)");
+  if (e->big) {  // (the workgroup-per-env kernels compute the pair from the planes every step: no cache)
+    e->base.dense = dense_out;
+    return ARCLE_OK;
+  }
   if (dense_out && !e->d_dense_cache) {  // the per-env cache of the current grid's pair; (0, 0) = unknown
     DeviceGuard guard(e->device);
     HIP_TRY(e, hipMalloc((void**)&e->d_dense_cache, (size_t)e->cfg.n_envs * 8));
@@ -1823,7 +1830,6 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
                                      int32_t out_stride, int tail, int32_t* reward, uint8_t* term, uint32_t flags, void* stream) {
   if (!e || !sel || !op || !reward || !term || !rows_out) return ARCLE_ERR_ARG;
   if (n_rows <= 0) return fail(e, ARCLE_ERR_ARG, "n_rows must be positive");
-  if (e->big && (flags & ARCLE_STEP_DENSE)) BIG_REFUSE(e, "the dense reward pair (ARCLE_STEP_DENSE)");
   if (!src_env && n_rows > e->cfg.n_envs) return fail(e, ARCLE_ERR_ARG, "more rows than envs: pass src_env (which env's answer every row uses)");
   if ((uint64_t)n_rows * ARCLE_MAX_CELLS >= (1ull << 32)) return fail(e, ARCLE_ERR_ARG, "too many rows");
   if (e->base.n_ops <= 0) return fail(e, ARCLE_ERR_CONFIG, "no op table installed (arcle_set_op_table)");
@@ -1877,6 +1883,7 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
     q.reward = reward;
     q.term = term;
     q.flags = flags | ARCLE_STEP_FLAT_OBS;
+    q.dense = e->base.dense;
     q.flat_out = rows_out;
     q.flat_stride = out_stride;
     q.flat_filter = 0;

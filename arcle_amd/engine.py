@@ -70,8 +70,7 @@ def _ptr(t):
 class EnvBatch:
     """n_envs envs of one kind on one GPU."""
     # what a batch of more than 1024 cells per plane (`self.big`) does not offer — the library refuses these calls with ARCLE_ERR_CONFIG
-    BIG_UNSUPPORTED = ("step_bits / pack_mask_bits", "dense reward pairs (STEP_DENSE)", "task augmentation", "transition_rows",
-                       "byte accounting", "autotune (one launch plan)")
+    BIG_UNSUPPORTED = ("step_bits / pack_mask_bits", "byte accounting", "autotune (one launch plan: returns no candidates)")
 
     def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None, plane_stride=None):
         check_grid_size(H, W)

@@ -203,15 +203,15 @@ typedef struct arcle_env arcle_env; /* opaque handle */
  * (ARC's own regime, 30 x 30: everything in this header applies).  A handle with H * W > ARCLE_MAX_CELLS (H, W <= ARCLE_MAX_SIDE) runs one
  * WORKGROUP per env (arcle_amd/csrc/arcle_big.hip): same layout (PS = H*W rounded up to 128), same entry points, same results bit for
  * bit against the reference's algorithm — with these differences:
- *   served      arcle_reset / _reset_from_table / _reset_sampled, arcle_step_mask / _bbox / _point / _bbox5, arcle_step_many, arcle_rollout_*
+ *   served      arcle_reset / _reset_from_table(_aug) / _reset_sampled (task augmentation included), arcle_step_mask / _bbox / _point / _bbox5,
+ *               arcle_step_many, arcle_rollout_*
  *               (= n_steps step launches: the state does not fit a wavefront's registers), arcle_transition_rows (three launches over
  *               library-owned scratch envs, allocated on first use: not inside a stream capture), arcle_flatten_obs / _get_state_rows /
- *               _set_state_rows, arcle_pack_obs, planes, status; step flags AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE, CONTINUE_RULE,
- *               RESET_ON_SUBMIT, FLAT_OBS (tail and completion signal included), PACK_OBS; ROWS_INCREMENTAL is accepted and rewrites the
- *               rows in full (identical bytes)
+ *               _set_state_rows, arcle_pack_obs, planes, status; step flags AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE, DENSE (the pair is
+ *               computed from the planes every step: no cache), CONTINUE_RULE, RESET_ON_SUBMIT, FLAT_OBS (tail and completion signal
+ *               included), PACK_OBS; ROWS_INCREMENTAL is accepted and rewrites the rows in full (identical bytes)
  *   refused     (ARCLE_ERR_CONFIG, arcle_last_error names the reason) arcle_step_bits / arcle_pack_mask_bits (their rows are
- *               ARCLE_MAX_CELLS / 8 bytes), ARCLE_STEP_DENSE / arcle_set_dense_output, task augmentation (arcle_set_sampler with
- *               aug_flags, arcle_reset_from_table_aug with arrays), arcle_enable_accounting
+ *               ARCLE_MAX_CELLS / 8 bytes), arcle_enable_accounting
  *   no-ops      arcle_set_dispatch_order, arcle_hint_next_ops, arcle_autotune (returns 0 candidates: one launch plan), arcle_launch_info
  *               reports {0, 0, waves per workgroup, 0}
  * Action arrays and row buffers may be device or pinned host memory as everywhere else. */

@@ -436,7 +436,8 @@ class _BigParams(ctypes.Structure):  # mirror of arcle_big::BigParams (arcle_amd
                 ("seed", ctypes.c_uint64), ("env_base", ctypes.c_int64), ("episode", ctypes.c_void_p),
                 ("cur_task", ctypes.c_void_p), ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p),
                 ("n_problems", ctypes.c_int32), ("rows_in", ctypes.c_void_p), ("rows_in_stride", ctypes.c_int32),
-                ("n_resident", ctypes.c_int32), ("src_env", ctypes.c_void_p), ("res_answer", ctypes.c_void_p), ("res_rec", ctypes.c_void_p)]
+                ("n_resident", ctypes.c_int32), ("src_env", ctypes.c_void_p), ("res_answer", ctypes.c_void_p), ("res_rec", ctypes.c_void_p),
+                ("aug_flags", ctypes.c_uint32), ("aug_k", ctypes.c_void_p), ("aug_perm", ctypes.c_void_p), ("dense", ctypes.c_void_p)]
 
 
 _big_emu = None
@@ -474,17 +475,19 @@ class BigEmuBackend(EmuBackend):
         p.d_ops = self._ops_arr.ctypes.data
         return p
 
+    def set_dense_output(self):
+        self.dense = np.full((self.N, 2), -7, np.int32)
+
     def _extras(self, p):
-        for name in ("trunc", "episode", "cur_task"):
+        for name in ("trunc", "episode", "cur_task", "dense"):
             arr = getattr(self, name, None)
             if arr is not None:
                 setattr(p, name, arr.ctypes.data)
         p.step_limit = getattr(self, "step_limit", 0)
         if getattr(self, "_sampler", None):
             off, cnt, seed, base, aug = self._sampler
-            assert aug == 0, "no augmentation on the big-grid path"
             p.pair_off, p.pair_cnt, p.n_problems = off.ctypes.data, cnt.ctypes.data, len(cnt)
-            p.seed, p.env_base = seed, base
+            p.seed, p.env_base, p.aug_flags = seed, base, aug
         if getattr(self, "tbl", None) is not None:
             p.tbl_in, p.tbl_in_dim, p.tbl_ans, p.tbl_ans_dim = [t.ctypes.data for t in self.tbl]
             p.n_tasks = len(self.tbl[0])
@@ -508,13 +511,19 @@ class BigEmuBackend(EmuBackend):
         self._run(1, p, 0)
 
     def reset_from_table(self, idx, mask=None, aug_k=None, aug_perm=None):
-        assert aug_k is None and aug_perm is None
         p = self._params()
         self._extras(p)
         idx = np.ascontiguousarray(idx, np.int32)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         p.rmask = None if m is None else m.ctypes.data
         p.task_idx = idx.ctypes.data
+        if aug_k is not None:
+            k8 = np.ascontiguousarray(aug_k, np.uint8)
+            p.aug_k = k8.ctypes.data
+        if aug_perm is not None:
+            pm = np.zeros((self.N, 16), np.uint8)
+            pm[:, :10] = aug_perm
+            p.aug_perm = pm.ctypes.data
         self._run(1, p, 1)
 
     def set_sampler(self, pair_off, pair_cnt, seed, env_base=0, aug_flags=0):

@@ -109,3 +109,67 @@ def task_table_case(be_cls):
         ep = int(episode[n]) - 1
         prob, sub, _, _ = sampling.draw_task(1234, 100 + n, ep, cnt)
         assert int(cur_task[n]) == off[prob] + sub
+
+
+def _augmented(a, k, perm):
+    """np.rot90 of the colour-permuted un-padded grid (agents/env.py:31-42)."""
+    lut = np.arange(256, dtype=np.int64)
+    lut[:10] = perm
+    return np.rot90(lut[a.astype(np.uint8)].astype(np.int8), k)
+
+
+def aug_case(be_cls):
+    """Task augmentation on the big path: explicit (rot90 count + colour permutation per env) and device-drawn (the function of (seed, global
+    env id, episode) arcle_amd.sampling mirrors), on a square plane; on a non-square one an explicit quarter turn that does not fit is
+    refused (AUG_DOMAIN, env untouched) and a drawn one is dropped (k & 2)."""
+    from arcle_amd import sampling
+    for (H, W) in ((40, 40), (34, 45)):
+        N, T = 6, 5
+        rng = np.random.default_rng(H + W)
+        ins = [rng.integers(0, 10, (rng.integers(2, H + 1), rng.integers(2, W + 1))).astype(np.int8) for _ in range(T)]
+        outs = [rng.integers(0, 10, (rng.integers(2, H + 1), rng.integers(2, W + 1))).astype(np.int8) for _ in range(T)]
+        if H != W:  # one entry that only fits unturned, one that fits both ways
+            ins[0], outs[0] = ins[0][:, :W][:H], np.zeros((3, W), np.int8) + 4
+            ins[1], outs[1] = ins[1][:H, :H][:20, :25], outs[1][:20, :30]
+        fits = [a.shape[1] <= H and a.shape[0] <= W and b_.shape[1] <= H and b_.shape[0] <= W for a, b_ in zip(ins, outs)]
+        be = be_cls(N, H, W, 3, "o2arc", O.o2arc_ops())
+        be.set_task_table(ins, outs)
+        idx = rng.integers(0, T, N).astype(np.int32)
+        idx[0], idx[1] = 0, 1
+        k = rng.integers(0, 4, N).astype(np.uint8)
+        k[0] = 1
+        perm = np.stack([rng.permutation(10) for _ in range(N)]).astype(np.uint8)
+        be.reset()  # (zeros: an env the explicit reset must leave untouched stays recognisable)
+        be.reset_from_table(idx, None, k, perm)
+        st = be.status()
+        refused = [n for n in range(N) if (k[n] & 1) and not fits[idx[n]]]
+        assert (st == 16) == bool(refused), (st, refused)
+        for n in range(N):
+            if n in refused:
+                assert not be.get("grid")[n].any() and not be.get("input")[n].any()
+                continue
+            a, b_ = _augmented(ins[idx[n]], int(k[n]), perm[n]), _augmented(outs[idx[n]], int(k[n]), perm[n])
+            want = np.zeros((H, W), np.int8)
+            want[:a.shape[0], :a.shape[1]] = a
+            assert np.array_equal(be.get("input")[n], want) and np.array_equal(be.get("grid")[n], want), (H, W, n)
+            want = np.zeros((H, W), np.int8)
+            want[:b_.shape[0], :b_.shape[1]] = b_
+            assert np.array_equal(be.get("answer")[n], want)
+            assert tuple(be.get("input_dim")[n]) == a.shape and tuple(be.get("answer_dim")[n]) == b_.shape and tuple(be.get("grid_dim")[n]) == a.shape
+        assert be.padding_is_zero()
+        off, cnt = np.array([0, 2, 3], np.int32), np.array([2, 1, 2], np.int32)
+        be.set_sampler(off, cnt, seed=99, env_base=7, aug_flags=3)
+        be.reset_sampled()
+        assert be.status() == 0
+        cur = np.asarray(be.cur_task)
+        for n in range(N):
+            prob, sub, dk, dperm = sampling.draw_task(99, 7 + n, 0, cnt, 3)
+            t = int(off[prob] + sub)
+            assert int(cur[n]) == t
+            if (dk & 1) and not fits[t]:
+                dk &= 2
+            a = _augmented(ins[t], dk, dperm)
+            want = np.zeros((H, W), np.int8)
+            want[:a.shape[0], :a.shape[1]] = a
+            assert np.array_equal(be.get("grid")[n], want), (H, W, n, dk)
+            assert tuple(be.get("answer_dim")[n]) == _augmented(outs[t], dk, dperm).shape

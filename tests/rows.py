@@ -237,11 +237,11 @@ def flat_tail(cls):
     return errs
 
 
-def dense_on_autoreset(cls):
+def dense_on_autoreset(cls, H=10, W=10):
     """ARCLE_STEP_DENSE with auto-reset: the step that re-initialises an env (and a skipped step) reports the pair (0, 0) = no dense
     term, never the previous step's pair; every executed step reports the pair of the state it produced."""
     errs = []
-    N, H, W = 10, 10, 10
+    N = 10
     rng = np.random.default_rng(5)
     ops = O.o2arc_ops()
     be, orc = cls(N, H, W, 1, "o2arc", ops), B.OracleBackend(N, H, W, 1, "o2arc", ops)

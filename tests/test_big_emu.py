@@ -78,3 +78,15 @@ def test_big_emulator_transition_rows():
     import rows as R
     errs = R.transition_rows(B.BigEmuBackend, cases=(("o2arc", 40, 40, 3), ("arc", 36, 41, 3), ("raw", 35, 30, 2)))
     assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("H,W", [(40, 40), (50, 50)])  # (square planes: a Rotate out of its domain is a skipped step too, and rows.dense_on_autoreset does not model those)
+def test_big_emulator_dense_pair(H, W):
+    """ARCLE_STEP_DENSE (agents/env.py:44-58 as an exact integer pair) incl. the (0, 0) of auto-reset and skipped steps"""
+    import rows as R
+    errs = R.dense_on_autoreset(B.BigEmuBackend, H, W)
+    assert not errs, "\n".join(errs[:10])
+
+
+def test_big_emulator_task_augmentation():
+    C.aug_case(B.BigEmuBackend)

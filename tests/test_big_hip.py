@@ -94,11 +94,46 @@ def test_hip_big_task_table_and_device_draw():
     C.task_table_case(B.HipBackend)
 
 
+@pytest.mark.parametrize("H,W", [(40, 40), (64, 64), (127, 127)])
+def test_hip_big_dense_pair(H, W):
+    """ARCLE_STEP_DENSE (agents/env.py:44-58 as an exact integer pair) incl. the (0, 0) of auto-reset and skipped steps"""
+    import rows as R
+    errs = R.dense_on_autoreset(B.HipBackend, H, W)
+    assert not errs, "\n".join(errs[:10])
+
+
 def test_hip_big_transition_rows():
     """the stateless batched transition (o2arcenv.py:149-151) on grids of more than 1024 cells: rows in, scratch envs, rows out"""
     import rows as R
     errs = R.transition_rows(B.HipBackend, cases=(("o2arc", 40, 40, 3), ("arc", 36, 41, 3), ("raw", 35, 30, 2), ("o2arc", 127, 127, -1)))
     assert not errs, "\n".join(errs[:10])
+
+
+def test_hip_big_task_augmentation():
+    C.aug_case(B.HipBackend)
+
+
+def test_hip_big_research_env_flags():
+    """ARCVecEnv as the research env (dense reward, TimeLimit, device-drawn tasks with augmentation at every auto-reset, FilterO2ARC rows) at
+    max_grid_size (40, 40): runs, stays consistent with its own stand-alone row writer, reports no device error"""
+    import torch
+    from arcle_amd.envs import ARCVecEnv, O2ARCv2Env
+    from arcle_amd.loaders import SyntheticLoader
+    loader = SyntheticLoader(n_tasks=8, seed=3, max_size=(40, 40))
+    venv = ARCVecEnv(O2ARCv2Env, 64, loader, max_grid_size=(40, 40), autoreset="resample", seed=5, max_episode_steps=6, dense_reward=True,
+                     augment=True)
+    rows = venv.enable_flat_rows(filtered=True)
+    obs, info = venv.reset()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for _ in range(20):
+        bbox = torch.randint(0, 40, (64, 4), generator=g, dtype=torch.int32).cuda()
+        op = torch.randint(0, 35, (64,), generator=g, dtype=torch.int32).cuda()
+        obs, reward, term, trunc, info = venv.step_bbox(bbox, op)
+        torch.cuda.synchronize()
+        assert reward.dtype == torch.float32 and int(info["steps"].max()) <= 6
+        assert torch.equal(rows, venv.flat_obs(filtered=True))
+    venv.check_errors()
+    assert int(venv.batch.episode.max()) >= 2  # envs restarted on freshly drawn tasks
 
 
 def test_hip_big_rollout_is_n_step_launches():
