@@ -23,7 +23,7 @@ BITS_STRIDE = 128  # bytes between envs of a bit-packed mask array (ARCLE_MAX_CE
 INGRESS = {"mask": 0, "bbox": 1, "point": 2, "bbox5": 3, "bits": 4}  # enum arcle_ingress
 EXPORTS = ["arcle_abi_version", "arcle_create", "arcle_destroy", "arcle_get_buffers", "arcle_set_op_table",
            "arcle_can_elide_selected", "arcle_reset", "arcle_set_task_table", "arcle_reset_from_table",
-           "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_step_bbox5", "arcle_step_bits", "arcle_pack_mask_bits",
+           "arcle_step_mask", "arcle_step_bbox", "arcle_step_point", "arcle_step_bbox5", "arcle_step_bits", "arcle_pack_mask_bits", "arcle_mask_bits_stride",
            "arcle_step_many", "arcle_set_dispatch_order", "arcle_hint_next_ops", "arcle_launch_info", "arcle_autotune", "arcle_rollout_bbox", "arcle_rollout_point", "arcle_rollout_mask", "arcle_set_truncation",
            "arcle_packed_obs_size", "arcle_pack_obs", "arcle_set_packed_output", "arcle_set_sampler", "arcle_reset_sampled",
            "arcle_reset_from_table_aug", "arcle_set_dense_output", "arcle_invalidate", "arcle_flat_obs_size", "arcle_flatten_obs",
@@ -103,6 +103,7 @@ def lib():
     L.arcle_step_bbox5.argtypes = [vp, vp, vp, vp, u32, vp]
     L.arcle_step_bits.argtypes = [vp, vp, vp, vp, vp, u32, vp]
     L.arcle_pack_mask_bits.argtypes = [vp, vp, vp, vp]
+    L.arcle_mask_bits_stride.argtypes = [vp]
     L.arcle_step_many.argtypes = [vp, ctypes.c_int, i32, vp, vp, vp, vp, u32, vp]
     L.arcle_set_dispatch_order.argtypes = [vp, ctypes.c_int]
     L.arcle_hint_next_ops.argtypes = [vp, vp, i32]

@@ -636,7 +636,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     int staged = -1;  // the plane A holds (arcle_plane) once the ingest barrier has passed
     bool staged_obj = false;  // ... and B / C hold the stored object / object_sel
     {
-      const bool tuple = p.ingress != ING_MASK;
+      const bool tuple = p.ingress != ING_MASK && p.ingress != ING_BITS;
       bool tuple_any = false;
       if (p.ingress == ING_POINT) tuple_any = (uint32_t)pay[0] < (uint32_t)H && (uint32_t)pay[1] < (uint32_t)W;
       else if (tuple) tuple_any = (uint32_t)imin(pay[0], pay[2]) < (uint32_t)H && (uint32_t)imin(pay[1], pay[3]) < (uint32_t)W;
@@ -667,15 +667,21 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     // ---- selection -> S (bytes in LDS) + its reductions -------------------------------------------------------------------------
     bool any_nz, any_pos;
     int ssum, x0, x1, y0, y1, amax_cell;
-    if (p.ingress == ING_MASK) {
-      const int8_t* const src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)env * (size_t)P;
+    if (p.ingress == ING_MASK || p.ingress == ING_BITS) {
+      const bool packed = p.ingress == ING_BITS;  // boolean masks, bit f of the env's row of PS / 8 bytes = cell f
+      const int8_t* const src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)env * (size_t)(packed ? x.PS >> 3 : P);
       const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
       int l_nz = 0, l_pos = 0, l_sum = 0, lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
       uint32_t l_amax = 0;
       for (int c = tid; c < nch; c += NT) {
         Chunk v = zero_chunk();
         const int f0 = 16 * c;
-        if (aligned && f0 + 16 <= P) {
+        if (packed) {
+          const uint32_t m = (uint32_t)(uint8_t)src[2 * c] | ((uint32_t)(uint8_t)src[2 * c + 1] << 8);
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            if (f0 + k < P) v.b[k] = (int8_t)((m >> k) & 1u);
+        } else if (aligned && f0 + 16 <= P) {
           v = ldg(src, c);
         } else {
 #pragma unroll
@@ -1206,6 +1212,19 @@ ARCLE_BIG_DEV void reset_env(const BigParams& p, int env, int mode, int8_t* lds)
 // mode 0: arcle_flatten_obs / arcle_get_state_rows (rows of the resident state, no tail); 1: arcle_pack_obs (reward / term arrays given)
 ARCLE_BIG_DEV void rows_env(const BigParams& p, int env, int mode, int8_t* lds) {
   const Ctx x(p, env, lds);
+  if (mode == 2) {  // arcle_pack_mask_bits: int8 [N][P] masks (truthy = non-zero) -> bit rows of PS / 8 bytes (p.pack_out)
+    const int8_t* const src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)env * (size_t)x.P;
+    uint8_t* const dst = p.pack_out + (size_t)env * (size_t)(x.PS >> 3);
+    for (int c = x.tid; c < x.nch; c += x.NT) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (16 * c + k < x.P && src[16 * c + k] != 0) m |= 1u << k;
+      dst[2 * c] = (uint8_t)m;
+      dst[2 * c + 1] = (uint8_t)(m >> 8);
+    }
+    return;
+  }
   const Chunk rc = ldg(p.rec, env);
   if (mode == 0) emit_rows(x, rc.b, ARCLE_STEP_FLAT_OBS, 0, 0, 0, 0, false, 0);
   else emit_rows(x, rc.b, ARCLE_STEP_PACK_OBS, p.reward[env], p.term[env], 0, 0, false, 0);

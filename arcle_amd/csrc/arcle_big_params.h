@@ -11,7 +11,7 @@
 
 namespace arcle_big {
 
-enum { ING_MASK = 0, ING_BBOX = 1, ING_POINT = 2, ING_BBOX5 = 3 };
+enum { ING_MASK = 0, ING_BBOX = 1, ING_POINT = 2, ING_BBOX5 = 3, ING_BITS = 4 };  // (= enum arcle_ingress)
 enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 32, MAX_ROWS_PER_THREAD = 4, FILL_INNER = 8 };
 
 struct BigParams {

@@ -1185,7 +1185,6 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
   if (e->big) {
     // one workgroup per env (arcle_big.hip).  Flags: AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE (without augmentation), CONTINUE_RULE,
     // RESET_ON_SUBMIT, FLAT_OBS (+ tail / completion signal), PACK_OBS; ROWS_INCREMENTAL rewrites the rows in full (identical bytes)
-    if (ingress == arcle::INGRESS_BITS) return fail(e, ARCLE_ERR_CONFIG, "bit-packed masks (rows of ARCLE_MAX_CELLS / 8 bytes) are not available for grids of more than ARCLE_MAX_CELLS cells");
     arcle_big::BigParams q = big_params(e);
     q.ingress = ingress;
     q.sel = sel;
@@ -1447,7 +1446,7 @@ static size_t payload_bytes(const arcle_env* e, int ingress) {
     case arcle::INGRESS_BBOX: return n * 16;
     case arcle::INGRESS_POINT: return n * 8;
     case arcle::INGRESS_BBOX5: return n * 20;
-    default: return n * ARCLE_BITS_STRIDE;
+    default: return n * (size_t)(e->big ? e->base.PS >> 3 : ARCLE_BITS_STRIDE);
   }
 }
 
@@ -1517,10 +1516,21 @@ extern "C" int arcle_set_dispatch_order(arcle_env* e, int enable) {
   return ARCLE_OK;
 }
 
+extern "C" int arcle_mask_bits_stride(const arcle_env* e) {
+  if (!e) return ARCLE_ERR_ARG;
+  return e->big ? e->base.PS >> 3 : ARCLE_BITS_STRIDE;
+}
+
 extern "C" int arcle_pack_mask_bits(arcle_env* e, const int8_t* sel, uint8_t* bits, void* stream) {
   if (!e || !sel || !bits) return ARCLE_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(bits) & 1) return fail(e, ARCLE_ERR_ARG, "bit-packed mask rows must be 2-byte aligned");
-  BIG_REFUSE(e, "arcle_pack_mask_bits (rows of ARCLE_MAX_CELLS / 8 bytes)");
+  if (e->big) {  // (rows of plane_stride / 8 bytes)
+    DeviceGuard guard(e->device);
+    arcle_big::BigParams q = big_params(e);
+    q.sel = sel;
+    q.pack_out = bits;
+    return big_done(e, arcle_big::launch_rows(q, 2, stream), "arcle_pack_mask_bits");
+  }
   DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.sel = sel;

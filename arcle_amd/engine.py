@@ -70,7 +70,7 @@ def _ptr(t):
 class EnvBatch:
     """n_envs envs of one kind on one GPU."""
     # what a batch of more than 1024 cells per plane (`self.big`) does not offer — the library refuses these calls with ARCLE_ERR_CONFIG
-    BIG_UNSUPPORTED = ("step_bits / pack_mask_bits", "byte accounting", "autotune (one launch plan: returns no candidates)")
+    BIG_UNSUPPORTED = ("byte accounting", "autotune (one launch plan: returns no candidates)")
 
     def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None, plane_stride=None):
         check_grid_size(H, W)
@@ -105,6 +105,7 @@ class EnvBatch:
         if rc != 0:
             raise ArcleHipError(f"arcle_create failed with status {rc}")
         self._h = h
+        self.bits_stride = int(self.L.arcle_mask_bits_stride(h))  # bytes between the envs' rows of a bit-packed mask array (128 up to 1024 cells)
         self.n_ops = 0
         self._reward_ptr, self._term_ptr = self.reward.data_ptr(), self.term.data_ptr()
 
@@ -320,7 +321,7 @@ class EnvBatch:
 
     def step_bits(self, bits, op, flags=0):
         """bits uint8 [N,128]: bit-packed boolean selection masks (bit f of row e = cell f of env e; `pack_mask_bits` makes them)."""
-        assert bits.dtype == torch.uint8 and bits.shape == (self.N, _lib.BITS_STRIDE) and bits.is_contiguous() and bits.device == self.device
+        assert bits.dtype == torch.uint8 and bits.shape == (self.N, self.bits_stride) and bits.is_contiguous() and bits.device == self.device
         return self._step(self.L.arcle_step_bits, bits, op, flags)
 
     def pack_mask_bits(self, sel, out=None):
@@ -330,7 +331,7 @@ class EnvBatch:
         if sel.dtype != torch.int8 or not sel.is_contiguous() or sel.device != self.device:
             sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
         if out is None:
-            out = torch.empty((self.N, _lib.BITS_STRIDE), dtype=torch.uint8, device=self.device)
+            out = torch.empty((self.N, self.bits_stride), dtype=torch.uint8, device=self.device)
         self._check(self.L.arcle_pack_mask_bits(self._h, _ptr(sel), _ptr(out), self._stream()), "arcle_pack_mask_bits")
         return out
 

@@ -203,15 +203,14 @@ typedef struct arcle_env arcle_env; /* opaque handle */
  * (ARC's own regime, 30 x 30: everything in this header applies).  A handle with H * W > ARCLE_MAX_CELLS (H, W <= ARCLE_MAX_SIDE) runs one
  * WORKGROUP per env (arcle_amd/csrc/arcle_big.hip): same layout (PS = H*W rounded up to 128), same entry points, same results bit for
  * bit against the reference's algorithm — with these differences:
- *   served      arcle_reset / _reset_from_table(_aug) / _reset_sampled (task augmentation included), arcle_step_mask / _bbox / _point / _bbox5,
- *               arcle_step_many, arcle_rollout_*
+ *   served      arcle_reset / _reset_from_table(_aug) / _reset_sampled (task augmentation included), arcle_step_mask / _bbox / _point / _bbox5 /
+ *               _bits (+ arcle_pack_mask_bits; rows of plane_stride / 8 bytes), arcle_step_many, arcle_rollout_*
  *               (= n_steps step launches: the state does not fit a wavefront's registers), arcle_transition_rows (three launches over
  *               library-owned scratch envs, allocated on first use: not inside a stream capture), arcle_flatten_obs / _get_state_rows /
  *               _set_state_rows, arcle_pack_obs, planes, status; step flags AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE, DENSE (the pair is
  *               computed from the planes every step: no cache), CONTINUE_RULE, RESET_ON_SUBMIT, FLAT_OBS (tail and completion signal
  *               included), PACK_OBS; ROWS_INCREMENTAL is accepted and rewrites the rows in full (identical bytes)
- *   refused     (ARCLE_ERR_CONFIG, arcle_last_error names the reason) arcle_step_bits / arcle_pack_mask_bits (their rows are
- *               ARCLE_MAX_CELLS / 8 bytes), arcle_enable_accounting
+ *   refused     (ARCLE_ERR_CONFIG, arcle_last_error names the reason) arcle_enable_accounting (these kernels carry no byte counters)
  *   no-ops      arcle_set_dispatch_order, arcle_hint_next_ops, arcle_autotune (returns 0 candidates: one launch plan), arcle_launch_info
  *               reports {0, 0, waves per workgroup, 0}
  * Action arrays and row buffers may be device or pinned host memory as everywhere else. */
@@ -270,7 +269,8 @@ int arcle_step_point(arcle_env* env, const int32_t* xy, const int32_t* op, int32
  *           5-tuple `BBoxWrapper.action` receives (bbox.py:22-30, examples/example_bbox.py:13-15); no separate op array, so a
  *           host-resident policy moves its actions with one 20-byte-per-env copy (or none: act5 may be pinned host memory)
  *   _bits : bits device uint8[n_envs][128] boolean selection masks, bit-packed: bit (f & 7) of byte (f >> 3) of row e = cell f
- *           (row-major, f = row * W + col) of env e is selected; rows are ARCLE_MAX_CELLS / 8 = 128 bytes apart, 2-byte aligned.
+ *           (row-major, f = row * W + col) of env e is selected; rows are ARCLE_MAX_CELLS / 8 = 128 bytes apart (handles of more than
+ *           ARCLE_MAX_CELLS cells: plane_stride / 8 bytes — arcle_mask_bits_stride() says which), 2-byte aligned.
  *           `create_action_space` accepts boolean masks (base.py:134-138); packed they are 1/8 of the int8 traffic and need no
  *           byte -> bit reduction in the kernel.  arcle_pack_mask_bits converts int8 [n_envs][H*W] masks (truthy = non-zero). */
 enum arcle_ingress { ARCLE_INGRESS_MASK = 0, ARCLE_INGRESS_BBOX = 1, ARCLE_INGRESS_POINT = 2, ARCLE_INGRESS_BBOX5 = 3, ARCLE_INGRESS_BITS = 4 };
@@ -278,6 +278,7 @@ int arcle_step_bbox5(arcle_env* env, const int32_t* act5, int32_t* reward, uint8
 int arcle_step_bits(arcle_env* env, const uint8_t* bits, const int32_t* op, int32_t* reward, uint8_t* term, uint32_t flags,
                     void* stream);
 int arcle_pack_mask_bits(arcle_env* env, const int8_t* sel, uint8_t* bits, void* stream);
+int arcle_mask_bits_stride(const arcle_env* env); /* bytes between the envs' rows of a bit-packed mask array */
 
 /* n_steps consecutive step() LAUNCHES enqueued by ONE call (the loop `for t in range(n): env.step(actions[t])` of a caller that
  * holds the actions of the next n steps; every step is a full step(): state observable in between on the stream, all step flags

@@ -58,7 +58,8 @@ def pack_bits(masks):
     m = np.asarray(masks)
     n = m.shape[0]
     flat = (m.reshape(n, -1) != 0)
-    out = np.zeros((n, BITS_STRIDE), np.uint8)
+    P = flat.shape[1]
+    out = np.zeros((n, BITS_STRIDE if P <= 1024 else ((P + 127) & ~127) // 8), np.uint8)  # (arcle_mask_bits_stride: plane stride / 8 beyond 1024 cells)
     pk = np.packbits(flat, axis=1, bitorder="little")
     out[:, :pk.shape[1]] = pk
     return out
@@ -547,12 +548,22 @@ class BigEmuBackend(EmuBackend):
         self._extras(p)
         if ingress == "mask":
             pay = np.ascontiguousarray(np.asarray(payload).astype(np.int8)).reshape(self.N, self.P)
+        elif ingress == "bits":
+            pay = np.ascontiguousarray(payload, np.uint8).reshape(self.N, self.PS // 8)
         else:
             pay = np.ascontiguousarray(payload, np.int32)
         opa = np.ascontiguousarray(op if op is not None else np.zeros(self.N), np.int32)
         p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
         self._run(0, p)
         return self.reward.copy(), self.term.copy()
+
+    def pack_mask_bits(self, masks):
+        p = self._params()
+        pay = np.ascontiguousarray(np.asarray(masks).astype(np.int8)).reshape(self.N, self.P)
+        out = np.full((self.N, self.PS // 8), 0x55, np.uint8)
+        p.sel, p.pack_out = pay.ctypes.data, out.ctypes.data
+        self._run(2, p, 2)
+        return out
 
     def flat_obs(self, filtered=False):
         L = self._flat_len(filtered)

@@ -90,3 +90,14 @@ def test_big_emulator_dense_pair(H, W):
 
 def test_big_emulator_task_augmentation():
     C.aug_case(B.BigEmuBackend)
+
+
+@pytest.mark.parametrize("H,W", [(40, 40), (36, 41)])
+def test_big_emulator_record_and_bit_packed_forms(H, W):
+    """5-tuple records and bit-packed boolean masks (rows of plane_stride / 8 bytes) against the oracle's classic forms; the packer"""
+    errs = B.random_trace_compare(B.BigEmuBackend, "o2arc", O.o2arc_ops(), H, W, N=5, S=60, seed=H + W, max_trial=3, flags=3, new_forms=True)
+    assert not errs, "\n".join(errs[:10])
+    rng = np.random.default_rng(1)
+    be = B.BigEmuBackend(5, H, W, 3, "o2arc", O.o2arc_ops())
+    m = (rng.random((5, H, W)) < 0.3).astype(np.int8) * rng.integers(-3, 4, (5, H, W)).astype(np.int8)
+    assert np.array_equal(be.pack_mask_bits(m), B.pack_bits(m))

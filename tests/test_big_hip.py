@@ -39,29 +39,17 @@ def test_hip_big_batch_of_2048_envs_50x50():
     assert not errs, "\n".join(errs[:10])
 
 
-def test_hip_big_record_form():
-    """BBoxWrapper 5-tuples as ONE record per env (arcle_step_bbox5); bit-packed masks are refused by name"""
-    import torch
-    from arcle_amd._lib import ArcleHipError
-    errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), 40, 40, N=16, S=0, seed=1)
-    be = B.HipBackend(16, 40, 40, 3, "o2arc", O.o2arc_ops())
-    orc = B.OracleBackend(16, 40, 40, 3, "o2arc", O.o2arc_ops())
-    rng = np.random.default_rng(5)
-    inp = rng.integers(0, 10, (16, 40, 40)).astype(np.int8)
-    dims = np.full((16, 2), 40, np.int8)
-    for b_ in (be, orc):
-        b_.set_tasks(inp, dims, inp, dims)
-        b_.reset()
-    for s in range(30):
-        act = np.stack([rng.integers(0, 40, 16), rng.integers(0, 40, 16), rng.integers(0, 40, 16), rng.integers(0, 40, 16), rng.integers(0, 35, 16)], 1)
-        r1, t1 = be.step("bbox5", act, None, 3)
-        r2, t2 = orc.step("bbox5", act, None, 3)
-        assert np.array_equal(r1, r2) and np.array_equal(t1, t2)
-        for f in ("grid", "selected", "object", "clip", "background", "object_sel"):
-            assert np.array_equal(be.get(f), orc.get(f)), (s, f)
-    with pytest.raises(ArcleHipError, match="ARCLE_MAX_CELLS"):
-        be.b.step_bits(torch.zeros((16, 128), dtype=torch.uint8, device=be.b.device), torch.zeros(16, dtype=torch.int32, device=be.b.device), 0)
-    assert not errs
+@pytest.mark.parametrize("H,W", [(40, 40), (36, 41), (127, 127)])
+def test_hip_big_record_and_bit_packed_forms(H, W):
+    """5-tuple records (arcle_step_bbox5) and bit-packed boolean masks (arcle_step_bits, rows of plane_stride / 8 bytes) against the oracle's
+    classic forms; arcle_pack_mask_bits"""
+    errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), H, W, N=24, S=60, seed=H + W, max_trial=3, flags=3, new_forms=True)
+    assert not errs, "\n".join(errs[:10])
+    rng = np.random.default_rng(1)
+    be = B.HipBackend(24, H, W, 3, "o2arc", O.o2arc_ops())
+    assert be.b.bits_stride == ((H * W + 127) & ~127) // 8
+    m = (rng.random((24, H, W)) < 0.3).astype(np.int8) * rng.integers(-3, 4, (24, H, W)).astype(np.int8)
+    assert np.array_equal(be.pack_mask_bits(m), B.pack_bits(m))
 
 
 @pytest.mark.parametrize("variant", ["o2arc_exotic", "o2arc_crop"])
