@@ -157,8 +157,10 @@ struct Ctx {
   Red* red;
   uint64_t *Eb, *Fb;
   size_t po;
+  mutable uint32_t io;  // 16-byte global-memory accesses this thread issued (plane chunks, table chunks, mask chunks, row units): the
+                        // byte accounting of arcle_enable_accounting — a register increment per access, summed per env when asked for
   ARCLE_BIG_DEV Ctx(const BigParams& p_, int env_, int8_t* lds)
-      : p(p_), env(env_), tid(bx::tid()), NT(bx::nt()), H(p_.H), W(p_.W), P(p_.P), PS(p_.PS), nch(p_.PS >> 4) {
+      : p(p_), env(env_), tid(bx::tid()), NT(bx::nt()), H(p_.H), W(p_.W), P(p_.P), PS(p_.PS), nch(p_.PS >> 4), io(0) {
     S = lds;
     A = lds + PS;
     B = lds + 2 * PS;
@@ -170,10 +172,23 @@ struct Ctx {
   }
   ARCLE_BIG_DEV int8_t* g(int pl) const { return p.plane[pl] + po; }
   ARCLE_BIG_DEV bool has(int pl) const { return p.plane[pl] != nullptr; }
-  // global plane -> LDS tile / LDS tile -> global plane / fill
-  ARCLE_BIG_DEV void stage(int8_t* dst, const int8_t* src) const {
-    for (int c = tid; c < nch; c += NT) stg(dst, c, ldg(src, c));
+  // chunk c of a state plane of this env: load / store (counted)
+  ARCLE_BIG_DEV Chunk gl(int pl, int c) const {
+    io++;
+    return ldg(p.plane[pl] + po, c);
   }
+  ARCLE_BIG_DEV void gs(int pl, int c, const Chunk& v) const {
+    io++;
+    stg(p.plane[pl] + po, c, v);
+  }
+  // global plane -> LDS tile / fill
+  ARCLE_BIG_DEV void stage(int8_t* dst, const int8_t* src) const {
+    for (int c = tid; c < nch; c += NT) {
+      io++;
+      stg(dst, c, ldg(src, c));
+    }
+  }
+  ARCLE_BIG_DEV void stage_g(int8_t* dst, int pl) const { stage(dst, p.plane[pl] + po); }
   ARCLE_BIG_DEV void fill(int8_t* dst, const Chunk& v) const {
     for (int c = tid; c < nch; c += NT) stg(dst, c, v);
   }
@@ -185,13 +200,14 @@ ARCLE_BIG_DEV void init_planes(const Ctx& x, const int8_t* src, bool write_input
   const Chunk z = zero_chunk();
   for (int c = x.tid; c < x.nch; c += x.NT) {
     const Chunk in = ldg(src, c);
-    if (write_input) stg(x.g(ARCLE_PL_INPUT), c, in);
-    stg(x.g(ARCLE_PL_GRID), c, in);
-    if (x.has(ARCLE_PL_SELECTED)) stg(x.g(ARCLE_PL_SELECTED), c, z);
-    if (x.has(ARCLE_PL_CLIP)) stg(x.g(ARCLE_PL_CLIP), c, z);
-    if (x.has(ARCLE_PL_OBJECT)) stg(x.g(ARCLE_PL_OBJECT), c, z);
-    if (x.has(ARCLE_PL_OBJECT_SEL)) stg(x.g(ARCLE_PL_OBJECT_SEL), c, z);
-    if (x.has(ARCLE_PL_BACKGROUND)) stg(x.g(ARCLE_PL_BACKGROUND), c, z);
+    x.io++;
+    if (write_input) x.gs(ARCLE_PL_INPUT, c, in);
+    x.gs(ARCLE_PL_GRID, c, in);
+    if (x.has(ARCLE_PL_SELECTED)) x.gs(ARCLE_PL_SELECTED, c, z);
+    if (x.has(ARCLE_PL_CLIP)) x.gs(ARCLE_PL_CLIP, c, z);
+    if (x.has(ARCLE_PL_OBJECT)) x.gs(ARCLE_PL_OBJECT, c, z);
+    if (x.has(ARCLE_PL_OBJECT_SEL)) x.gs(ARCLE_PL_OBJECT_SEL, c, z);
+    if (x.has(ARCLE_PL_BACKGROUND)) x.gs(ARCLE_PL_BACKGROUND, c, z);
   }
 }
 ARCLE_BIG_DEV void init_rec(int8_t* r, int max_trial) {
@@ -221,7 +237,10 @@ ARCLE_BIG_DEV bool load_task(const Ctx& x, int8_t* r, int t, int rot_k, uint64_t
   const int8_t* const tin = p.tbl_in + (size_t)t * x.PS;
   const int8_t* const tan = p.tbl_ans + (size_t)t * x.PS;
   if (rot_k == 0 && perm == ARCLE_BIG_PERM_IDENTITY) {
-    for (int c = x.tid; c < x.nch; c += x.NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(tan, c));
+    for (int c = x.tid; c < x.nch; c += x.NT) {
+      x.io++;
+      x.gs(ARCLE_PL_ANSWER, c, ldg(tan, c));
+    }
     init_planes(x, tin, true);
   } else {
     x.stage(x.A, tin);
@@ -235,9 +254,9 @@ ARCLE_BIG_DEV bool load_task(const Ctx& x, int8_t* r, int t, int rot_k, uint64_t
       if (rot_k == 1) { ai = -1; bj = W; c0 = w - 1; nh = w; nw = h; }                // np.rot90(x, 1)[i, j] = x[j, w-1-i]
       else if (rot_k == 2) { ai = -W; bj = -1; c0 = (h - 1) * W + (w - 1); }          // x[h-1-i, w-1-j]
       else if (rot_k == 3) { ai = 1; bj = -W; c0 = (h - 1) * W; nh = w; nw = h; }      // x[h-1-j, i]
-      int8_t* const dst = x.g(which ? ARCLE_PL_ANSWER : ARCLE_PL_INPUT);
+      const int dpl = which ? ARCLE_PL_ANSWER : ARCLE_PL_INPUT;
       for (int c = x.tid; c < x.nch; c += x.NT)
-        stg(dst, c, build_chunk(c, W, x.P, [&](int, int i, int j) {
+        x.gs(dpl, c, build_chunk(c, W, x.P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int v = (uint8_t)src[in ? c0 + ai * i + bj * j : 0];
               const int pv = v < 16 ? (int)((perm >> (4 * v)) & 15u) : v;  // (cells beyond the palette keep their value)
@@ -264,7 +283,7 @@ ARCLE_BIG_DEV bool grid_equals_answer(const Ctx& x, const int8_t* r) {
   bool differs = false;
   const int lastc = imin(x.nch, (gh * x.W + 15) >> 4);  // cells of the rows >= gh are never compared
   for (int c = x.tid; c < lastc; c += x.NT) {
-    const Chunk a = ldg(x.g(ARCLE_PL_GRID), c), b = ldg(x.g(ARCLE_PL_ANSWER), c);
+    const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
     if ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) {
       int f = 16 * c;
       int i = f / x.W, j = f - i * x.W;
@@ -394,6 +413,7 @@ ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, in
         }
       }
     }
+    x.io += 2;  // (the unit stored + the 16 source bytes read)
     stg(dst, u, v);
   }
 }
@@ -523,7 +543,7 @@ ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int 
       any |= in;
       return in ? (int8_t)colour : x.A[f];
     });
-    if (any) stg(x.g(ARCLE_PL_GRID), c, o);
+    if (any) x.gs(ARCLE_PL_GRID, c, o);
   }
 }
 
@@ -552,8 +572,8 @@ ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const 
       sel.b[k] = in ? qv : (int8_t)0;         // :165
       return gv;
     });
-    stg(x.g(ARCLE_PL_GRID), c, grid);
-    stg(x.g(ARCLE_PL_SELECTED), c, sel);
+    x.gs(ARCLE_PL_GRID, c, grid);
+    x.gs(ARCLE_PL_SELECTED, c, sel);
   }
 }
 
@@ -657,10 +677,10 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           break;
         default: break;
       }
-      if (staged >= 0) x.stage(x.A, x.g(staged));
+      if (staged >= 0) x.stage_g(x.A, staged);
       if (staged_obj) {
-        x.stage(x.B, x.g(ARCLE_PL_OBJECT));
-        x.stage(x.C, x.g(ARCLE_PL_OBJECT_SEL));
+        x.stage_g(x.B, ARCLE_PL_OBJECT);
+        x.stage_g(x.C, ARCLE_PL_OBJECT_SEL);
       }
     }
 
@@ -676,6 +696,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       for (int c = tid; c < nch; c += NT) {
         Chunk v = zero_chunk();
         const int f0 = 16 * c;
+        x.io++;  // (the mask chunk: 16 bytes, or 2 of a bit row — counted as a chunk)
         if (packed) {
           const uint32_t m = (uint32_t)(uint8_t)src[2 * c] | ((uint32_t)(uint8_t)src[2 * c + 1] << 8);
 #pragma unroll
@@ -740,7 +761,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         // `selected` plane continues the active object, i.e. is sent with an empty selection
         bool differs = false;
         for (int c = tid; c < nch; c += NT) {
-          const Chunk a = ldg(x.g(ARCLE_PL_SELECTED), c), b = ldg(x.S, c);
+          const Chunk a = x.gl(ARCLE_PL_SELECTED, c), b = ldg(x.S, c);
           differs |= ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) != 0;
         }
         if (differs) q->neq = 1;
@@ -850,9 +871,9 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
 
     // ---- the wrappers' plane writes ----
     if (oflags & ARCLE_OPF_KEEP_SEL) {
-      for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_SELECTED), c, ldg(x.S, c));
+      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, ldg(x.S, c));
     } else if ((oflags & ARCLE_OPF_RESET_SEL) && !((flags & ARCLE_STEP_ELIDE_SELECTED) && active_before == 0)) {
-      for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_SELECTED), c, zero_chunk());
+      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, zero_chunk());
     }
 
     int eq = -1;  // grid == answer, evaluated at most once
@@ -863,11 +884,11 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         for (int c = tid; c < nch; c += NT) {
           const Chunk s = ldg(x.S, c);
           if (!(s.w[0] | s.w[1] | s.w[2] | s.w[3])) continue;
-          Chunk gr = ldg(x.g(ARCLE_PL_GRID), c);
+          Chunk gr = x.gl(ARCLE_PL_GRID, c);
 #pragma unroll
           for (int k = 0; k < 16; k++)
             if (s.b[k] != 0) gr.b[k] = (int8_t)arg;
-          stg(x.g(ARCLE_PL_GRID), c, gr);
+          x.gs(ARCLE_PL_GRID, c, gr);
         }
         break;
       }
@@ -888,7 +909,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const bool transform = kind != ARCLE_OP_MOVE;
         if (fresh) {  // object.py:67-99
           if (staged != ARCLE_PL_GRID) {
-            x.stage(x.A, x.g(ARCLE_PL_GRID));
+            x.stage_g(x.A, ARCLE_PL_GRID);
             bx::sync();
           }
           for (int c = tid; c < nch; c += NT) {
@@ -906,15 +927,15 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             stg(x.B, c, ob);
             stg(x.C, c, qs);
             if (!transform) {  // Move: the lifted tiles are final
-              stg(x.g(ARCLE_PL_OBJECT), c, ob);
-              stg(x.g(ARCLE_PL_OBJECT_SEL), c, qs);
+              x.gs(ARCLE_PL_OBJECT, c, ob);
+              x.gs(ARCLE_PL_OBJECT_SEL, c, qs);
               // background = where(sel > 0, 0, grid)  :87-88 — this thread's own chunk; place() forms it again from A and S
               Chunk gr = ldg(x.A, c);
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
               for (int k = 0; k < 16; k++)
                 if (sm.b[k] > 0) gr.b[k] = 0;
-              stg(x.g(ARCLE_PL_BACKGROUND), c, gr);
+              x.gs(ARCLE_PL_BACKGROUND, c, gr);
             }
           }
           r[ARCLE_REC_OBJECT_DIM] = (int8_t)oh;
@@ -927,9 +948,9 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         } else {  // :102-107 the stored object continues (the selection is empty: S is all zero)
           if (!staged_obj) {
             if (staged >= 0) bx::sync();  // (a mask selection that turned out empty: every thread is done with the guessed plane)
-            x.stage(x.A, x.g(ARCLE_PL_BACKGROUND));
-            x.stage(x.B, x.g(ARCLE_PL_OBJECT));
-            x.stage(x.C, x.g(ARCLE_PL_OBJECT_SEL));
+            x.stage_g(x.A, ARCLE_PL_BACKGROUND);
+            x.stage_g(x.B, ARCLE_PL_OBJECT);
+            x.stage_g(x.C, ARCLE_PL_OBJECT_SEL);
           }
           bg_in_A = true;
         }
@@ -950,7 +971,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               for (int k = 0; k < 16; k++)
                 if (sm.b[k] > 0) gr.b[k] = 0;
               stg(x.A, c, gr);
-              stg(x.g(ARCLE_PL_BACKGROUND), c, gr);
+              x.gs(ARCLE_PL_BACKGROUND, c, gr);
             }
             const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
@@ -958,7 +979,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               return in ? v : (int8_t)0;
             });
             stg(x.S, c, t);
-            stg(x.g(ARCLE_PL_OBJECT), c, t);
+            x.gs(ARCLE_PL_OBJECT, c, t);
           }
           bg_in_A = true;
           bx::sync();
@@ -969,7 +990,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               return in ? v : (int8_t)0;
             });
             stg(x.B, c, t);
-            stg(x.g(ARCLE_PL_OBJECT_SEL), c, t);
+            x.gs(ARCLE_PL_OBJECT_SEL, c, t);
           }
           O = x.S;
           Q = x.B;
@@ -993,7 +1014,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const int h = x1 - x0 + 1, w = y1 - y0 + 1;
         // (the source plane is in A)
         for (int c = tid; c < nch; c += NT)
-          stg(x.g(ARCLE_PL_CLIP), c, build_chunk(c, W, P, [&](int, int i, int j) {
+          x.gs(ARCLE_PL_CLIP, c, build_chunk(c, W, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
                 const int s = in ? (x0 + i) * W + (y0 + j) : 0;
                 const int8_t sv = x.S[s], av = x.A[s];
@@ -1011,8 +1032,8 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         // (the clip plane is in A)
         const int c_first = (x0 * W) >> 4, c_last = imin(nch - 1, (ex * W) >> 4);
         for (int c = c_first + tid; c <= c_last; c += NT) {
-          const Chunk gr = ldg(x.g(ARCLE_PL_GRID), c);
-          stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int f, int i, int j) {
+          const Chunk gr = x.gl(ARCLE_PL_GRID, c);
+          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int f, int i, int j) {
                 const bool in = i >= x0 && i < ex && j >= y0 && j < ey;
                 const int8_t pv = x.A[in ? (i - x0) * W + (j - y0) : 0];
                 return (in && (arg || pv > 0)) ? pv : gr.b[f & 15];  // :345-348
@@ -1021,18 +1042,18 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         break;
       }
       case ARCLE_OP_COPY_FROM_INPUT: {  // critical.py:28-29
-        for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_GRID), c, ldg(x.g(ARCLE_PL_INPUT), c));
+        for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, x.gl(ARCLE_PL_INPUT, c));
         r[ARCLE_REC_GRID_DIM] = r[ARCLE_REC_INPUT_DIM];
         r[ARCLE_REC_GRID_DIM + 1] = r[ARCLE_REC_INPUT_DIM + 1];
         break;
       }
       case ARCLE_OP_RESET_GRID: {  // critical.py:17
-        for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_GRID), c, zero_chunk());
+        for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, zero_chunk());
         break;
       }
       case ARCLE_OP_RESIZE_GRID: {  // critical.py:39-46
         if (!any_nz) break;
-        for (int c = tid; c < nch; c += NT) stg(x.g(ARCLE_PL_GRID), c, zero_chunk());
+        for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, zero_chunk());
         r[ARCLE_REC_GRID_DIM] = (int8_t)(x1 - x0 + 1);
         r[ARCLE_REC_GRID_DIM + 1] = (int8_t)(y1 - y0 + 1);
         break;
@@ -1041,7 +1062,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         if (!any_nz) break;
         const int h = x1 - x0 + 1, w = y1 - y0 + 1;  // (the grid is in A)
         for (int c = tid; c < nch; c += NT)
-          stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int, int i, int j) {
+          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
                 const int s = in ? (x0 + i) * W + (y0 + j) : 0;
                 const int8_t sv = x.S[s], av = x.A[s];
@@ -1056,8 +1077,8 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         r[ARCLE_REC_GRID_DIM] = (int8_t)ah;
         r[ARCLE_REC_GRID_DIM + 1] = (int8_t)aw;
         for (int c = tid; c < nch; c += NT) {
-          const Chunk gr = ldg(x.g(ARCLE_PL_GRID), c);
-          stg(x.g(ARCLE_PL_GRID), c, build_chunk(c, W, P, [&](int f, int i, int j) { return (i < ah && j < aw) ? gr.b[f & 15] : (int8_t)0; }));
+          const Chunk gr = x.gl(ARCLE_PL_GRID, c);
+          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int f, int i, int j) { return (i < ah && j < aw) ? gr.b[f & 15] : (int8_t)0; }));
         }
         break;
       }
@@ -1116,7 +1137,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       int mine = 0;
       const int lastc = imin(nch, (imax(mh, 0) * W + 15) >> 4);
       for (int c = tid; c < lastc; c += NT) {
-        const Chunk a = ldg(x.g(ARCLE_PL_GRID), c), b = ldg(x.g(ARCLE_PL_ANSWER), c);
+        const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
         int f = 16 * c;
         int i = f / W, j = f - i * W;
 #pragma unroll
@@ -1142,6 +1163,20 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
   }
   const int term = r[ARCLE_REC_TERMINATED] != 0;
   const bool truncated = (flags & ARCLE_STEP_TRUNCATE) && cnt0 >= p.step_limit;
+  if (p.acct) {
+    // byte accounting (arcle_enable_accounting): every 16-byte access of the step the threads counted, + the env's scalars (record in / out,
+    // counters, action, outputs).  "issued" = those bytes; the other figure leaves the row padding out (chunks x 16 x P / PS).  Rows written
+    // by the FLAT_OBS / PACK_OBS epilogue below are not in it (as in the one-wavefront kernels, where the host adds them per launch).
+    if (tid == 0) x.red->sum = 0;
+    bx::sync();
+    if (x.io) bx::lds_add(&x.red->sum, (int)x.io);
+    bx::sync();
+    if (tid == 0) {
+      const uint32_t chunks = (uint32_t)x.red->sum, scal = 2u * ARCLE_REC_BYTES + 16u + 20u + 5u;
+      p.acct[env] += (uint32_t)(((uint64_t)chunks * 16u * (uint32_t)P) / (uint32_t)x.PS) + scal;
+      p.acct[(size_t)p.n_envs + env] += chunks * 16u + scal;
+    }
+  }
   if (tid == 0) {
     stg(p.rec, env, rc);
     p.cnt[2 * (size_t)env] = cnt0;
@@ -1242,7 +1277,7 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
     int src = p.src_env ? p.src_env[env] : env;
     if (src < 0 || src >= p.n_resident) src = 0;  // (the step launch flags the row and skips it)
     rc = ldg(p.res_rec, src);
-    for (int c = x.tid; c < x.nch; c += x.NT) stg(x.g(ARCLE_PL_ANSWER), c, ldg(p.res_answer + (size_t)src * x.PS, c));
+    for (int c = x.tid; c < x.nch; c += x.NT) x.gs(ARCLE_PL_ANSWER, c, ldg(p.res_answer + (size_t)src * x.PS, c));
     if (x.tid == 0) p.cnt[2 * (size_t)env] = p.cnt[2 * (size_t)env + 1] = 0;
   }
   bx::sync();
@@ -1258,7 +1293,8 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
           if (f0 + k < x.P) v.b[k] = src[f0 + k];
-        stg(x.g(sg.plane), c, v);
+        x.io++;  // (the row bytes read)
+        x.gs(sg.plane, c, v);
       }
     }
   }

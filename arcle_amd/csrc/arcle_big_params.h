@@ -56,6 +56,7 @@ struct BigParams {
   uint32_t aug_flags;
   const uint8_t* aug_k;     // uint8 [n_envs]: np.rot90 count
   const uint8_t* aug_perm;  // uint8 [n_envs][16]: perm[c] for colour c < 10
+  uint32_t* acct;  // arcle_enable_accounting: uint32 [2][n_envs] — bytes without the row padding / bytes of every access issued, per env
   int32_t* dense;  // ARCLE_STEP_DENSE: int32 [n_envs][2] = (cells of the grid that match the answer inside the common rectangle, total cells)
 };
 

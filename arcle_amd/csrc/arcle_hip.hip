@@ -1193,6 +1193,8 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
     q.term = term;
     q.flags = flags;
     q.dense = e->base.dense;
+    q.acct = e->d_acct;
+    if (e->d_acct) e->acct_steps += (uint64_t)q.n_envs;
     if (flags & ARCLE_STEP_FLAT_OBS) {
       if (!e->flat_out) return fail(e, ARCLE_ERR_CONFIG, "ARCLE_STEP_FLAT_OBS without arcle_set_flat_output");
       q.flat_out = e->flat_out;
@@ -2004,7 +2006,6 @@ extern "C" int arcle_get_status(arcle_env* e, uint32_t* status, int clear, void*
 
 extern "C" int arcle_enable_accounting(arcle_env* e, int on) {
   if (!e) return ARCLE_ERR_ARG;
-  if (on) BIG_REFUSE(e, "byte accounting");
   DeviceGuard guard(e->device);
   if (on && !e->d_acct) {
     HIP_TRY(e, hipMalloc((void**)&e->d_acct, (size_t)e->cfg.n_envs * 64));

@@ -70,7 +70,7 @@ def _ptr(t):
 class EnvBatch:
     """n_envs envs of one kind on one GPU."""
     # what a batch of more than 1024 cells per plane (`self.big`) does not offer — the library refuses these calls with ARCLE_ERR_CONFIG
-    BIG_UNSUPPORTED = ("byte accounting", "autotune (one launch plan: returns no candidates)")
+    BIG_UNSUPPORTED = ("autotune (one launch plan: returns no candidates)",)
 
     def __init__(self, n_envs, H, W, max_trial=-1, kind="o2arc", device=None, plane_stride=None):
         check_grid_size(H, W)

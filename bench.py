@@ -929,12 +929,12 @@ def big_grid_case(dev, H, W, n, K=24, ops=None):
     def enqueue(sh):
         for i in range(K):
             batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), FL, sh)
+    alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
     sec, _ = graph_time(dev, enqueue, K)
-    alg = _big_model_bytes(oo, batch.PS)
-    rl = {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK, "traffic": None,
-          "kernel": "arcle_big_step_kernel", "avg_launch_us": sec * 1e6, "algorithmic_bytes_per_launch": alg,
-          "note": "bytes MODELLED per op kind (planes read + written x plane stride; the workgroup-per-env kernels carry no byte counter); "
-                  "state = 8 planes x envs x PS"}
+    rl = roofline_block("arcle_big_step_kernel", sec, alg, issued, n, PS=batch.PS, planes=len(batch.planes),
+                        note="bytes counted by the kernel in this run (every 16-byte access a thread issues; `algorithmic` = the same without "
+                             "the row padding); bound: a thread's per-chunk instruction chain x the op's dependent phases, not HBM")
+    rl["modelled_bytes_per_launch"] = _big_model_bytes(oo, batch.PS)  # (the per-op-kind model the first measurements of this path used)
     return {"workload": f"O2ARCv2Env {H}x{W}, {n} envs, C3 action mix (max_grid_size beyond one wavefront: one workgroup per env)", "envs": n,
             "plane_stride": batch.PS, "us_per_step_batch": sec * 1e6, "value": n / sec, "unit": "env-steps/s", "roofline": rl}
 

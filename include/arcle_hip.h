@@ -210,7 +210,8 @@ typedef struct arcle_env arcle_env; /* opaque handle */
  *               _set_state_rows, arcle_pack_obs, planes, status; step flags AUTORESET, ELIDE_SELECTED, TRUNCATE, RESAMPLE, DENSE (the pair is
  *               computed from the planes every step: no cache), CONTINUE_RULE, RESET_ON_SUBMIT, FLAT_OBS (tail and completion signal
  *               included), PACK_OBS; ROWS_INCREMENTAL is accepted and rewrites the rows in full (identical bytes)
- *   refused     (ARCLE_ERR_CONFIG, arcle_last_error names the reason) arcle_enable_accounting (these kernels carry no byte counters)
+ *   accounting  arcle_enable_accounting counts every 16-byte access the threads issue (planes, table entries, mask chunks, rows in) + the
+ *               env's scalars as `issued`; the `bytes` figure is the same without the row padding (x H*W / plane_stride)
  *   no-ops      arcle_set_dispatch_order, arcle_hint_next_ops, arcle_autotune (returns 0 candidates: one launch plan), arcle_launch_info
  *               reports {0, 0, waves per workgroup, 0}
  * Action arrays and row buffers may be device or pinned host memory as everywhere else. */

@@ -438,7 +438,7 @@ class _BigParams(ctypes.Structure):  # mirror of arcle_big::BigParams (arcle_amd
                 ("cur_task", ctypes.c_void_p), ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p),
                 ("n_problems", ctypes.c_int32), ("rows_in", ctypes.c_void_p), ("rows_in_stride", ctypes.c_int32),
                 ("n_resident", ctypes.c_int32), ("src_env", ctypes.c_void_p), ("res_answer", ctypes.c_void_p), ("res_rec", ctypes.c_void_p),
-                ("aug_flags", ctypes.c_uint32), ("aug_k", ctypes.c_void_p), ("aug_perm", ctypes.c_void_p), ("dense", ctypes.c_void_p)]
+                ("aug_flags", ctypes.c_uint32), ("aug_k", ctypes.c_void_p), ("aug_perm", ctypes.c_void_p), ("acct", ctypes.c_void_p), ("dense", ctypes.c_void_p)]
 
 
 _big_emu = None
@@ -474,6 +474,8 @@ class BigEmuBackend(EmuBackend):
         self._ops_arr = np.zeros(65, np.uint32)
         self._ops_arr[:len(self.ops)] = self.ops
         p.d_ops = self._ops_arr.ctypes.data
+        if getattr(self, "count_bytes", False):
+            p.acct = self.acct.ctypes.data  # uint32 [2][N]: bytes without the row padding / bytes issued
         return p
 
     def set_dense_output(self):

@@ -101,3 +101,20 @@ def test_big_emulator_record_and_bit_packed_forms(H, W):
     be = B.BigEmuBackend(5, H, W, 3, "o2arc", O.o2arc_ops())
     m = (rng.random((5, H, W)) < 0.3).astype(np.int8) * rng.integers(-3, 4, (5, H, W)).astype(np.int8)
     assert np.array_equal(be.pack_mask_bits(m), B.pack_bits(m))
+
+
+def test_big_emulator_byte_accounting():
+    """arcle_enable_accounting on the big path: every 16-byte access a thread issues is counted.  CopyFromInput on an inactive env with the
+    zero-fill of `selected` elided reads the input plane and writes the grid plane: 2 planes + the env's scalars."""
+    H, W, N = 40, 40, 3
+    be = B.BigEmuBackend(N, H, W, 3, "o2arc", O.o2arc_ops())
+    inp = np.random.default_rng(0).integers(0, 10, (N, H, W)).astype(np.int8)
+    dims = np.full((N, 2), H, np.int8)
+    be.set_tasks(inp, dims, inp, dims)
+    be.reset()
+    be.count_bytes = True
+    be.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 31, np.int32), 2)
+    scal = 2 * 16 + 16 + 20 + 5
+    assert be.acct[N:].tolist() == [2 * be.PS + scal] * N and be.acct[:N].tolist() == [2 * H * W + scal] * N
+    be.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 3, np.int32), 2)  # Color on a one-cell selection: 1 grid chunk read + written
+    assert be.acct[N:].tolist() == [2 * be.PS + 32 + 2 * scal] * N

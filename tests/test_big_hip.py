@@ -97,6 +97,22 @@ def test_hip_big_transition_rows():
     assert not errs, "\n".join(errs[:10])
 
 
+def test_hip_big_byte_accounting():
+    """arcle_enable_accounting on a big handle: CopyFromInput of inactive envs (zero-fill of `selected` elided) moves two planes per env"""
+    H, W, N = 40, 40, 64
+    be = B.HipBackend(N, H, W, 3, "o2arc", O.o2arc_ops())
+    inp = np.random.default_rng(0).integers(0, 10, (N, H, W)).astype(np.int8)
+    dims = np.full((N, 2), H, np.int8)
+    be.set_tasks(inp, dims, inp, dims)
+    be.reset()
+    be.b.enable_accounting(True)
+    be.step("bbox", np.zeros((N, 4), np.int32), np.full(N, 31, np.int32), 2)
+    alg, issued, steps = be.b.accounting_ex(clear=True)
+    scal = 2 * 16 + 16 + 20 + 5
+    assert (alg, issued, steps) == (N * (2 * H * W + scal), N * (2 * be.b.PS + scal), N)
+    be.b.enable_accounting(False)
+
+
 def test_hip_big_task_augmentation():
     C.aug_case(B.HipBackend)
 

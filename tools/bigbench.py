@@ -30,8 +30,10 @@ def main():
                 lo, hi = (int(v) for v in a.ops.split("-"))
                 ops = (lo, hi)
             leg = BN.big_grid_case(dev, H, W, n, a.steps, ops=ops)
-            print(f"{H}x{W} envs {n}{' ops ' + a.ops if a.ops else ''}: {leg['us_per_step_batch']:.1f} us per step = {leg['value'] / 1e6:.1f} M env-steps/s; modelled plane traffic "
-                  f"{leg['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch -> {leg['roofline']['frac']:.3f} of 8 TB/s", flush=True)
+            rl = leg["roofline"]
+            print(f"{H}x{W} envs {n}{' ops ' + a.ops if a.ops else ''}: {leg['us_per_step_batch']:.1f} us per step = {leg['value'] / 1e6:.1f} M env-steps/s; kernel-counted "
+                  f"{rl['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch ({rl['traffic'] / 1e6:.1f} issued) -> {rl['frac']:.3f} of 8 TB/s "
+                  f"({rl['frac_by_traffic']:.3f} by issued bytes; modelled {rl['modelled_bytes_per_launch'] / 1e6:.1f} MB)", flush=True)
 
 
 if __name__ == "__main__":
