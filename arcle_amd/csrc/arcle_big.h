@@ -25,8 +25,8 @@
 
 #include "arcle_big_params.h"
 
-#if !defined(ARCLE_BIG_DEV)
-#error "include through arcle_big.hip (or the test emulator), which defines ARCLE_BIG_DEV and namespace bx"
+#if !defined(ARCLE_BIG_DEV) || !defined(ARCLE_BIG_ROWS)
+#error "include through arcle_big.hip (or the test emulator), which defines ARCLE_BIG_DEV, ARCLE_BIG_ROWS and namespace bx"
 #endif
 
 namespace arcle_big {
@@ -150,12 +150,15 @@ ARCLE_BIG_DEV B128 spread(B128 E, B128 S) {
   return r;
 }
 
+struct Layout;
 struct Ctx {
   const BigParams& p;
   int env, tid, NT, H, W, P, PS, nch;
   int8_t *S, *A, *B, *C;
   Red* red;
   uint64_t *Eb, *Fb;
+  int8_t* sc;   // 32 bytes of LDS: the scalar block of a row (record, reward, terminated) — indexed per byte, so not in registers
+  Layout* lay;  // the row layout being written / read, in LDS for the same reason (dynamic indexing of a local array means scratch memory)
   size_t po;
   mutable uint32_t io;  // 16-byte global-memory accesses this thread issued (plane chunks, table chunks, mask chunks, row units): the
                         // byte accounting of arcle_enable_accounting — a register increment per access, summed per env when asked for
@@ -168,6 +171,8 @@ struct Ctx {
     red = reinterpret_cast<Red*>(lds + 4 * PS);
     Eb = reinterpret_cast<uint64_t*>(lds + 4 * PS + 64);
     Fb = Eb + 256;
+    sc = lds + 4 * PS + 64 + 4096;
+    lay = reinterpret_cast<Layout*>(sc + 32);
     po = (size_t)env * (size_t)PS;
   }
   ARCLE_BIG_DEV int8_t* g(int pl) const { return p.plane[pl] + po; }
@@ -332,8 +337,7 @@ struct Layout {
     n++;
   }
 };
-ARCLE_BIG_DEV Layout flat_layout(const BigParams& p, int filtered) {
-  Layout L;
+ARCLE_BIG_DEV void flat_layout(const BigParams& p, int filtered, Layout& L) {  // (one thread builds it in LDS; a barrier follows)
   L.n = 0;
   L.len = 0;
   const bool o2 = p.plane[ARCLE_PL_SELECTED] != nullptr, clip = p.plane[ARCLE_PL_CLIP] != nullptr;
@@ -348,7 +352,7 @@ ARCLE_BIG_DEV Layout flat_layout(const BigParams& p, int filtered) {
     L.add_sc(ARCLE_REC_OBJECT_DIM, 2);
     L.add_sc(ARCLE_REC_OBJECT_POS, 2);
     L.add_sc(ARCLE_REC_TRIALS, 1);
-    return L;
+    return;
   }
   if (clip) {
     L.add_plane(ARCLE_PL_CLIP, P);
@@ -370,17 +374,14 @@ ARCLE_BIG_DEV Layout flat_layout(const BigParams& p, int filtered) {
   }
   L.add_sc(ARCLE_REC_TERMINATED, 1);
   L.add_sc(ARCLE_REC_TRIALS, 1);
-  return L;
 }
-ARCLE_BIG_DEV Layout packed_layout(const BigParams& p) {
-  Layout L;
+ARCLE_BIG_DEV void packed_layout(const BigParams& p, Layout& L) {
   L.n = 0;
   L.len = 0;
   L.add_plane(ARCLE_PL_GRID, p.P);
   L.add_sc(ARCLE_REC_GRID_DIM, 2);
   L.add_sc(16, 4);
   L.add_sc(20, 1);
-  return L;
 }
 
 // writes bytes [0, limit) of the row at `dst` (16-byte aligned, limit a multiple of 16): the layout's bytes, zeros behind them.  A plane
@@ -422,24 +423,30 @@ ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, in
 ARCLE_BIG_DEV void emit_rows(const Ctx& x, const int8_t* r, uint32_t flags, int reward, int term, int cnt0, int cnt1, bool truncated,
                              uint32_t st) {
   const BigParams& p = x.p;
-  int8_t sc[24];
+  // (entered behind a barrier: nobody is still reading the LDS tail area)
+  int8_t* const sc = x.sc;
+  if (x.tid == 0) {
 #pragma unroll
-  for (int k = 0; k < 16; k++) sc[k] = r[k];
-  sc[16] = (int8_t)(reward & 0xff);
-  sc[17] = (int8_t)((reward >> 8) & 0xff);
-  sc[18] = (int8_t)((reward >> 16) & 0xff);
-  sc[19] = (int8_t)((reward >> 24) & 0xff);
-  sc[20] = (int8_t)term;
-  sc[21] = sc[22] = sc[23] = 0;
+    for (int k = 0; k < 16; k++) sc[k] = r[k];
+    sc[16] = (int8_t)(reward & 0xff);
+    sc[17] = (int8_t)((reward >> 8) & 0xff);
+    sc[18] = (int8_t)((reward >> 16) & 0xff);
+    sc[19] = (int8_t)((reward >> 24) & 0xff);
+    sc[20] = (int8_t)term;
+    sc[21] = sc[22] = sc[23] = 0;
+  }
   if ((flags & ARCLE_STEP_PACK_OBS) && p.pack_out) {
-    const Layout L = packed_layout(p);
+    if (x.tid == 0) packed_layout(p, *x.lay);
+    bx::sync();
     const int stride = packed_stride(p.P);
-    write_row(x, L, sc, reinterpret_cast<int8_t*>(p.pack_out) + (size_t)x.env * stride, stride);
+    write_row(x, *x.lay, sc, reinterpret_cast<int8_t*>(p.pack_out) + (size_t)x.env * stride, stride);
+    bx::sync();
   }
   if ((flags & ARCLE_STEP_FLAT_OBS) && p.flat_out) {
-    const Layout L = flat_layout(p, p.flat_filter);
+    if (x.tid == 0) flat_layout(p, p.flat_filter, *x.lay);
+    bx::sync();
     int8_t* const row = p.flat_out + (size_t)x.env * p.flat_stride;
-    write_row(x, L, sc, row, p.flat_stride - (p.flat_tail ? 16 : 0));
+    write_row(x, *x.lay, sc, row, p.flat_stride - (p.flat_tail ? 16 : 0));
     if (p.flat_tail) {
       // int32 reward | int32 action_steps | int32 submit_count | uint8 terminated | uint8 truncated | uint8 status | seq
       // (arcle_set_flat_output_ex / arcle_set_flat_seq: the last word behind a system-scope release, after every row store of the
@@ -495,10 +502,13 @@ ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int 
   // changed anything evaluated every row against boards that were constant throughout: the fixpoint.  Flag slots rotate over three
   // passes: slot (k + 1) % 3 is cleared during pass k — last read at the end of pass k - 2, behind a barrier every thread has passed.
   volatile uint64_t* const Fv = reinterpret_cast<volatile uint64_t*>(F);
-  B128 mine[MAX_ROWS_PER_THREAD], elig[MAX_ROWS_PER_THREAD];
-  {
-    int k = 0;
-    for (int i = x.tid; i < H; i += x.NT, k++) {
+  // (a thread's rows are tid, tid + NT, ...: ARCLE_BIG_ROWS of them at most — 1 on the GPU, where a workgroup has at least 128 threads — in
+  // loops of constant trip count, so that the boards stay in registers)
+  B128 mine[ARCLE_BIG_ROWS], elig[ARCLE_BIG_ROWS];
+#pragma unroll
+  for (int k = 0; k < ARCLE_BIG_ROWS; k++) {
+    const int i = x.tid + k * x.NT;
+    if (i < H) {
       mine[k] = F[i];
       elig[k] = E[i];
     }
@@ -506,8 +516,10 @@ ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int 
   for (int pass = 0;; pass++) {
     bool changed = false;
     for (int it = 0; it < FILL_INNER; it++) {
-      int k = 0;
-      for (int i = x.tid; i < H; i += x.NT, k++) {
+#pragma unroll
+      for (int k = 0; k < ARCLE_BIG_ROWS; k++) {
+        const int i = x.tid + k * x.NT;
+        if (i >= H) continue;
         const B128 cur = mine[k], e = elig[k];
         B128 s = cur;
         if (i > 0) {
@@ -1270,7 +1282,6 @@ ARCLE_BIG_DEV void rows_env(const BigParams& p, int env, int mode, int8_t* lds) 
 ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
   if (p.rmask && !p.rmask[env]) return;
   const Ctx x(p, env, lds);
-  const Layout L = flat_layout(p, 0);
   const int8_t* const row = p.rows_in + (size_t)env * p.rows_in_stride;
   Chunk rc = ldg(p.rec, env);
   if (p.res_rec) {  // a scratch env of arcle_transition_rows: the task side comes from a resident env, the counters start at zero
@@ -1280,11 +1291,17 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
     for (int c = x.tid; c < x.nch; c += x.NT) x.gs(ARCLE_PL_ANSWER, c, ldg(p.res_answer + (size_t)src * x.PS, c));
     if (x.tid == 0) p.cnt[2 * (size_t)env] = p.cnt[2 * (size_t)env + 1] = 0;
   }
+  if (x.tid == 0) {
+    flat_layout(p, 0, *x.lay);
+    stg(x.sc, 0, rc);  // the record; the row's scalar segments overwrite their fields below
+  }
   bx::sync();
+  const Layout& L = *x.lay;
   for (int s = 0; s < L.n; s++) {
-    const Seg& sg = L.s[s];
+    const Seg sg = L.s[s];
     if (sg.plane < 0) {
-      for (int k = 0; k < sg.len; k++) rc.b[sg.soff + k] = row[sg.start + k];
+      if (x.tid == 0)
+        for (int k = 0; k < sg.len; k++) x.sc[sg.soff + k] = row[sg.start + k];
     } else {
       const int8_t* const src = row + sg.start;
       for (int c = x.tid; c < x.nch; c += x.NT) {
@@ -1298,7 +1315,7 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
       }
     }
   }
-  if (x.tid == 0) stg(p.rec, env, rc);
+  if (x.tid == 0) stg(p.rec, env, ldg(x.sc, 0));
 }
 
 }  // namespace arcle_big

@@ -8,6 +8,7 @@
 
 #define ARCLE_BIG_DEV __device__ __forceinline__
 #define ARCLE_BIG_HD __host__ __device__
+#define ARCLE_BIG_ROWS 1  // board rows per thread of the flood fill: a workgroup has at least 128 threads (threads_for), a plane at most 127 rows
 
 namespace bx {
 ARCLE_BIG_DEV int tid() { return (int)threadIdx.x; }
@@ -73,12 +74,12 @@ static unsigned threads_for(int PS) {
   if (forced < 0) {
     const char* s = getenv("ARCLE_BIG_THREADS");
     const int v = s ? atoi(s) : 0;
-    forced = (v >= 64 && v <= BIG_THREADS && (v & 63) == 0) ? v : 0;
+    forced = (v >= 128 && v <= BIG_THREADS && (v & 63) == 0) ? v : 0;
   }
   if (forced) return (unsigned)forced;
   const int nch = PS >> 4;
   const int t = (nch + 63) & ~63;
-  return (unsigned)(t < 64 ? 64 : t > 512 ? 512 : t);  // (127 x 127, 1016 chunks: 512 threads 36.7 us, 1024 threads 41.5, 256 threads 51.0 per 1024 envs)
+  return (unsigned)(t < 128 ? 128 : t > 512 ? 512 : t);  // (127 x 127, 1016 chunks: 512 threads 36.7 us, 1024 threads 41.5, 256 threads 51.0 per 1024 envs)
 }
 
 int workgroup_threads(int PS) { return (int)threads_for(PS); }

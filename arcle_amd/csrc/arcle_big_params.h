@@ -12,7 +12,7 @@
 namespace arcle_big {
 
 enum { ING_MASK = 0, ING_BBOX = 1, ING_POINT = 2, ING_BBOX5 = 3, ING_BITS = 4 };  // (= enum arcle_ingress)
-enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 32, MAX_ROWS_PER_THREAD = 4, FILL_INNER = 8 };
+enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 32, FILL_INNER = 8 };
 
 struct BigParams {
   int8_t* plane[ARCLE_N_PLANES];
@@ -60,8 +60,8 @@ struct BigParams {
   int32_t* dense;  // ARCLE_STEP_DENSE: int32 [n_envs][2] = (cells of the grid that match the answer inside the common rectangle, total cells)
 };
 
-// bytes of LDS one workgroup needs: four staging planes + the reduction block + two row boards of 128 x 128 bits
-ARCLE_BIG_HD inline int lds_bytes(int PS) { return 4 * PS + 64 + 2 * 128 * 16; }  // 69 184 at 127 x 127 (gfx950: 160 KB per workgroup)
+// bytes of LDS one workgroup needs: four staging planes + the reduction block + two row boards of 128 x 128 bits + a row's scalars and layout
+ARCLE_BIG_HD inline int lds_bytes(int PS) { return 4 * PS + 64 + 2 * 128 * 16 + 256; }  // 69 440 at 127 x 127 (gfx950: 160 KB per workgroup)
 
 ARCLE_BIG_HD inline int flat_len(int P, bool o2, bool clip, int filtered) {
   if (filtered) return 3 * P + 10;

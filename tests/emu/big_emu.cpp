@@ -11,6 +11,7 @@
 
 #define ARCLE_BIG_DEV inline
 #define ARCLE_BIG_HD
+#define ARCLE_BIG_ROWS 4  // board rows per thread of the flood fill: 127 rows over the 32 threads of the emulated workgroup
 
 namespace bx {
 static thread_local int t_tid;

@@ -20,8 +20,21 @@ def main():
     ap.add_argument("--envs", default="1024,4096")
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--ops", default="", help="restrict the op indices drawn, e.g. 10-19 (FloodFill) or 20-23 (Move); default: all 35")
+    ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replays (PMC passes: rocprofv3 counts no graph-launched kernels)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.eager:
+        for size in a.sizes.split(","):
+            H, W = (int(v) for v in size.split("x"))
+            for n in (int(v) for v in a.envs.split(",")):
+                batch = BN.make_batch(dev, n, 1000, "o2arc", H, W)
+                bb, oo = BN.make_actions(a.steps, n, 2000, H, W)
+                bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
+                for i in range(a.steps):
+                    batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), batch.elide_flag | 1, torch.cuda.current_stream(dev).cuda_stream)
+                torch.cuda.synchronize()
+                print(f"{H}x{W} envs {n}: {a.steps} eager steps", flush=True)
+        return
     for size in a.sizes.split(","):
         H, W = (int(v) for v in size.split("x"))
         for n in (int(v) for v in a.envs.split(",")):
