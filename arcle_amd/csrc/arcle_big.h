@@ -3,10 +3,10 @@
 // (/root/reference/arcle/envs/base.py:37-49); ARC itself never exceeds 30 x 30, so this is the completeness path, not the headline:
 // the 30 x 30 batch keeps its one-wavefront-per-env kernels (arcle_wave.h).
 //
-// Execution model — ONE WORKGROUP per env (256 threads = 4 wavefronts on gfx950):
+// Execution model — ONE WORKGROUP per env (128 … 512 threads: about one 16-byte chunk of a plane per thread):
 //   * a plane is PS = H*W rounded up to 128 bytes; thread t owns the 16-byte chunks t, t + NT, t + 2 NT ... of it: every global plane
 //     access is one aligned 16 B load / store per thread, consecutive threads on consecutive chunks (fully coalesced);
-//   * the selection and up to three planes are staged in the workgroup's LDS (4 x PS bytes, dynamic: 6.5 KB at 40 x 40, 64 KB at
+//   * the selection and up to three planes are staged in the workgroup's LDS (4 x PS bytes + 4.4 KB, dynamic: 11 KB at 40 x 40, 69 KB at
 //     127 x 127), geometric ops (object lift / place, Rotate / Flip, Copy / Paste / Crop) gather single cells from those tiles and write
 //     whole chunks back;
 //   * reductions (any / sum / arg-max / bounding box of the selection, grid == answer) are LDS atomics + a workgroup barrier;

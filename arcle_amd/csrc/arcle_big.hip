@@ -1,4 +1,4 @@
-// arcle_big.hip — gfx950 kernels for grids beyond ARCLE_MAX_CELLS (H * W > 1024, H, W <= 127): one WORKGROUP of 256 threads per env.
+// arcle_big.hip — gfx950 kernels for grids beyond ARCLE_MAX_CELLS (H * W > 1024, H, W <= 127): one WORKGROUP of 128 … 512 threads per env.
 // The bodies live in arcle_big.h (also compiled by the test emulator); this file supplies the workgroup primitives (namespace bx),
 // the __global__ wrappers and the host-side launchers arcle_hip.hip routes big handles to.  Second translation unit of
 // libarcle_hip.so (arcle_amd/_lib.py compiles both and links them).
@@ -67,8 +67,8 @@ static int allow_lds(K kernel, int bytes) {
 
 // Threads per workgroup: a thread owns the chunks t, t + NT, ... of a plane.  Measured on MI355X (profiles/round5_experiments.txt §15): the
 // kernel is bound by the per-chunk instruction chain of a thread (a chunk is 16 cells built one by one), not by barriers — one chunk per
-// thread is fastest at every size tried, so: the chunk count rounded up to whole wavefronts (128 threads at 40 x 40, 256 at 64 x 64,
-// 1024 at 127 x 127).  ARCLE_BIG_THREADS overrides (tuning runs).
+// thread is fastest up to 512 threads, so: the chunk count rounded up to whole wavefronts, at least 128 (the flood fill gives every board
+// row its own thread) and at most 512 (128 threads at 40 x 40, 256 at 64 x 64, 512 at 127 x 127).  ARCLE_BIG_THREADS overrides (tuning runs).
 static unsigned threads_for(int PS) {
   static int forced = -1;
   if (forced < 0) {
