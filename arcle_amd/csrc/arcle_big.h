@@ -612,7 +612,8 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
   } else if (p.ingress == ING_BBOX5) {
     for (int k = 0; k < 5; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[5 * (size_t)env + k];
   }
-  opi = p.ingress == ING_BBOX5 ? pay[4] : p.op[env];
+  // (workgroup-uniform by construction; telling the compiler so turns the dependent op-table read into a scalar load)
+  opi = bx::uniform(p.ingress == ING_BBOX5 ? pay[4] : p.op[env]);
   if (tid == 0) {
     Red* q = x.red;
     q->any_nz = q->any_pos = q->sum = 0;

@@ -26,6 +26,7 @@ ARCLE_BIG_DEV void lds_max(int32_t* a, int v) { atomicMax(a, v); }
 ARCLE_BIG_DEV void lds_umax(uint32_t* a, uint32_t v) { atomicMax(a, v); }
 ARCLE_BIG_DEV void status_or(uint32_t* g, uint32_t v) { atomicOr(g, v); }
 ARCLE_BIG_DEV uint64_t brev64(uint64_t x) { return __brevll(x); }
+ARCLE_BIG_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }  // a value every lane holds alike, moved to a scalar register
 ARCLE_BIG_DEV void release_store_system(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }  // namespace bx
 

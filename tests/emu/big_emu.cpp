@@ -46,6 +46,7 @@ inline uint64_t brev64(uint64_t x) {
   return __builtin_bswap64(x);
 }
 inline void release_store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+inline int uniform(int v) { return v; }
 }  // namespace bx
 
 #include "../../arcle_amd/csrc/arcle_big.h"
