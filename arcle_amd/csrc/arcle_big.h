@@ -882,12 +882,15 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       }
     }
 
-    // ---- the wrappers' plane writes ----
-    if (oflags & ARCLE_OPF_KEEP_SEL) {
-      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, ldg(x.S, c));
-    } else if ((oflags & ARCLE_OPF_RESET_SEL) && !((flags & ARCLE_STEP_ELIDE_SELECTED) && active_before == 0)) {
-      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, zero_chunk());
-    }
+    // ---- the wrappers' plane writes: reset_sel / keep_sel set `selected` BEFORE the wrapped op runs and an object op that places its
+    // object overwrites it — so the plane is written once, behind the op, with whichever value is final (1 = zeros, 2 = the selection;
+    // place() clears the request).  No op below stores a plane ahead of its last barrier (a barrier also waits for the stores issued before
+    // it): gathers go to LDS first, the stores come at the end — neutral in time on MI355X (profiles/round5_experiments.txt §19), kept for
+    // the single write of `selected`. ----
+    int sel_pending = 0;
+    if (oflags & ARCLE_OPF_KEEP_SEL) sel_pending = 2;
+    else if ((oflags & ARCLE_OPF_RESET_SEL) && !((flags & ARCLE_STEP_ELIDE_SELECTED) && active_before == 0)) sel_pending = 1;
+    // (the only ops that recycle the S tile — Rotate / Flip that proceed — end in place(): a pending keep_sel never needs S after them)
 
     int eq = -1;  // grid == answer, evaluated at most once
     bool grid_moved = true;  // (conservative: every op below that stores the grid plane ends with a barrier before the compare)
@@ -939,17 +942,6 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             });
             stg(x.B, c, ob);
             stg(x.C, c, qs);
-            if (!transform) {  // Move: the lifted tiles are final
-              x.gs(ARCLE_PL_OBJECT, c, ob);
-              x.gs(ARCLE_PL_OBJECT_SEL, c, qs);
-              // background = where(sel > 0, 0, grid)  :87-88 — this thread's own chunk; place() forms it again from A and S
-              Chunk gr = ldg(x.A, c);
-              const Chunk sm = ldg(x.S, c);
-#pragma unroll
-              for (int k = 0; k < 16; k++)
-                if (sm.b[k] > 0) gr.b[k] = 0;
-              x.gs(ARCLE_PL_BACKGROUND, c, gr);
-            }
           }
           r[ARCLE_REC_OBJECT_DIM] = (int8_t)oh;
           r[ARCLE_REC_OBJECT_DIM + 1] = (int8_t)ow;
@@ -973,6 +965,18 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           const int dy = (arg == 2) ? 1 : (arg == 3) ? -1 : 0;
           r[ARCLE_REC_OBJECT_POS] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS] + dx);  // :238, int8 wrap
           r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS + 1] + dy);
+          if (fresh) {  // the lifted tiles and the background go out now, behind the last barrier (this thread's own chunks)
+            for (int c = tid; c < nch; c += NT) {
+              x.gs(ARCLE_PL_OBJECT, c, ldg(x.B, c));
+              x.gs(ARCLE_PL_OBJECT_SEL, c, ldg(x.C, c));
+              Chunk gr = ldg(x.A, c);  // background = where(sel > 0, 0, grid)  :87-88; place() forms it again from A and S
+              const Chunk sm = ldg(x.S, c);
+#pragma unroll
+              for (int k = 0; k < 16; k++)
+                if (sm.b[k] > 0) gr.b[k] = 0;
+              x.gs(ARCLE_PL_BACKGROUND, c, gr);
+            }
+          }
         } else {
           // dst[:nh,:nw] = T(src[:h,:w]), rest 0 (_pad_assign, object.py:43-47): object B -> S, then object_sel C -> B.  A thread
           // overwrites S only at its OWN chunks, after it has formed the background of those chunks from them (fresh selections).
@@ -984,7 +988,6 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               for (int k = 0; k < 16; k++)
                 if (sm.b[k] > 0) gr.b[k] = 0;
               stg(x.A, c, gr);
-              x.gs(ARCLE_PL_BACKGROUND, c, gr);
             }
             const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
@@ -992,7 +995,6 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               return in ? v : (int8_t)0;
             });
             stg(x.S, c, t);
-            x.gs(ARCLE_PL_OBJECT, c, t);
           }
           bg_in_A = true;
           bx::sync();
@@ -1003,7 +1005,6 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               return in ? v : (int8_t)0;
             });
             stg(x.B, c, t);
-            x.gs(ARCLE_PL_OBJECT_SEL, c, t);
           }
           O = x.S;
           Q = x.B;
@@ -1015,7 +1016,13 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             r[ARCLE_REC_PARITY] = (int8_t)npar;
           }
           bx::sync();
+          for (int c = tid; c < nch; c += NT) {  // the transformed tiles (and a fresh background) go out behind the last barrier
+            if (fresh) x.gs(ARCLE_PL_BACKGROUND, c, ldg(x.A, c));
+            x.gs(ARCLE_PL_OBJECT, c, ldg(x.S, c));
+            x.gs(ARCLE_PL_OBJECT_SEL, c, ldg(x.B, c));
+          }
         }
+        sel_pending = 0;  // (place() writes the whole `selected` plane)
         place(x, r, x.A, bg_in_A ? nullptr : x.S, O, Q);
         break;
       }
@@ -1119,6 +1126,11 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       }
       default:  // ARCLE_OP_HOST: a device no-op, the step is counted
         break;
+    }
+    if (sel_pending == 2) {
+      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, ldg(x.S, c));
+    } else if (sel_pending == 1) {
+      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, zero_chunk());
     }
 
     // reward(): only the LAST op of the table can be rewarded (o2arcenv.py:121-128)
