@@ -559,6 +559,68 @@ ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int 
   }
 }
 
+// ---- whole-chunk (SWAR) forms of the gathers, for W >= 16 (a chunk then spans at most two plane rows) ------------------------------------
+// The object lift / place, Copy, Paste and Crop are FLAT SHIFTS of a plane: destination cell f reads source cell f + delta for one delta per
+// op (rows and columns move together in the row-major layout), valid wherever the destination lies inside the op's rectangle.  So a
+// chunk's 16 source bytes are 16 CONSECUTIVE bytes of the LDS tile — five aligned dword reads and four funnel shifts — and the rectangle
+// becomes a byte mask built from (at most) two column runs: ~130 vector instructions per chunk instead of ~25 per cell
+// (profiles/round5_experiments.txt §19-20).  W < 16 keeps the per-cell form.
+ARCLE_BIG_DEV Chunk shifted16(const int8_t* tile, int off, int PS) {  // bytes [off, off + 16) of the tile; bytes outside [0, PS) are unspecified
+  const uint32_t* const t32 = reinterpret_cast<const uint32_t*>(tile);
+  const int d = off >> 2, sh = 8 * (off & 3), last = (PS >> 2) - 1;
+  uint32_t w[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) w[q] = t32[imin(imax(d + q, 0), last)];
+  Chunk o;
+#pragma unroll
+  for (int q = 0; q < 4; q++) o.w[q] = (uint32_t)((((uint64_t)w[q + 1] << 32) | (uint64_t)w[q]) >> sh);
+  return o;
+}
+ARCLE_BIG_DEV uint64_t low_bytes(int n) { return n >= 8 ? ~0ull : (1ull << (8 * n)) - 1ull; }  // bytes [0, n) of a 64-bit word set, 0 <= n
+ARCLE_BIG_DEV Chunk range_mask16(int lo, int hi) {  // bytes [lo, hi) = 0xff (0 <= lo, hi <= 16; empty when hi <= lo)
+  Chunk o = zero_chunk();
+  if (hi > lo) {
+    const uint64_t a = low_bytes(hi) & ~low_bytes(lo);
+    const uint64_t b = low_bytes(imax(hi - 8, 0)) & ~low_bytes(imax(lo - 8, 0));
+    o.w[0] = (uint32_t)a;
+    o.w[1] = (uint32_t)(a >> 32);
+    o.w[2] = (uint32_t)b;
+    o.w[3] = (uint32_t)(b >> 32);
+  }
+  return o;
+}
+// byte mask of the cells of chunk c inside rows [r0, r1) x columns [c0, c1) (W >= 16; the rectangle lies inside the plane)
+ARCLE_BIG_DEV Chunk rect_mask16(int c, int W, int r0, int r1, int c0, int c1) {
+  const int f0 = 16 * c, i0 = f0 / W, j0 = f0 - i0 * W, n0 = imin(16, W - j0);
+  Chunk m = zero_chunk();
+  if (i0 >= r0 && i0 < r1) m = range_mask16(imin(imax(c0 - j0, 0), n0), imin(imax(c1 - j0, 0), n0));
+  if (n0 < 16 && i0 + 1 >= r0 && i0 + 1 < r1) {
+    const Chunk m2 = range_mask16(n0 + imin(imax(c0, 0), 16 - n0), n0 + imin(imax(c1, 0), 16 - n0));
+#pragma unroll
+    for (int q = 0; q < 4; q++) m.w[q] |= m2.w[q];
+  }
+  return m;
+}
+ARCLE_BIG_DEV uint32_t nz_bytes(uint32_t v) {  // 0xff in every byte of v that is non-zero
+  const uint32_t t = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u) >> 7;
+  return (t << 8) - t;
+}
+ARCLE_BIG_DEV uint32_t pos_bytes(uint32_t v) {  // 0xff in every byte of v that is > 0 as an int8
+  const uint32_t t = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) & ~v) & 0x80808080u) >> 7;
+  return (t << 8) - t;
+}
+
+// Copy / CropGrid (W >= 16): chunk c of the h x w tile whose cell (i, j) is plane A's cell (x0 + i, y0 + j) where the selection S is non-zero
+ARCLE_BIG_DEV Chunk cut_out16(const Ctx& x, int c, int x0, int y0, int h, int w) {
+  const int delta = x0 * x.W + y0;
+  const Chunk sv = shifted16(x.S, 16 * c + delta, x.PS), av = shifted16(x.A, 16 * c + delta, x.PS);
+  const Chunk in = rect_mask16(c, x.W, 0, h, 0, w);
+  Chunk o;
+#pragma unroll
+  for (int q = 0; q < 4; q++) o.w[q] = av.w[q] & in.w[q] & nz_bytes(sv.w[q]);
+  return o;
+}
+
 // _apply_patch (object.py:113-138) + _apply_sel (object.py:140-165): grid := background, selected := 0, then the object tile `O`
 // (LDS, tile origin at cell 0) is drawn at object_pos wherever it is > 0 and `Q` becomes the selection there; clipped to grid_dim.
 // `cut`: nullptr when `bg` is the background itself; else `bg` is the grid and the background is where(cut > 0, 0, grid) (object.py:87-88).
@@ -570,6 +632,26 @@ ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const 
   const int xh = i8w(px + h), yw = i8w(py + w);  // int8 + int8
   const bool draw = xh > 0 && px < gh && yw > 0 && py < gw;
   const int stx = imax(px, 0), edx = imin(gh, xh), sty = imax(py, 0), edy = imin(gw, yw);
+  if (W >= 16) {  // whole chunks: the object tile read at the flat shift -(px * W + py), the destination rectangle as a byte mask
+    const int d2 = px * W + py;
+    for (int c = x.tid; c < x.nch; c += x.NT) {
+      const Chunk bgc = ldg(bg, c);
+      const Chunk pv = shifted16(O, 16 * c - d2, x.PS), qv = shifted16(Q, 16 * c - d2, x.PS);
+      const Chunk in = draw ? rect_mask16(c, W, stx, edx, sty, edy) : zero_chunk();
+      Chunk grid, sel;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        uint32_t b = bgc.w[q];
+        if (cut) b &= ~pos_bytes(reinterpret_cast<const uint32_t*>(cut)[4 * c + q]);  // background = where(sel > 0, 0, grid)
+        const uint32_t m = in.w[q] & pos_bytes(pv.w[q]);                                // :138 where=(p > 0)
+        grid.w[q] = (pv.w[q] & m) | (b & ~m);
+        sel.w[q] = qv.w[q] & in.w[q];                                                   // :165
+      }
+      x.gs(ARCLE_PL_GRID, c, grid);
+      x.gs(ARCLE_PL_SELECTED, c, sel);
+    }
+    return;
+  }
   for (int c = x.tid; c < x.nch; c += x.NT) {
     Chunk sel = zero_chunk();
     const Chunk bgc = ldg(bg, c);
@@ -928,6 +1010,22 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             x.stage_g(x.A, ARCLE_PL_GRID);
             bx::sync();
           }
+          if (W >= 16) {  // whole chunks: selection and grid read at the flat shift x0 * W + y0, the tile rectangle as a byte mask
+            const int delta = x0 * W + y0;
+            for (int c = tid; c < nch; c += NT) {
+              const Chunk sv = shifted16(x.S, 16 * c + delta, x.PS), av = shifted16(x.A, 16 * c + delta, x.PS);
+              const Chunk in = rect_mask16(c, W, 0, oh, 0, ow);
+              Chunk ob, qs;
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const uint32_t m = in.w[q] & pos_bytes(sv.w[q]);  // :78 sel > 0
+                ob.w[q] = av.w[q] & m;                            // :81
+                qs.w[q] = 0x01010101u & m;                        // :84
+              }
+              stg(x.B, c, ob);
+              stg(x.C, c, qs);
+            }
+          } else
           for (int c = tid; c < nch; c += NT) {
             Chunk qs = zero_chunk();
             // (every gather below reads LDS UNCONDITIONALLY at a clamped index and selects afterwards: the 16 cells' reads are then
@@ -1033,6 +1131,9 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         if (x1 > ss_h || y1 > ss_w) break;  // :301 (sic: > not >=)
         const int h = x1 - x0 + 1, w = y1 - y0 + 1;
         // (the source plane is in A)
+        if (W >= 16) {
+          for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_CLIP, c, cut_out16(x, c, x0, y0, h, w));  // :310-312 where=logical_and(src, sel)
+        } else
         for (int c = tid; c < nch; c += NT)
           x.gs(ARCLE_PL_CLIP, c, build_chunk(c, W, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
@@ -1051,6 +1152,19 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const int ex = imin(x0 + h, H), ey = imin(y0 + w, W);  // :340-341 clipped to H x W, not grid_dim
         // (the clip plane is in A)
         const int c_first = (x0 * W) >> 4, c_last = imin(nch - 1, (ex * W) >> 4);
+        if (W >= 16) {  // whole chunks: the clip read at the flat shift -(x0 * W + y0), the pasted rectangle as a byte mask
+          const int d2 = x0 * W + y0;
+          for (int c = c_first + tid; c <= c_last; c += NT) {
+            Chunk gr = x.gl(ARCLE_PL_GRID, c);
+            const Chunk pv = shifted16(x.A, 16 * c - d2, x.PS), in = rect_mask16(c, W, x0, ex, y0, ey);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const uint32_t m = arg ? in.w[q] : in.w[q] & pos_bytes(pv.w[q]);  // :345-348
+              gr.w[q] = (pv.w[q] & m) | (gr.w[q] & ~m);
+            }
+            x.gs(ARCLE_PL_GRID, c, gr);
+          }
+        } else
         for (int c = c_first + tid; c <= c_last; c += NT) {
           const Chunk gr = x.gl(ARCLE_PL_GRID, c);
           x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int f, int i, int j) {
@@ -1081,6 +1195,9 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       case ARCLE_OP_CROP_GRID: {  // critical.py:56-66
         if (!any_nz) break;
         const int h = x1 - x0 + 1, w = y1 - y0 + 1;  // (the grid is in A)
+        if (W >= 16) {
+          for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, cut_out16(x, c, x0, y0, h, w));
+        } else
         for (int c = tid; c < nch; c += NT)
           x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
