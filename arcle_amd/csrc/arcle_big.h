@@ -610,6 +610,24 @@ ARCLE_BIG_DEV uint32_t pos_bytes(uint32_t v) {  // 0xff in every byte of v that 
   return (t << 8) - t;
 }
 
+// Rotate / Flip (W >= 16): chunk c of dst[:nh, :nw] = src[c0 + ai * i + bj * j] — a true gather (a column of the source becomes a row), but the
+// source index of consecutive cells advances by bj, restarts once where the chunk crosses into its second plane row, and the [:nh, :nw]
+// rectangle is applied as a byte mask afterwards: an add, a clamp (v_med3) and a byte read per cell instead of the compare chain
+ARCLE_BIG_DEV Chunk gather_affine16(const int8_t* tile, int c, int W, int P, int nh, int nw, int c0, int ai, int bj) {
+  const int f0 = 16 * c, i0 = f0 / W, j0 = f0 - i0 * W, n0 = imin(16, W - j0);
+  const int ta = c0 + ai * i0 + bj * j0, tb = c0 + ai * (i0 + 1) - bj * n0;  // cell k: ta + bj * k in the first row, tb + bj * k in the second
+  Chunk o;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int t = (k < n0 ? ta : tb) + bj * k;
+    o.b[k] = tile[imin(imax(t, 0), P - 1)];
+  }
+  const Chunk in = rect_mask16(c, W, 0, nh, 0, nw);
+#pragma unroll
+  for (int q = 0; q < 4; q++) o.w[q] &= in.w[q];
+  return o;
+}
+
 // Copy / CropGrid (W >= 16): chunk c of the h x w tile whose cell (i, j) is plane A's cell (x0 + i, y0 + j) where the selection S is non-zero
 ARCLE_BIG_DEV Chunk cut_out16(const Ctx& x, int c, int x0, int y0, int h, int w) {
   const int delta = x0 * x.W + y0;
@@ -890,6 +908,14 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         any = (uint32_t)xa < (uint32_t)H && (uint32_t)ya < (uint32_t)W;
         if (!any && (xa | ya) < 0) st |= ARCLE_ST_BAD_SELECTION;
       }
+      if (W >= 16) {
+        for (int c = tid; c < nch; c += NT) {
+          Chunk m = any ? rect_mask16(c, W, xa, xb + 1, ya, yb + 1) : zero_chunk();
+#pragma unroll
+          for (int q = 0; q < 4; q++) m.w[q] &= 0x01010101u;
+          stg(x.S, c, m);
+        }
+      } else
       for (int c = tid; c < nch; c += NT)
         stg(x.S, c, build_chunk(c, W, P, [&](int, int i, int j) { return (any && i >= xa && i <= xb && j >= ya && j <= yb) ? 1 : 0; }));
       any_nz = any_pos = any;
@@ -984,8 +1010,10 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           if (!(s.w[0] | s.w[1] | s.w[2] | s.w[3])) continue;
           Chunk gr = x.gl(ARCLE_PL_GRID, c);
 #pragma unroll
-          for (int k = 0; k < 16; k++)
-            if (s.b[k] != 0) gr.b[k] = (int8_t)arg;
+          for (int q = 0; q < 4; q++) {
+            const uint32_t m = nz_bytes(s.w[q]);
+            gr.w[q] = (gr.w[q] & ~m) | ((((uint32_t)arg & 0xffu) * 0x01010101u) & m);
+          }
           x.gs(ARCLE_PL_GRID, c, gr);
         }
         break;
@@ -1070,8 +1098,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               Chunk gr = ldg(x.A, c);  // background = where(sel > 0, 0, grid)  :87-88; place() forms it again from A and S
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
-              for (int k = 0; k < 16; k++)
-                if (sm.b[k] > 0) gr.b[k] = 0;
+              for (int q = 0; q < 4; q++) gr.w[q] &= ~pos_bytes(sm.w[q]);
               x.gs(ARCLE_PL_BACKGROUND, c, gr);
             }
           }
@@ -1083,11 +1110,10 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               Chunk gr = ldg(x.A, c);
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
-              for (int k = 0; k < 16; k++)
-                if (sm.b[k] > 0) gr.b[k] = 0;
+              for (int q = 0; q < 4; q++) gr.w[q] &= ~pos_bytes(sm.w[q]);
               stg(x.A, c, gr);
             }
-            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) {
+            const Chunk t = W >= 16 ? gather_affine16(x.B, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int8_t v = x.B[in ? c0 + ai * i + bj * j : 0];
               return in ? v : (int8_t)0;
@@ -1097,7 +1123,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           bg_in_A = true;
           bx::sync();
           for (int c = tid; c < nch; c += NT) {
-            const Chunk t = build_chunk(c, W, P, [&](int, int i, int j) {
+            const Chunk t = W >= 16 ? gather_affine16(x.C, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int8_t v = x.C[in ? c0 + ai * i + bj * j : 0];
               return in ? v : (int8_t)0;
