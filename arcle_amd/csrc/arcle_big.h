@@ -62,6 +62,12 @@ ARCLE_BIG_DEV Chunk ldg(const int8_t* base, int c) {
   o.v = *reinterpret_cast<const V16*>(base + 16 * (size_t)c);
   return o;
 }
+// 16 bytes at any alignment (global memory takes unaligned vector loads; the compiler is told nothing about the alignment)
+ARCLE_BIG_DEV Chunk ldu(const int8_t* p) {
+  Chunk o;
+  __builtin_memcpy(&o, p, 16);
+  return o;
+}
 ARCLE_BIG_DEV void stg(int8_t* base, int c, const Chunk& v) { *reinterpret_cast<V16*>(base + 16 * (size_t)c) = v.v; }
 ARCLE_BIG_DEV Chunk zero_chunk() {
   Chunk o;
@@ -398,9 +404,7 @@ ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, in
       const Seg s0 = L.s[si];
       if (s0.plane >= 0 && b0 + 16 <= s0.start + s0.len) {
         // the unit lies inside one plane segment: 16 consecutive bytes of the plane
-        const int8_t* src = x.p.plane[s0.plane] + x.po + (b0 - s0.start);
-#pragma unroll
-        for (int k = 0; k < 16; k++) v.b[k] = src[k];
+        v = ldu(x.p.plane[s0.plane] + x.po + (b0 - s0.start));
       } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -815,8 +819,8 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
 #pragma unroll
           for (int k = 0; k < 16; k++)
             if (f0 + k < P) v.b[k] = (int8_t)((m >> k) & 1u);
-        } else if (aligned && f0 + 16 <= P) {
-          v = ldg(src, c);
+        } else if (f0 + 16 <= P) {
+          v = aligned ? ldg(src, c) : ldu(src + f0);
         } else {
 #pragma unroll
           for (int k = 0; k < 16; k++)
@@ -1463,9 +1467,13 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
       for (int c = x.tid; c < x.nch; c += x.NT) {
         Chunk v = zero_chunk();
         const int f0 = 16 * c;
+        if (f0 + 16 <= x.P) {
+          v = ldu(src + f0);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-          if (f0 + k < x.P) v.b[k] = src[f0 + k];
+          for (int k = 0; k < 16; k++)
+            if (f0 + k < x.P) v.b[k] = src[f0 + k];
+        }
         x.io++;  // (the row bytes read)
         x.gs(sg.plane, c, v);
       }
