@@ -7,8 +7,9 @@
 //   * a plane is PS = H*W rounded up to 128 bytes; thread t owns the 16-byte chunks t, t + NT, t + 2 NT ... of it: every global plane
 //     access is one aligned 16 B load / store per thread, consecutive threads on consecutive chunks (fully coalesced);
 //   * the selection and up to three planes are staged in the workgroup's LDS (4 x PS bytes + 4.4 KB, dynamic: 11 KB at 40 x 40, 69 KB at
-//     127 x 127), geometric ops (object lift / place, Rotate / Flip, Copy / Paste / Crop) gather single cells from those tiles and write
-//     whole chunks back;
+//     127 x 127); the geometric ops work on whole chunks: object lift / place, Copy, Paste and Crop are FLAT SHIFTS of a plane (16
+//     consecutive tile bytes through five dword reads and funnel shifts, the op's rectangle as a byte mask of two column runs), Rotate /
+//     Flip gather cell by cell with an add + clamp + byte read and take the rectangle as a mask (W < 16 keeps per-cell forms);
 //   * reductions (any / sum / arg-max / bounding box of the selection, grid == answer) are LDS atomics + a workgroup barrier;
 //   * FloodFill runs on 128-bit row boards (one thread per row): a pass pulls the fill from the rows above and below and spreads it along
 //     the row's eligible runs with the carry trick (E + F ripples through a run of ones), until no row changes;
