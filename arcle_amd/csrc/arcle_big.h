@@ -647,7 +647,10 @@ ARCLE_BIG_DEV Chunk cut_out16(const Ctx& x, int c, int x0, int y0, int h, int w)
 // _apply_patch (object.py:113-138) + _apply_sel (object.py:140-165): grid := background, selected := 0, then the object tile `O`
 // (LDS, tile origin at cell 0) is drawn at object_pos wherever it is > 0 and `Q` becomes the selection there; clipped to grid_dim.
 // `cut`: nullptr when `bg` is the background itself; else `bg` is the grid and the background is where(cut > 0, 0, grid) (object.py:87-88).
-ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q) {
+// `lift_delta` >= 0 (W >= 16, a fresh selection that is only MOVED): there are no object tiles — the object is the grid `bg` under the
+// selection `cut`, read at the lift's flat shift on top of the placement's: one gather pass instead of lift + barrier + place.
+ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q,
+                         int lift_delta = -1) {
   const int W = x.W;
   const int px = r[ARCLE_REC_OBJECT_POS], py = r[ARCLE_REC_OBJECT_POS + 1];
   const int h = r[ARCLE_REC_OBJECT_DIM], w = r[ARCLE_REC_OBJECT_DIM + 1];
@@ -659,7 +662,20 @@ ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const 
     const int d2 = px * W + py;
     for (int c = x.tid; c < x.nch; c += x.NT) {
       const Chunk bgc = ldg(bg, c);
-      const Chunk pv = shifted16(O, 16 * c - d2, x.PS), qv = shifted16(Q, 16 * c - d2, x.PS);
+      Chunk pv, qv;
+      if (lift_delta >= 0) {
+        const Chunk sv = shifted16(cut, 16 * c - d2 + lift_delta, x.PS);
+        pv = shifted16(bg, 16 * c - d2 + lift_delta, x.PS);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t m = pos_bytes(sv.w[q]);  // object.py:78 sel > 0
+          pv.w[q] &= m;                           // :81
+          qv.w[q] = 0x01010101u & m;              // :84
+        }
+      } else {
+        pv = shifted16(O, 16 * c - d2, x.PS);
+        qv = shifted16(Q, 16 * c - d2, x.PS);
+      }
       const Chunk in = draw ? rect_mask16(c, W, stx, edx, sty, edy) : zero_chunk();
       Chunk grid, sel;
 #pragma unroll
@@ -1038,27 +1054,84 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         int8_t *O = x.B, *Q = x.C;  // object / object_sel tiles
         bool bg_in_A = false;        // A holds the background itself (else: the grid, and the background is where(sel > 0, 0, grid))
         const bool transform = kind != ARCLE_OP_MOVE;
-        if (fresh) {  // object.py:67-99
+        if (fresh && W >= 16) {
+          // A fresh selection, whole chunks (object.py:67-99 fused with the op): the lifted object is the grid under the selection at the flat
+          // shift delta = x0 * W + y0, so nothing is lifted into tiles first.  Move: the three object planes are formed straight from A / S
+          // and place() reads A / S at the combined shift — ONE gather pass.  Rotate / Flip: the transformed tiles are gathered straight
+          // from A / S (source index + delta) — one gather pass and one barrier, then place().
           if (staged != ARCLE_PL_GRID) {
             x.stage_g(x.A, ARCLE_PL_GRID);
             bx::sync();
           }
-          if (W >= 16) {  // whole chunks: selection and grid read at the flat shift x0 * W + y0, the tile rectangle as a byte mask
-            const int delta = x0 * W + y0;
+          const int delta = x0 * W + y0;
+          r[ARCLE_REC_OBJECT_DIM] = (int8_t)oh;
+          r[ARCLE_REC_OBJECT_DIM + 1] = (int8_t)ow;
+          r[ARCLE_REC_OBJECT_POS] = (int8_t)x0;
+          r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)y0;
+          r[ARCLE_REC_ACTIVE] = 1;
+          r[ARCLE_REC_PARITY] = 0;
+          if (!transform) {  // gen_move(d), object.py:230-240
+            const int dx = (arg == 0) ? -1 : (arg == 1) ? 1 : 0;
+            const int dy = (arg == 2) ? 1 : (arg == 3) ? -1 : 0;
+            r[ARCLE_REC_OBJECT_POS] = (int8_t)i8w(x0 + dx);  // :238, int8 wrap
+            r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)i8w(y0 + dy);
             for (int c = tid; c < nch; c += NT) {
               const Chunk sv = shifted16(x.S, 16 * c + delta, x.PS), av = shifted16(x.A, 16 * c + delta, x.PS);
               const Chunk in = rect_mask16(c, W, 0, oh, 0, ow);
-              Chunk ob, qs;
+              Chunk ob, qs, gr = ldg(x.A, c);
+              const Chunk sm = ldg(x.S, c);
 #pragma unroll
               for (int q = 0; q < 4; q++) {
                 const uint32_t m = in.w[q] & pos_bytes(sv.w[q]);  // :78 sel > 0
                 ob.w[q] = av.w[q] & m;                            // :81
                 qs.w[q] = 0x01010101u & m;                        // :84
+                gr.w[q] &= ~pos_bytes(sm.w[q]);                   // :87-88 background = where(sel > 0, 0, grid)
+              }
+              x.gs(ARCLE_PL_OBJECT, c, ob);
+              x.gs(ARCLE_PL_OBJECT_SEL, c, qs);
+              x.gs(ARCLE_PL_BACKGROUND, c, gr);
+            }
+            place(x, r, x.A, x.S, nullptr, nullptr, delta);
+          } else {
+            for (int c = tid; c < nch; c += NT) {
+              const Chunk gs_ = gather_affine16(x.S, c, W, P, nh, nw, c0 + delta, ai, bj), ga = gather_affine16(x.A, c, W, P, nh, nw, c0 + delta, ai, bj);
+              Chunk ob, qs;
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const uint32_t m = pos_bytes(gs_.w[q]);
+                ob.w[q] = ga.w[q] & m;
+                qs.w[q] = 0x01010101u & m;
               }
               stg(x.B, c, ob);
               stg(x.C, c, qs);
             }
-          } else
+            if (new_geom) {
+              r[ARCLE_REC_OBJECT_POS] = (int8_t)nx;
+              r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)ny;
+              r[ARCLE_REC_OBJECT_DIM] = (int8_t)nh;
+              r[ARCLE_REC_OBJECT_DIM + 1] = (int8_t)nw;
+              r[ARCLE_REC_PARITY] = (int8_t)npar;
+            }
+            bx::sync();
+            for (int c = tid; c < nch; c += NT) {
+              Chunk gr = ldg(x.A, c);
+              const Chunk sm = ldg(x.S, c);
+#pragma unroll
+              for (int q = 0; q < 4; q++) gr.w[q] &= ~pos_bytes(sm.w[q]);
+              x.gs(ARCLE_PL_BACKGROUND, c, gr);
+              x.gs(ARCLE_PL_OBJECT, c, ldg(x.B, c));
+              x.gs(ARCLE_PL_OBJECT_SEL, c, ldg(x.C, c));
+            }
+            place(x, r, x.A, x.S, x.B, x.C);
+          }
+          sel_pending = 0;  // (place() writes the whole `selected` plane)
+          break;
+        }
+        if (fresh) {  // object.py:67-99 (W < 16: cell by cell, through object tiles)
+          if (staged != ARCLE_PL_GRID) {
+            x.stage_g(x.A, ARCLE_PL_GRID);
+            bx::sync();
+          }
           for (int c = tid; c < nch; c += NT) {
             Chunk qs = zero_chunk();
             // (every gather below reads LDS UNCONDITIONALLY at a clamped index and selects afterwards: the 16 cells' reads are then
