@@ -66,10 +66,11 @@ static int allow_lds(K kernel, int bytes) {
   return rc;
 }
 
-// Threads per workgroup: a thread owns the chunks t, t + NT, ... of a plane.  Measured on MI355X (profiles/round5_experiments.txt §15): the
-// kernel is bound by the per-chunk instruction chain of a thread (a chunk is 16 cells built one by one), not by barriers — one chunk per
-// thread is fastest up to 512 threads, so: the chunk count rounded up to whole wavefronts, at least 128 (the flood fill gives every board
-// row its own thread) and at most 512 (128 threads at 40 x 40, 256 at 64 x 64, 512 at 127 x 127).  ARCLE_BIG_THREADS overrides (tuning runs).
+// Threads per workgroup: a thread owns the chunks t, t + NT, ... of a plane.  About one chunk per thread won every sweep on MI355X, with the
+// per-cell kernels and with the whole-chunk (SWAR) ones (profiles/round5_experiments.txt §15, §20: 40 x 40 x 16 384 envs 39 us with 128
+// threads, 61 with 256, 117 with 512; 127 x 127: 264 us with 512, 312 with 256, 443 with 128) — so: the chunk count rounded up to whole
+// wavefronts, at least 128 (the flood fill gives every board row its own thread) and at most 512 (128 threads at 40 x 40, 256 at 64 x 64,
+// 512 at 127 x 127).  ARCLE_BIG_THREADS overrides (tuning runs).
 static unsigned threads_for(int PS) {
   static int forced = -1;
   if (forced < 0) {
@@ -80,7 +81,7 @@ static unsigned threads_for(int PS) {
   if (forced) return (unsigned)forced;
   const int nch = PS >> 4;
   const int t = (nch + 63) & ~63;
-  return (unsigned)(t < 128 ? 128 : t > 512 ? 512 : t);  // (127 x 127, 1016 chunks: 512 threads 36.7 us, 1024 threads 41.5, 256 threads 51.0 per 1024 envs)
+  return (unsigned)(t < 128 ? 128 : t > 512 ? 512 : t);
 }
 
 int workgroup_threads(int PS) { return (int)threads_for(PS); }
