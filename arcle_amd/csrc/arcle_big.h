@@ -6,7 +6,7 @@
 // Execution model — ONE WORKGROUP per env (128 … 512 threads: about one 16-byte chunk of a plane per thread):
 //   * a plane is PS = H*W rounded up to 128 bytes; thread t owns the 16-byte chunks t, t + NT, t + 2 NT ... of it: every global plane
 //     access is one aligned 16 B load / store per thread, consecutive threads on consecutive chunks (fully coalesced);
-//   * the selection and up to three planes are staged in the workgroup's LDS (4 x PS bytes + 4.4 KB, dynamic: 11 KB at 40 x 40, 69 KB at
+//   * the selection and up to three planes are staged in the workgroup's LDS (4 x PS bytes + 320, dynamic: 7 KB at 40 x 40, 64 KB at
 //     127 x 127); the geometric ops work on whole chunks: object lift / place, Copy, Paste and Crop are FLAT SHIFTS of a plane (16
 //     consecutive tile bytes through five dword reads and funnel shifts, the op's rectangle as a byte mask of two column runs), Rotate /
 //     Flip gather cell by cell with an add + clamp + byte read and take the rectangle as a mask (W < 16 keeps per-cell forms);
@@ -176,9 +176,14 @@ struct Ctx {
     B = lds + 2 * PS;
     C = lds + 3 * PS;
     red = reinterpret_cast<Red*>(lds + 4 * PS);
-    Eb = reinterpret_cast<uint64_t*>(lds + 4 * PS + 64);
-    Fb = Eb + 256;
-    sc = lds + 4 * PS + 64 + 4096;
+    sc = lds + 4 * PS + 64;
+    if (boards_in_tiles(PS, H)) {  // the row boards of the flood fill in the tiles no fill uses
+      Eb = reinterpret_cast<uint64_t*>(B);
+      Fb = reinterpret_cast<uint64_t*>(C);
+    } else {
+      Eb = reinterpret_cast<uint64_t*>(lds + 4 * PS + 64 + 256);
+      Fb = Eb + 256;
+    }
     lay = reinterpret_cast<Layout*>(sc + 32);
     po = (size_t)env * (size_t)PS;
   }

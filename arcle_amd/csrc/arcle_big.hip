@@ -53,7 +53,8 @@ __global__ __launch_bounds__(BIG_THREADS) void arcle_big_set_rows_kernel(const B
 
 namespace arcle_big {
 
-// the dynamic LDS of a launch: up to 69 KB (127 x 127) — beyond the 64 KB a kernel gets without asking
+// the dynamic LDS of a launch: 65 344 bytes at 127 x 127; a plane stride that needs more than the 64 KB a kernel gets without asking
+// (a caller-chosen stride with padding) asks for it
 template <int ID, class K>
 static int allow_lds(K kernel, int bytes) {
   if (bytes <= 65536) return 0;
@@ -61,7 +62,7 @@ static int allow_lds(K kernel, int bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (done & (1ull << (dev & 63))) return 0;
-  const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(MAX_PS));
+  const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(MAX_PS, 127));
   if (rc == 0) done |= 1ull << (dev & 63);
   return rc;
 }
@@ -87,25 +88,25 @@ static unsigned threads_for(int PS) {
 int workgroup_threads(int PS) { return (int)threads_for(PS); }
 
 int launch_step(const BigParams& p, void* stream) {
-  const int lds = lds_bytes(p.PS);
+  const int lds = lds_bytes(p.PS, p.H);
   if (int rc = allow_lds<0>(arcle_big_step_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_step_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 int launch_reset(const BigParams& p, int mode, void* stream) {
-  const int lds = lds_bytes(p.PS);
+  const int lds = lds_bytes(p.PS, p.H);
   if (int rc = allow_lds<1>(arcle_big_reset_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_reset_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p, mode);
   return (int)hipGetLastError();
 }
 int launch_rows(const BigParams& p, int mode, void* stream) {
-  const int lds = lds_bytes(p.PS);
+  const int lds = lds_bytes(p.PS, p.H);
   if (int rc = allow_lds<2>(arcle_big_rows_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_rows_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p, mode);
   return (int)hipGetLastError();
 }
 int launch_set_rows(const BigParams& p, void* stream) {
-  const int lds = lds_bytes(p.PS);
+  const int lds = lds_bytes(p.PS, p.H);
   if (int rc = allow_lds<3>(arcle_big_set_rows_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_set_rows_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p);
   return (int)hipGetLastError();

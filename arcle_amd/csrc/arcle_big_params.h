@@ -61,7 +61,10 @@ struct BigParams {
 };
 
 // bytes of LDS one workgroup needs: four staging planes + the reduction block + two row boards of 128 x 128 bits + a row's scalars and layout
-ARCLE_BIG_HD inline int lds_bytes(int PS) { return 4 * PS + 64 + 2 * 128 * 16 + 256; }  // 69 440 at 127 x 127 (gfx950: 160 KB per workgroup)
+// (the flood fill's two row boards, 16 bytes per plane row each, live in the B and C tiles — idle during a fill — whenever a tile holds them:
+// 16 * H <= PS, i.e. always for W >= 16; only narrow planes get 4 KB of their own)
+ARCLE_BIG_HD inline bool boards_in_tiles(int PS, int H) { return 16 * H <= PS; }
+ARCLE_BIG_HD inline int lds_bytes(int PS, int H) { return 4 * PS + 64 + 256 + (boards_in_tiles(PS, H) ? 0 : 2 * 128 * 16); }  // 65 344 at 127 x 127
 
 ARCLE_BIG_HD inline int flat_len(int P, bool o2, bool clip, int filtered) {
   if (filtered) return 3 * P + 10;

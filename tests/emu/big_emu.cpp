@@ -54,14 +54,14 @@ inline int uniform(int v) { return v; }
 using arcle_big::BigParams;
 
 extern "C" int big_emu_params_size(void) { return (int)sizeof(BigParams); }
-extern "C" int big_emu_lds_bytes(int PS) { return arcle_big::lds_bytes(PS); }
+extern "C" int big_emu_lds_bytes(int PS, int H) { return arcle_big::lds_bytes(PS, H); }
 
 // what: 0 step, 1 reset (mode 0 / 1 / 2), 2 rows out (mode 0 flat / 1 packed), 3 state rows in
 extern "C" int big_emu_run(int what, const BigParams* p, int mode, int nthreads) {
   if (nthreads < arcle_big::MIN_THREADS || p->PS > arcle_big::MAX_PS) return -1;
   void* lds = nullptr;
-  if (posix_memalign(&lds, 64, (size_t)arcle_big::lds_bytes(p->PS))) return -2;
-  memset(lds, 0x5a, (size_t)arcle_big::lds_bytes(p->PS));  // LDS is not zero at kernel start
+  if (posix_memalign(&lds, 64, (size_t)arcle_big::lds_bytes(p->PS, p->H))) return -2;
+  memset(lds, 0x5a, (size_t)arcle_big::lds_bytes(p->PS, p->H));  // LDS is not zero at kernel start
   bx::g_nt = nthreads;
   pthread_barrier_init(&bx::g_bar, nullptr, (unsigned)nthreads);
   std::vector<std::thread> th;
