@@ -12,7 +12,7 @@
 namespace arcle_big {
 
 enum { ING_MASK = 0, ING_BBOX = 1, ING_POINT = 2, ING_BBOX5 = 3, ING_BITS = 4 };  // (= enum arcle_ingress)
-enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 32, FILL_INNER = 8 };
+enum { MAX_SIDE = 127, MAX_PS = (127 * 127 + 127) & ~127, MIN_THREADS = 16, FILL_INNER = 8 };
 
 struct BigParams {
   int8_t* plane[ARCLE_N_PLANES];

@@ -461,7 +461,7 @@ def big_emu_lib():
 class BigEmuBackend(EmuBackend):
     """arcle_big.h (one workgroup per env; H * W > 1024) on host threads.  Same surface as EmuBackend where the big path has the feature."""
     name = "bigemu"
-    THREADS = 32  # the emulated workgroup (the product launches 256: every loop of the body is strided by the thread count)
+    THREADS = 16  # the emulated workgroup (the product launches 128-512: every loop of the body is strided by the thread count)
 
     def _params(self):
         p = _BigParams()

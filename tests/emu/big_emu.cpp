@@ -1,5 +1,5 @@
 // big_emu.cpp — TEST INFRASTRUCTURE: runs the workgroup-per-env kernel bodies of arcle_amd/csrc/arcle_big.h on the CPU, so that their
-// logic can be checked against the oracle without a GPU.  A "workgroup" is `nthreads` host threads (>= 32) that walk the envs together;
+// logic can be checked against the oracle without a GPU.  A "workgroup" is `nthreads` host threads (>= 16) that walk the envs together;
 // the workgroup barrier is a pthread barrier, LDS is one shared buffer, LDS atomics are GCC atomics.  Never part of the product.
 #include <pthread.h>
 #include <stdint.h>
@@ -11,7 +11,7 @@
 
 #define ARCLE_BIG_DEV inline
 #define ARCLE_BIG_HD
-#define ARCLE_BIG_ROWS 4  // board rows per thread of the flood fill: 127 rows over the 32 threads of the emulated workgroup
+#define ARCLE_BIG_ROWS 8  // board rows per thread of the flood fill: 127 rows over the 16 threads of the emulated workgroup
 
 namespace bx {
 static thread_local int t_tid;
