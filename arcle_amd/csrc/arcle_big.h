@@ -401,12 +401,13 @@ ARCLE_BIG_DEV void packed_layout(const BigParams& p, Layout& L) {
 // rows may live in pinned host memory) from the bytes of the segments that cross it.
 ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, int8_t* dst, int limit) {
   const int nu = limit >> 4;
-  for (int u = x.tid; u < nu; u += x.NT) {
+  int seg = 0;  // the segment holding this thread's current unit: units only move forward, so the search resumes where it stopped
+  auto unit = [&](int u) {
     const int b0 = 16 * u;
     Chunk v = zero_chunk();
     if (b0 < L.len) {
-      int si = 0;  // the segment holding byte b0 (segments are in row order)
-      while (si + 1 < L.n && L.s[si + 1].start <= b0) si++;
+      while (seg + 1 < L.n && L.s[seg + 1].start <= b0) seg++;
+      int si = seg;
       const Seg s0 = L.s[si];
       if (s0.plane >= 0 && b0 + 16 <= s0.start + s0.len) {
         // the unit lies inside one plane segment: 16 consecutive bytes of the plane
@@ -425,7 +426,20 @@ ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, in
       }
     }
     x.io += 2;  // (the unit stored + the 16 source bytes read)
-    stg(dst, u, v);
+    return v;
+  };
+  // four units per round: their loads are issued together, then the stores (a row in pinned host memory is written across PCIe — a loop
+  // of load -> store -> load would pay a round trip per unit)
+  for (int u = x.tid; u < nu; u += 4 * x.NT) {
+    const int u1 = u + x.NT, u2 = u + 2 * x.NT, u3 = u + 3 * x.NT;
+    const Chunk v0 = unit(u);
+    const Chunk v1 = u1 < nu ? unit(u1) : zero_chunk();
+    const Chunk v2 = u2 < nu ? unit(u2) : zero_chunk();
+    const Chunk v3 = u3 < nu ? unit(u3) : zero_chunk();
+    stg(dst, u, v0);
+    if (u1 < nu) stg(dst, u1, v1);
+    if (u2 < nu) stg(dst, u2, v2);
+    if (u3 < nu) stg(dst, u3, v3);
   }
 }
 
