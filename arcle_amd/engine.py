@@ -140,8 +140,12 @@ class EnvBatch:
         if rc != 0:
             raise ArcleHipError(f"hipStreamSynchronize failed ({rc})")
 
-    def next_seq(self):
-        """Arms the completion signal of the next launch that writes a row tail (arcle_set_flat_seq) and returns its sequence number."""
+    def next_seq(self, tail_u8):
+        """Arms the completion signal of the next launch that writes the row tail `tail_u8` (arcle_set_flat_seq) and returns its
+        sequence number.  The tail's signal byte is cleared first: one counter serves several tail buffers (the step() row and the
+        transition() row of a single env), so a stale byte of an earlier launch on THIS buffer could equal the new number — the
+        launch is stream-ordered after this host write to pinned memory."""
+        tail_u8[15] = 0
         self._seq = getattr(self, "_seq", 0) % 255 + 1
         rc = self.L.arcle_set_flat_seq(self._h, self._seq)
         if rc != 0:

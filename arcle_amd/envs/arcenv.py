@@ -10,6 +10,7 @@ from .base import AbstractARCEnv
 class RawARCEnv(AbstractARCEnv):
     """12 ops: Color0-9, ResizeToAnswer, Submit (arcenv.py:26-41); base state only."""
     KIND = "raw"
+    _RECORD_ACTION_FIRST = True  # arcenv.py:62-64
 
     def __init__(self, data_loader: Loader = None, max_grid_size=(30, 30), colors=10, max_trial=-1, render_mode=None,
                  render_size=None, device=None):
@@ -27,6 +28,13 @@ class RawARCEnv(AbstractARCEnv):
         info = super().init_info()
         info["steps"] = 0
         return info
+
+    def _step_flags(self):
+        """reset_on_submit in RawARCEnv.step (arcenv.py:62-76): `state = self.current_state` is bound BEFORE the op runs, so the reward
+        and `terminated` the step returns are those of the state that was submitted, while the observation is the re-initialised
+        one (the other classes read all three from the new state, o2arcenv.py:138-147).  The kernel therefore steps without
+        RESET_ON_SUBMIT and AbstractARCEnv.step re-initialises the state afterwards."""
+        return 0
 
 
 class ARCEnv(AbstractARCEnv):

@@ -110,17 +110,11 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         return self._plan
 
     def _state_from_row(self, row, live=False):
-        """The reference's obs dict from one flattened row.  live (the env's own pinned row, copy_observations False): the dict whose
-        arrays ARE the row — built once, the kernel rewrites it under the caller.  Otherwise fresh numpy int8 arrays, independent of the
+        """The reference's obs dict from one flattened row.  live (the env's own pinned row, copy_observations False): a dict whose
+        arrays ARE the row — the kernel rewrites them under the caller.  Otherwise fresh numpy int8 arrays, independent of the
         staging buffer: ONE copy of the row, every key a view into that copy."""
         plan = self._row_plan()
-        if live and not self.copy_observations:
-            st = getattr(self, "_live_state", None)
-            if st is not None and self._live_row is row:
-                return st
-            buf = row[:self._row_len]
-        else:
-            buf = row[:self._row_len].copy()
+        buf = row[:self._row_len] if live and not self.copy_observations else row[:self._row_len].copy()
         st = {}
         for path, lo, hi, shape in plan:
             v = buf[lo:hi]
@@ -130,17 +124,57 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
                 st[path[0]] = v
             else:
                 st.setdefault(path[0], {})[path[1]] = v
-        if live and not self.copy_observations:
-            self._live_state, self._live_row = st, row
         return st
 
+    def _new_live_state(self):
+        """A NEW state dict over the pinned row — one per episode, like the reference's init_state (base.py:156-167: reset, and Submit
+        under reset_on_submit, bind self.current_state to a fresh dict; between them step() hands out the same dict every time).  The
+        views are remembered so that a key rebound behind the env's back (a reference-style op doing `state['grid'] = ...`,
+        color.py:73) can be pointed at the row again."""
+        st = self._state_from_row(self._io()["row"], live=True)
+        self._live_views = None
+        if not self.copy_observations:
+            self._live_views = [(path, st[path[0]] if len(path) == 1 else st[path[0]][path[1]]) for path, _, _, _ in self._row_plan()]
+            self._live_nested = st.get("object_states")
+        self.current_state = st
+        return st
+
+    def _live_state(self):
+        """The state dict after a device step.  Live views: the episode's own dict, keys somebody rebound pointed at the row again;
+        copy_observations: a fresh dict over an independent copy of the row."""
+        if self._live_views is None:
+            self.current_state = self._state_from_row(self._io()["row"])
+            return self.current_state
+        st = self.current_state
+        if self._live_nested is not None and st.get("object_states") is not self._live_nested:
+            st["object_states"] = self._live_nested
+        for path, v in self._live_views:
+            d = st if len(path) == 1 else self._live_nested
+            if d.get(path[-1]) is not v:
+                d[path[-1]] = v
+        return st
+
+    def _detach_live_state(self):
+        """Before the pinned row is rewritten for a NEW episode: the previous episode's dict (somebody may have kept it — the
+        reference's reset leaves the old dict alone) gets its own memory."""
+        st = self.current_state
+        if st is None or getattr(self, "_live_views", None) is None:
+            return
+        buf = self._io()["row"][:self._row_len].copy()
+        for path, lo, hi, shape in self._row_plan():
+            d = st if len(path) == 1 else st.get(path[0])
+            if isinstance(d, dict) and any(d.get(path[-1]) is v for p2, v in self._live_views if p2 == path):
+                d[path[-1]] = buf[lo:hi].reshape(shape) if shape is not None else buf[lo:hi]
+        self._live_views = None
+
     def _fetch_state(self, b):
-        """Current state as the obs dict: one flatten launch that writes the row into pinned host memory, one synchronisation."""
+        """Current state as a NEW obs dict: one flatten launch that writes the row into pinned host memory, one synchronisation."""
+        self._detach_live_state()
         io = self._io()
         buf = b._flat_buf
         b._check(b.L.arcle_flatten_obs(b._h, buf.data_ptr(), buf.shape[1], 0, b._stream()), "arcle_flatten_obs")
         b.sync()
-        return self._state_from_row(io["row"], live=True)
+        return self._new_live_state()
 
     def _row_from_state(self, state, out):
         """Inverse of _state_from_row: writes the obs dict `state` into the numpy int8 row `out` (full layout)."""
@@ -222,7 +256,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         b = self.batch
         b.set_tasks([self.input_], [self.answer])
         b.reset()
-        self.current_state = self._fetch_state(b)
+        self.current_state = self._fetch_state(b)  # (a new dict per episode)
         self.info = self.init_info()
         if self.render_mode:
             self.render()
@@ -239,14 +273,29 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         return STEP_RESET_ON_SUBMIT if self.reset_on_submit else 0
 
     def _check_action(self, action):
-        op = int(action["operation"])
-        if not -len(self.operations) <= op < len(self.operations):
+        """(operation as given, its table slot, selection).  A negative index counts from the end like the Python list of the
+        reference (`self.operations[op]`, o2arcenv.py:149-151); the un-normalised value is what `last_action_op` keeps."""
+        raw = int(action["operation"])
+        n = len(self.operations)
+        if not -n <= raw < n:
             raise IndexError("list index out of range")  # what self.operations[op] raises in the reference
-        op %= len(self.operations)  # (a negative index counts from the end, like the Python list of the reference)
         sel = np.asarray(action["selection"])
         if sel.shape != (self.H, self.W):
             raise ValueError(f"selection must have shape {(self.H, self.W)}")
-        return op, sel
+        return raw, raw % n, sel
+
+    def _put_selection(self, sel, out):
+        """Selection of any dtype / memory layout -> the int8 mask the kernel reads (`out`: flat pinned view of H*W bytes).  int8 and
+        bool go in as they are; other dtypes (uint8, wider ints, floats) are accepted when every value is exactly representable as
+        int8 — then truthiness, `> 0`, the sum and the arg-max the operations take of the mask (color.py:71-99, object.py:68-88) are
+        what the reference computes on the original.  Anything else (200 in a uint8 mask, 0.5, NaN) is refused by name: the int8
+        kernel cannot reproduce what NumPy would do with it."""
+        out2 = out.reshape(self.H, self.W)
+        with np.errstate(invalid="ignore"):  # (a NaN casts to some int8; the comparison below refuses it)
+            np.copyto(out2, sel, casting="unsafe")
+        if sel.dtype != np.int8 and sel.dtype != np.bool_ and not np.array_equal(out2, sel):
+            raise ValueError(f"selection of dtype {sel.dtype} holds values that are not representable as int8 "
+                             "(the action space is Box(0, 1, int8), base.py:135)")
 
     @staticmethod
     def _raise_status(st):
@@ -255,8 +304,7 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         if st & ST_BAD_OP:
             raise IndexError("list index out of range")
 
-    def _device_step(self, b, action):
-        op, sel = self._check_action(action)
+    def _device_step(self, b, op, sel, action):
         fn = self.operations[op]
         if not isinstance(fn, actions.Operation) and not actions.is_submit(fn):
             # an arbitrary Python callable in the table (base.py:140-142 allows it; agents/wrapper.py:53-57): applied on the
@@ -265,10 +313,10 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             fn(state, action)
             self._state_to_device(b, state)
         io = self._io()
-        io["sel"][:] = sel.reshape(-1)  # (any integer / bool dtype -> int8, straight into the pinned buffer the kernel reads)
+        self._put_selection(sel, io["sel"])
         io["op"][0] = op
         st = b._stream()
-        seq = b.next_seq()
+        seq = b.next_seq(io["tail_u8"])
         b._check(b.L.arcle_step_mask(b._h, io["sel_ptr"], io["op_ptr"], b._reward_ptr, b._term_ptr,
                                      self._step_flags() | STEP_FLAT_OBS, st), "arcle_step_mask")
         b.wait_tail(io["tail_u8"], seq, st)  # the one wait of the step: the kernel's own completion signal in the pinned row's tail
@@ -279,13 +327,23 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             self._raise_status(status)
         return int(tail[0]), bool(int(tail[3]) & 0xFF)
 
+    # RawARCEnv.step records the action before it applies the op (arcenv.py:62-68), the other classes after (o2arcenv.py:132-136,
+    # arcenv.py:157-161): it only shows when the op raises
+    _RECORD_ACTION_FIRST = False
+
     def step(self, action):
         """o2arcenv.py:130-147 / arcenv.py:60-76,155-172."""
         b = self.batch
+        if self._RECORD_ACTION_FIRST:
+            self.last_action_op, self.last_action = int(action["operation"]), action
         if type(self).transition is not AbstractARCEnv.transition:
             # a subclass overrides transition() (the reference's step calls self.transition(self.current_state, action),
             # o2arcenv.py:134): run it on the state dict, then write the dict back and do the bookkeeping here
-            self.transition(self.current_state, action)
+            self._in_step = True
+            try:
+                self.transition(self.current_state, action)
+            finally:
+                self._in_step = False
             self._state_to_device(b, self.current_state)
             self.action_steps += 1
             b.cnt[0, 0] = self.action_steps
@@ -295,16 +353,24 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
             reward = self.reward(self.current_state)
             term = bool(self.current_state["terminated"][0])
         else:
-            dev_reward, term = self._device_step(b, action)
-            self.last_action_op = int(action["operation"]) % len(self.operations)
+            raw, op, sel = self._check_action(action)
+            dev_reward, term = self._device_step(b, op, sel, action)
+            self.last_action_op = raw
             self.last_action = action
             io = self._io()
-            self.current_state = self._state_from_row(io["row"], live=True)  # (the kernel wrote it into pinned host memory)
-            self.action_steps, self.submit_count = int(io["tail"][1]), int(io["tail"][2])
-            # a subclass that overrides reward() (e.g. the dense reward of agents/env.py:44-58) is evaluated on the host;
-            # so is the reward of a host-applied last op
-            host_reward = type(self).reward is not AbstractARCEnv.reward or not isinstance(
-                self.operations[self.last_action_op], actions.Operation) and not actions.is_submit(self.operations[self.last_action_op])
+            submits = int(io["tail"][2])
+            resubmitted = self.reset_on_submit and submits != self.submit_count
+            self.action_steps, self.submit_count = int(io["tail"][1]), submits
+            if resubmitted and not self._step_flags():
+                self._reinit_state(b)   # (RawARCEnv: the kernel stepped without RESET_ON_SUBMIT, see its _step_flags)
+            elif resubmitted:
+                self._new_live_state()  # Submit re-initialised the state: a new dict, like init_state (base.py:179-180)
+            else:
+                self._live_state()      # (the kernel wrote the row into pinned host memory)
+            # evaluated on the host: the reward of a subclass that overrides reward() (e.g. the dense one of agents/env.py:44-58), of a
+            # host-applied last op, and of an op given by a negative index (`last_action_op == len(ops) - 1` is false for -1)
+            host_reward = raw != op or type(self).reward is not AbstractARCEnv.reward or not isinstance(
+                self.operations[op], actions.Operation) and not actions.is_submit(self.operations[op])
             reward = self.reward(self.current_state) if host_reward else dev_reward
         self.last_reward = reward
         self.info["steps"] = self.action_steps
@@ -329,39 +395,64 @@ class AbstractARCEnv(spaces.Env, metaclass=ABCMeta):
         return self._tio_bufs
 
     def transition(self, state, action):
-        """o2arcenv.py:149-151 — applies one operation to `state` IN PLACE (README usage:
-        `env.transition(deepcopy(state), action)`).  One launch of the stateless row kernel: the dict becomes a state row in pinned
-        host memory, arcle_transition_rows applies the op, the result row is read back into the dict; the env's own device state is
-        not involved.  Like the reference, a Submit routed through here counts (`self.submit_count`, base.py:175); `action_steps`
-        does not move.  (Planning over many states at once: ARCVecEnv.transition — same kernel, any number of rows per launch.)"""
-        op, sel = self._check_action(action)
+        """o2arcenv.py:149-151 — applies one operation to `state` IN PLACE (README usage: `env.transition(deepcopy(state), action)`).
+        One launch of the stateless row kernel: the dict becomes a state row in pinned host memory, arcle_transition_rows applies the
+        op, the result is written back into the dict's own arrays.  Like the reference, a Submit routed through here counts
+        (`self.submit_count`, base.py:175) and, under reset_on_submit, re-initialises the ENV's state (base.py:179-180:
+        `self.init_state`, a new `current_state` dict) while `state` itself only loses a trial; `action_steps` and `last_action_op`
+        do not move.  `state is env.current_state`: the env's resident device state follows, as the reference's one dict does.
+        (Planning over many states at once: ARCVecEnv.transition — same kernel, any number of rows per launch.)"""
+        _, op, sel = self._check_action(action)
         fn = self.operations[op]
         if not isinstance(fn, actions.Operation) and not actions.is_submit(fn):
             fn(state, action)  # a host callable in the table: it IS the transition
+            if state is self.current_state and not getattr(self, "_in_step", False):
+                self._state_to_device(self.batch, state)
             return
         b = self.batch
         t = self._tio()
         self._row_from_state(state, t["rin_np"])
-        t["sel"][:] = sel.reshape(-1)
+        self._put_selection(sel, t["sel"])
         t["op"][0] = op
         ap = t["act"].data_ptr()
         st = b._stream()
-        seq = b.next_seq()
+        seq = b.next_seq(t["tail_u8"])
+        # (RESET_ON_SUBMIT is not passed: the row is the caller's `state`, which the reference does not re-initialise)
         b._check(b.L.arcle_transition_rows(b._h, 1, t["rin"].data_ptr(), t["stride"], 0, ap, ap + t["op_off"], None,
-                                           t["rout"].data_ptr(), t["stride"], 1, b._reward_ptr, b._term_ptr, self._step_flags(),
-                                           st), "arcle_transition_rows")
+                                           t["rout"].data_ptr(), t["stride"], 1, b._reward_ptr, b._term_ptr, 0, st),
+                 "arcle_transition_rows")
         b.wait_tail(t["tail_u8"], seq, st)
         status = (int(t["tail"][3]) >> 16) & 0xFF
         if status:
             b.status()
             self._raise_status(status)
-        self.submit_count += int(t["tail"][2])
-        new = self._state_from_row(t["rout_np"])
-        for k, v in new.items():
-            if k == "object_states":
-                state.setdefault("object_states", {}).update(v)
+        submitted = int(t["tail"][2])
+        if submitted:
+            self.submit_count += submitted
+            b.cnt[0, 1] = self.submit_count  # (the env's counter, whatever state the Submit ran on: the next step() reports it)
+        live = state is self.current_state and not getattr(self, "_in_step", False)
+        row = t["rout_np"]
+        for path, lo, hi, shape in self._row_plan():
+            d = state if len(path) == 1 else state.setdefault(path[0], {})
+            cur = d.get(path[-1])
+            v = row[lo:hi]
+            if type(cur) is np.ndarray and cur.size == hi - lo and cur.flags.writeable:
+                np.copyto(cur, v.reshape(cur.shape), casting="unsafe")  # in place: the dict's arrays stay the caller's (and the env's)
             else:
-                state[k] = v
+                d[path[-1]] = v.reshape(shape).copy() if shape is not None else v.copy()
+        if submitted and self.reset_on_submit:
+            self._reinit_state(b)  # (a live `state` is orphaned by the new dict and keeps what was just written, in its own memory)
+        elif live:
+            b.set_state_rows(t["rout"])
+            b.sync()
+
+    def _reinit_state(self, b):
+        """init_state(self.input_) in the middle of an episode (base.py:179-180): the env's state as reset() leaves it — a NEW dict —,
+        counters kept."""
+        b.reset()
+        b.cnt[0, 0] = self.action_steps
+        b.cnt[0, 1] = self.submit_count
+        self.current_state = self._fetch_state(b)
 
     def submit(self, state, action):
         """base.py:172-183 as an operation on `state` (the table slot `self.submit` maps to the device op)."""

@@ -50,7 +50,10 @@ batches on an evolving state.)  Besides the contract fields the line carries
                 ALL host cores) and `numpy_step` = a plain-NumPy one-env-at-a-time step() loop with the reference's call
                 structure (oracle/numpy_env.py; leaner than the reference itself, labelled so), 1 process / all cores;
   sustained     (N=1) the headline graph replayed back to back on a side thread for the ~15 s of the single-threaded CPU legs;
-  collective    (N>1) backend, world size and the number of ranks an all-reduce of ones actually counted.
+  collective    (N>1) backend, world size and the number of ranks an all-reduce of ones actually counted;
+  multi         (N>1, c3) bounded legs of BASELINE configs[3] / [4] on the same process group, after the headline: c4 = 8192 envs/GPU,
+                step + ONE packed all-gather per step (overlapped on a side stream / serial / the collective alone, GB/s), c5 = ARCEnv
+                4096 envs/GPU FloodFill-heavy, sharded without a collective (multi_legs below; --no-multi skips them).
 """
 import argparse
 import json
@@ -417,6 +420,14 @@ def emit(out, a):
     for k in ("collective", "floodfill"):
         if k in out:
             c[k] = out[k]
+    m = out.get("multi")
+    if m:  # (N > 1: BASELINE configs[3] / [4] on the same process group)
+        c["multi"] = {"error": m["error"][:160]} if "error" in m else {
+            "c4_us_per_step": _r(m["c4"]["us_per_step"]), "c4_serial_us_per_step": _r(m["c4"]["serial_us_per_step"]),
+            "c4_gather_only_us": _r(m["c4"]["gather_only_us"]), "c4_value": _r(m["c4"]["value"], 6), "c4_global_envs": m["c4"]["global_envs"],
+            "gather_GBps": _r(m["c4"]["gather_GBps"]), "gather_GBps_per_link_dir": _r(m["c4"]["gather_GBps_per_link_dir"]),
+            "c5_us_per_step": _r(m["c5"]["us_per_step"]), "c5_value": _r(m["c5"]["value"], 6), "c5_global_envs": m["c5"]["global_envs"],
+            "transport": m["c4"]["transport"][:40], "steps_per_region": m["steps_per_region"], "regions": m["regions"]}
     c["full_record"] = "stderr line BENCH_FULL / gpurun_out/bench_full_*.json"
     line = json.dumps(c)
     if len(line) > 3800:  # never let the headline grow past what the driver keeps
@@ -946,6 +957,155 @@ def big_grid_leg(dev):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def multi_legs(dev, dist, world, rank, shared_gpu, K=20, R=3):
+    """N > 1 only — after the c3 headline, on the same process group: bounded legs of BASELINE configs[3] and configs[4], so that the
+    driver's plain `bench.py --gpus N` also measures what north_star calls the "RCCL-over-xGMI gather of (obs, reward, done)":
+
+      c4  8192 envs/GPU (65 536 on 8), step with the fused packed-row epilogue + ONE all_gather_into_tensor of the 912-byte rows per step;
+          `overlapped`: the collective on a side stream behind an event, rows double-buffered, step t+1 runs under the gather of step t
+          (what ShardedVecEnv.gather_async does); `serial`: step, then the collective, on one stream; `gather_only`: the collective alone
+      c5  ARCEnv, 4096 envs/GPU (32 768 on 8), 70 % FloodFill point seeds: sharded, no collective (one hipGraph of the K launches)
+
+    Every figure is the max over ranks of the median of R regions of K steps (eager launches + host clock for c4 — the collective is
+    30-40x longer than a launch; HIP events around a graph replay for c5).  Ranks sharing one GPU (functional runs on a one-GPU box)
+    gather over gloo through a host bounce.  The sequence of collectives is the same on every rank whatever happens locally."""
+    import torch.distributed  # noqa: F401
+    from arcle_amd import actions
+    from arcle_amd.engine import EnvBatch
+    from arcle_amd.envs import ARCEnv
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        t = t if shared_gpu else t.to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    res = {"steps_per_region": K, "regions": R, "clock": "host perf_counter between barrier + synchronize pairs (c4), HIP events around one graph replay (c5); median region, max over ranks"}
+    # ---- setup on every rank, then ONE agreement collective before any data-path collective is issued --------------------------------
+    err = None
+    try:
+        c4, c5 = CONFIGS["c4"], CONFIGS["c5"]
+        n = c4["envs"]
+        S = K + 4
+        b4 = make_batch(dev, n, seed=1000 + rank)
+        FL4 = b4.elide_flag | c4["flags"] | STEP_PACK_OBS
+        bb_np, op_np = make_actions(S, n, 2000 + rank)
+        bb4, op4 = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+        R_ = b4.packed_obs_size()
+        packed = [torch.zeros((n, R_), dtype=torch.uint8, device=dev) for _ in range(2)]
+        full = [torch.empty((world * n, R_), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host_full = torch.empty((world * n, R_), dtype=torch.uint8) if shared_gpu else None
+        side = None if shared_gpu else torch.cuda.Stream(dev)
+        n5 = c5["envs"]
+        b5 = EnvBatch(n5, 30, 30, c5["max_trial"], "arc", dev)
+        b5.set_op_table(actions.table_descs(ARCEnv.default_operations()))
+        b5.set_tasks_padded(*make_tasks_c5(n5, 1000 + rank))
+        b5.reset()
+        FL5 = b5.elide_flag | c5["flags"]
+        bb5_np, op5_np = make_actions_c5(S, n5, 2000 + rank)
+        bb5, op5 = torch.from_numpy(bb5_np).to(dev), torch.from_numpy(op5_np).to(dev)
+        torch.cuda.synchronize(dev)
+    except Exception as exc:  # noqa: BLE001
+        err = f"{type(exc).__name__}: {exc}"
+    bad = max_over_ranks(0.0 if err is None else 1.0)
+    if bad:
+        return {"error": err or "setup failed on another rank"}
+
+    stream = torch.cuda.current_stream(dev)
+    sh = stream.cuda_stream
+
+    def all_gather(slot):
+        if shared_gpu:
+            dist.all_gather_into_tensor(host_full, packed[slot].cpu())
+        else:
+            dist.all_gather_into_tensor(full[slot], packed[slot])
+
+    def step4(i):
+        b4.set_packed_output(packed[i & 1])  # (launch parameters are taken by value)
+        b4.step_bbox_ptr(bb4[i % S].data_ptr(), op4[i % S].data_ptr(), FL4, sh)
+
+    done = [None, None]
+
+    def overlapped(i):
+        slot = i & 1
+        if done[slot] is not None:
+            stream.wait_event(done[slot])  # the gather that last read this buffer
+        step4(i)
+        if side is None:
+            all_gather(slot)
+            return
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            all_gather(slot)
+            done[slot] = torch.cuda.Event()
+            done[slot].record(side)
+
+    def serial(i):
+        step4(i)
+        all_gather(i & 1)
+
+    def gather_only(i):
+        all_gather(i & 1)
+
+    def step_only(i):
+        step4(i)
+
+    def timed(fn):
+        for i in range(4):  # warm-up (RCCL builds its channels on the first call)
+            fn(i)
+        if side is not None:
+            stream.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        ts = []
+        for r in range(R):
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(K):
+                fn(4 + i)
+            if side is not None:
+                stream.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            ts.append((time.perf_counter() - t0) / K)
+        return max_over_ranks(float(np.median(ts)))
+
+    t_over = timed(overlapped)
+    done[0] = done[1] = None
+    t_serial = timed(serial)
+    t_gather = timed(gather_only)
+    t_step = timed(step_only)
+    assert b4.status() == 0
+    shard_bytes = n * R_
+    res["c4"] = {"workload": c4["name"], "envs_per_gpu": n, "global_envs": n * world, "row_bytes": R_,
+                 "us_per_step": t_over * 1e6, "serial_us_per_step": t_serial * 1e6, "gather_only_us": t_gather * 1e6,
+                 "step_only_us_eager": t_step * 1e6, "value": n * world / t_over, "unit": "env-steps/s",
+                 "gather_bytes_per_rank_in": shard_bytes * (world - 1),
+                 "gather_GBps": shard_bytes * world / t_gather / 1e9,
+                 "gather_GBps_per_link_dir": shard_bytes / t_gather / 1e9,
+                 "gather_note": "gather_GBps = gathered tensor bytes / collective time (algorithm bandwidth); per_link_dir = one shard / collective "
+                                "time: what each directed xGMI link carries when every peer pair exchanges its shard directly",
+                 "transport": "gloo through a host bounce (ranks share one GPU: functional, not a measurement)" if shared_gpu else "RCCL all_gather_into_tensor"}
+
+    # ---- c5: sharded, no collective -------------------------------------------------------------------------------------------------
+    def enqueue5(sh_):
+        for i in range(K):
+            b5.step_bbox_ptr(bb5[i].data_ptr(), op5[i].data_ptr(), FL5, sh_)
+    for i in range(4):
+        b5.step_bbox_ptr(bb5[K + i].data_ptr(), op5[K + i].data_ptr(), FL5, sh)
+    dist.barrier()
+    sec5, g5 = graph_time(dev, enqueue5, K, reps=max(R, 5))
+    t5 = max_over_ranks(sec5)
+    assert b5.status() == 0
+    res["c5"] = {"workload": c5["name"], "envs_per_gpu": n5, "global_envs": n5 * world, "us_per_step": t5 * 1e6,
+                 "value": n5 * world / t5, "unit": "env-steps/s", "collective": "none (envs are independent)"}
+    del g5
+    return res
+
+
+
 def _spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per rank)."""
     with socket.socket() as s:
@@ -974,6 +1134,7 @@ def main():
                     "through them; a small number keeps the action stream cache-resident — a policy that writes one batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the non-headline legs (kernel A/B runs)")
+    ap.add_argument("--no-multi", action="store_true", help="N > 1: skip the bounded c4 (step + RCCL all-gather) and c5 (sharded FloodFill) legs after the c3 headline")
     ap.add_argument("--no-forms", "--no-ordered", dest="no_ordered", action="store_true", help="skip the `forms` leg (the region's K launches as ONE arcle_step_many call, "
                     "and the K single-step calls with the dispatch order off)")
     ap.add_argument("--no-graph", action="store_true", help="launch the K steps of a region eagerly instead of as one hipGraph")
@@ -1266,6 +1427,13 @@ def main():
         for f_ in (forms or {}).values():
             f_["frac"] = per_launch_bytes / (f_["avg_launch_us"] * 1e-6) / HBM_PEAK
 
+    multi = None
+    if dist is not None and world > 1 and a.config == "c3" and not a.no_multi:
+        try:
+            multi = multi_legs(dev, dist, world, rank, shared_gpu, K=4 if shared_gpu else 20, R=2 if shared_gpu else 3)
+        except Exception as exc:  # noqa: BLE001 - (a local failure after the agreement point; the headline line is still printed)
+            multi = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         out = {
             "metric": "env-steps/sec (whole node), O2ARCv2Env 30x30, 8192 envs/GPU" if a.config in ("c3", "c4")
@@ -1291,6 +1459,8 @@ def main():
             out["collective"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_seen": ranks_seen,
                                  "devices_visible": ndev, "shared_gpu": bool(shared_gpu),
                                  "data_path": "none (envs are independent)" if gather is None else "one all_gather_into_tensor of the packed rows per step"}
+        if multi is not None:
+            out["multi"] = multi
         if a.config == "c5":
             seeds = [(int(bbox_np[0, e, 0]), int(bbox_np[0, e, 1])) for e in range(n) if 10 <= op_np[0, e] < 20]
             grids = [tasks[0][e] for e in range(n) if 10 <= op_np[0, e] < 20]

@@ -182,3 +182,10 @@ def test_bench_all_gpus_over_rccl_as_the_driver_launches_it(cfg):
     rank_lines = [ln for ln in p.stderr.splitlines() if ln.startswith("bench: rank ")]
     assert len(rank_lines) == n and all("backend=nccl" in ln for ln in rank_lines), p.stderr[-2000:]
     assert all(" RCCL " in ln for ln in rank_lines), "every rank logs the RCCL version it runs"
+    if cfg == "c3":  # BASELINE configs[3] / [4] over RCCL, on the same process group, inside the driver's own command
+        m = out["multi"]
+        assert "error" not in m, m
+        assert m["c4_global_envs"] == 8192 * n and m["c5_global_envs"] == 4096 * n and m["transport"].startswith("RCCL")
+        for k in ("c4_us_per_step", "c4_serial_us_per_step", "c4_gather_only_us", "gather_GBps", "gather_GBps_per_link_dir", "c5_us_per_step"):
+            assert m[k] > 0, k
+        assert m["c4_us_per_step"] <= m["c4_serial_us_per_step"] * 1.15, "the overlapped form must not be slower than step-then-gather"

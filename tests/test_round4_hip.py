@@ -412,6 +412,16 @@ def test_bench_two_ranks_on_one_gpu(cfg):
     assert out["roofline"]["frac"] > 0 and out["roofline"]["algorithmic_bytes_per_launch"] > 8192 * 1000
     ranks = [ln for ln in p.stderr.splitlines() if ln.startswith("bench: rank ")]
     assert len(ranks) == 2 and any("rank 0/2" in ln for ln in ranks) and any("rank 1/2" in ln for ln in ranks), p.stderr[-1500:]
+    if cfg == "c3":  # the driver's own command (no --config) also measures BASELINE configs[3] / [4] on the same process group
+        m = out["multi"]
+        assert "error" not in m, m
+        assert m["c4_global_envs"] == 16384 and m["c5_global_envs"] == 8192
+        for k in ("c4_us_per_step", "c4_serial_us_per_step", "c4_gather_only_us", "gather_GBps", "gather_GBps_per_link_dir", "c5_us_per_step",
+                  "c4_value", "c5_value"):
+            assert m[k] > 0, k
+        assert abs(m["c5_value"] - 8192 / (m["c5_us_per_step"] * 1e-6)) / m["c5_value"] < 1e-2
+    else:
+        assert "multi" not in out
 
 
 def test_bench_one_rank_is_the_same_line_with_and_without_a_launcher():
