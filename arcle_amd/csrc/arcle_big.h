@@ -158,7 +158,22 @@ ARCLE_BIG_DEV B128 spread(B128 E, B128 S) {
 }
 
 struct Layout;
-struct Ctx {
+// Flag bits the LEAN instantiations of the step kernel may see at run time (every other bit is known to be clear when the launcher picks
+// them, so the code behind it folds away): the flag sets ARCVecEnv steps with when no row epilogue, dense reward or trace rule is on.
+enum : uint32_t { LEAN_FLAGS = ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_RESAMPLE | ARCLE_STEP_TRUNCATE | ARCLE_STEP_RESET_ON_SUBMIT };
+#ifndef ARCLE_BIG_LEAN_THREADS
+#define ARCLE_BIG_LEAN_THREADS 512  // (the emulator runs its workgroups on 16 host threads)
+#endif
+enum { LEAN_THREADS = ARCLE_BIG_LEAN_THREADS };  // workgroup size of a LEAN launch whose planes have more chunks than that (ONE_ = false)
+
+// The per-workgroup context.  ONE_: the launch has at least one thread per 16-byte chunk of a plane (PS / 16 <= workgroup size: every
+// plane of up to 8192 cells with the workgroup sizes threads_for picks) — every "my chunks" loop is then a single guarded body, no
+// induction variable, no back edge.  LEAN_: compile-time knowledge of the launch — flags within LEAN_FLAGS, W >= 16, no byte accounting, no
+// transition_rows scratch envs (and, with ONE_ false, exactly LEAN_THREADS threads).  CtxT<false, false> is the generic form: every
+// run-time parameter honoured (the reset / row kernels, the emulator, tuning launches).
+template <bool ONE_, bool LEAN_>
+struct CtxT {
+  static constexpr bool ONE = ONE_, LEAN = LEAN_;
   const BigParams& p;
   int env, tid, NT, H, W, P, PS, nch;
   int8_t *S, *A, *B, *C;
@@ -169,8 +184,8 @@ struct Ctx {
   size_t po;
   mutable uint32_t io;  // 16-byte global-memory accesses this thread issued (plane chunks, table chunks, mask chunks, row units): the
                         // byte accounting of arcle_enable_accounting — a register increment per access, summed per env when asked for
-  ARCLE_BIG_DEV Ctx(const BigParams& p_, int env_, int8_t* lds)
-      : p(p_), env(env_), tid(bx::tid()), NT(bx::nt()), H(p_.H), W(p_.W), P(p_.P), PS(p_.PS), nch(p_.PS >> 4), io(0) {
+  ARCLE_BIG_DEV CtxT(const BigParams& p_, int env_, int8_t* lds)
+      : p(p_), env(env_), tid(bx::tid()), NT(LEAN_ && !ONE_ ? (int)LEAN_THREADS : bx::nt()), H(p_.H), W(p_.W), P(p_.P), PS(p_.PS), nch(p_.PS >> 4), io(0) {
     S = lds;
     A = lds + PS;
     B = lds + 2 * PS;
@@ -187,37 +202,45 @@ struct Ctx {
     lay = reinterpret_cast<Layout*>(sc + 32);
     po = (size_t)env * (size_t)PS;
   }
+  ARCLE_BIG_DEV void count(uint32_t k = 1) const {
+    if (!LEAN_) io += k;
+  }
+  ARCLE_BIG_DEV bool wide() const { return LEAN_ || W >= 16; }  // whole-chunk (SWAR) forms of the geometric ops
   ARCLE_BIG_DEV int8_t* g(int pl) const { return p.plane[pl] + po; }
   ARCLE_BIG_DEV bool has(int pl) const { return p.plane[pl] != nullptr; }
   // chunk c of a state plane of this env: load / store (counted)
   ARCLE_BIG_DEV Chunk gl(int pl, int c) const {
-    io++;
+    count();
     return ldg(p.plane[pl] + po, c);
   }
   ARCLE_BIG_DEV void gs(int pl, int c, const Chunk& v) const {
-    io++;
+    count();
     stg(p.plane[pl] + po, c, v);
   }
   // global plane -> LDS tile / fill
   ARCLE_BIG_DEV void stage(int8_t* dst, const int8_t* src) const {
-    for (int c = tid; c < nch; c += NT) {
-      io++;
+    for (int c = tid, n_ = 0; c < nch && (!ONE_ || n_ == 0); c += NT, n_++) {
+      count();
       stg(dst, c, ldg(src, c));
     }
   }
   ARCLE_BIG_DEV void stage_g(int8_t* dst, int pl) const { stage(dst, p.plane[pl] + po); }
   ARCLE_BIG_DEV void fill(int8_t* dst, const Chunk& v) const {
-    for (int c = tid; c < nch; c += NT) stg(dst, c, v);
+    for (int c = tid, n_ = 0; c < nch && (!ONE_ || n_ == 0); c += NT, n_++) stg(dst, c, v);
   }
 };
+typedef CtxT<false, false> Ctx;
+// "for every chunk c of a plane that this thread owns" (c = tid, tid + NT, ...; with X::ONE at most the first)
+#define BIG_EACH_CHUNK(x, c) for (int c = (x).tid, n_##c = 0; c < (x).nch && (!(x).ONE || n_##c == 0); c += (x).NT, n_##c++)
 
 // init_state (base.py:155-166 + o2arcenv.py:16-34 / arcenv.py:81-89): grid := input, the other state planes := 0, the record's state
 // fields; `src` = the input plane to copy (the env's own, or a task-table entry that is also written to PL_INPUT)
-ARCLE_BIG_DEV void init_planes(const Ctx& x, const int8_t* src, bool write_input) {
+template <class X>
+ARCLE_BIG_DEV void init_planes(const X& x, const int8_t* src, bool write_input) {
   const Chunk z = zero_chunk();
-  for (int c = x.tid; c < x.nch; c += x.NT) {
+  BIG_EACH_CHUNK(x, c) {
     const Chunk in = ldg(src, c);
-    x.io++;
+    x.count();
     if (write_input) x.gs(ARCLE_PL_INPUT, c, in);
     x.gs(ARCLE_PL_GRID, c, in);
     if (x.has(ARCLE_PL_SELECTED)) x.gs(ARCLE_PL_SELECTED, c, z);
@@ -243,7 +266,8 @@ ARCLE_BIG_DEV void init_rec(int8_t* r, int max_trial) {
 // into the env's input and answer planes and the record's dims, then runs init_state's plane part.  Returns false (nothing written) when
 // a quarter turn does not fit the H x W plane; `soften`: such a turn is dropped (k &= 2) instead — device-drawn augmentations never fail
 // (the rule of arcle_wave.h load_task).  Workgroup-uniform; contains barriers when it augments.
-ARCLE_BIG_DEV bool load_task(const Ctx& x, int8_t* r, int t, int rot_k, uint64_t perm, bool soften) {
+template <class X>
+ARCLE_BIG_DEV bool load_task(const X& x, int8_t* r, int t, int rot_k, uint64_t perm, bool soften) {
   const BigParams& p = x.p;
   int ih = p.tbl_in_dim[2 * (size_t)t], iw = p.tbl_in_dim[2 * (size_t)t + 1];
   int ah = p.tbl_ans_dim[2 * (size_t)t], aw = p.tbl_ans_dim[2 * (size_t)t + 1];
@@ -254,8 +278,8 @@ ARCLE_BIG_DEV bool load_task(const Ctx& x, int8_t* r, int t, int rot_k, uint64_t
   const int8_t* const tin = p.tbl_in + (size_t)t * x.PS;
   const int8_t* const tan = p.tbl_ans + (size_t)t * x.PS;
   if (rot_k == 0 && perm == ARCLE_BIG_PERM_IDENTITY) {
-    for (int c = x.tid; c < x.nch; c += x.NT) {
-      x.io++;
+    BIG_EACH_CHUNK(x, c) {
+      x.count();
       x.gs(ARCLE_PL_ANSWER, c, ldg(tan, c));
     }
     init_planes(x, tin, true);
@@ -272,7 +296,7 @@ ARCLE_BIG_DEV bool load_task(const Ctx& x, int8_t* r, int t, int rot_k, uint64_t
       else if (rot_k == 2) { ai = -W; bj = -1; c0 = (h - 1) * W + (w - 1); }          // x[h-1-i, w-1-j]
       else if (rot_k == 3) { ai = 1; bj = -W; c0 = (h - 1) * W; nh = w; nw = h; }      // x[h-1-j, i]
       const int dpl = which ? ARCLE_PL_ANSWER : ARCLE_PL_INPUT;
-      for (int c = x.tid; c < x.nch; c += x.NT)
+      BIG_EACH_CHUNK(x, c)
         x.gs(dpl, c, build_chunk(c, W, x.P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int v = (uint8_t)src[in ? c0 + ai * i + bj * j : 0];
@@ -292,14 +316,16 @@ ARCLE_BIG_DEV bool load_task(const Ctx& x, int8_t* r, int t, int rot_k, uint64_t
 
 // answer.shape == grid_dim and grid[:h,:w] == answer (base.py:177, o2arcenv.py:124-127); workgroup-uniform result.
 // (two barriers; the caller has made the grid plane in global memory final and visible — a barrier since its last store)
-ARCLE_BIG_DEV bool grid_equals_answer(const Ctx& x, const int8_t* r) {
+template <class X>
+ARCLE_BIG_DEV bool grid_equals_answer(const X& x, const int8_t* r) {
   const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1];
   if (gh != r[ARCLE_REC_ANSWER_DIM] || gw != r[ARCLE_REC_ANSWER_DIM + 1]) return false;
   if (x.tid == 0) x.red->neq = 0;
   bx::sync();
   bool differs = false;
   const int lastc = imin(x.nch, (gh * x.W + 15) >> 4);  // cells of the rows >= gh are never compared
-  for (int c = x.tid; c < lastc; c += x.NT) {
+  BIG_EACH_CHUNK(x, c) {
+    if (c >= lastc) break;
     const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
     if ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) {
       int f = 16 * c;
@@ -399,7 +425,8 @@ ARCLE_BIG_DEV void packed_layout(const BigParams& p, Layout& L) {
 // writes bytes [0, limit) of the row at `dst` (16-byte aligned, limit a multiple of 16): the layout's bytes, zeros behind them.  A plane
 // segment lands at an arbitrary byte offset of the row, so each thread assembles whole 16-byte units of the row (one aligned store —
 // rows may live in pinned host memory) from the bytes of the segments that cross it.
-ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, int8_t* dst, int limit) {
+template <class X>
+ARCLE_BIG_DEV void write_row(const X& x, const Layout& L, const int8_t* sc, int8_t* dst, int limit) {
   const int nu = limit >> 4;
   int seg = 0;  // the segment holding this thread's current unit: units only move forward, so the search resumes where it stopped
   auto unit = [&](int u) {
@@ -425,7 +452,7 @@ ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, in
         }
       }
     }
-    x.io += 2;  // (the unit stored + the 16 source bytes read)
+    x.count(2);  // (the unit stored + the 16 source bytes read)
     return v;
   };
   // four units per round: their loads are issued together, then the stores (a row in pinned host memory is written across PCIe — a loop
@@ -444,7 +471,8 @@ ARCLE_BIG_DEV void write_row(const Ctx& x, const Layout& L, const int8_t* sc, in
 }
 
 // the FLAT_OBS / PACK_OBS epilogue of a step (and the stand-alone flatten / pack kernels): rows of the env's CURRENT state
-ARCLE_BIG_DEV void emit_rows(const Ctx& x, const int8_t* r, uint32_t flags, int reward, int term, int cnt0, int cnt1, bool truncated,
+template <class X>
+ARCLE_BIG_DEV void emit_rows(const X& x, const int8_t* r, uint32_t flags, int reward, int term, int cnt0, int cnt1, bool truncated,
                              uint32_t st) {
   const BigParams& p = x.p;
   // (entered behind a barrier: nobody is still reading the LDS tail area)
@@ -491,7 +519,8 @@ ARCLE_BIG_DEV void emit_rows(const Ctx& x, const int8_t* r, uint32_t flags, int 
 
 // ---- FloodFill (color.py:88-100, dfs :8-30): 4-connected region of (sx, sy) among the cells of the gh x gw grid that hold its colour.
 // The grid is staged in A.  Iterative propagation is equivalent to the reference's DFS (the visited set does not depend on the order).
-ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int colour) {
+template <class X>
+ARCLE_BIG_DEV void flood_fill(const X& x, int gh, int gw, int sx, int sy, int colour) {
   const int W = x.W, H = x.H;
   const int col = x.A[sx * W + sy];
   B128* const E = reinterpret_cast<B128*>(x.Eb);
@@ -571,7 +600,7 @@ ARCLE_BIG_DEV void flood_fill(const Ctx& x, int gh, int gw, int sx, int sy, int 
     if (!x.red->flag[pass % 3]) break;
   }
   // the region takes the colour: chunks of the staged grid, rewritten where the board has a bit
-  for (int c = x.tid; c < x.nch; c += x.NT) {
+  BIG_EACH_CHUNK(x, c) {
     bool any = false;
     const Chunk o = build_chunk(c, W, x.P, [&](int f, int i, int j) {
       const B128 fr = F[i];
@@ -653,7 +682,8 @@ ARCLE_BIG_DEV Chunk gather_affine16(const int8_t* tile, int c, int W, int P, int
 }
 
 // Copy / CropGrid (W >= 16): chunk c of the h x w tile whose cell (i, j) is plane A's cell (x0 + i, y0 + j) where the selection S is non-zero
-ARCLE_BIG_DEV Chunk cut_out16(const Ctx& x, int c, int x0, int y0, int h, int w) {
+template <class X>
+ARCLE_BIG_DEV Chunk cut_out16(const X& x, int c, int x0, int y0, int h, int w) {
   const int delta = x0 * x.W + y0;
   const Chunk sv = shifted16(x.S, 16 * c + delta, x.PS), av = shifted16(x.A, 16 * c + delta, x.PS);
   const Chunk in = rect_mask16(c, x.W, 0, h, 0, w);
@@ -668,7 +698,8 @@ ARCLE_BIG_DEV Chunk cut_out16(const Ctx& x, int c, int x0, int y0, int h, int w)
 // `cut`: nullptr when `bg` is the background itself; else `bg` is the grid and the background is where(cut > 0, 0, grid) (object.py:87-88).
 // `lift_delta` >= 0 (W >= 16, a fresh selection that is only MOVED): there are no object tiles — the object is the grid `bg` under the
 // selection `cut`, read at the lift's flat shift on top of the placement's: one gather pass instead of lift + barrier + place.
-ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q,
+template <class X>
+ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q,
                          int lift_delta = -1) {
   const int W = x.W;
   const int px = r[ARCLE_REC_OBJECT_POS], py = r[ARCLE_REC_OBJECT_POS + 1];
@@ -677,9 +708,9 @@ ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const 
   const int xh = i8w(px + h), yw = i8w(py + w);  // int8 + int8
   const bool draw = xh > 0 && px < gh && yw > 0 && py < gw;
   const int stx = imax(px, 0), edx = imin(gh, xh), sty = imax(py, 0), edy = imin(gw, yw);
-  if (W >= 16) {  // whole chunks: the object tile read at the flat shift -(px * W + py), the destination rectangle as a byte mask
+  if (x.wide()) {  // whole chunks: the object tile read at the flat shift -(px * W + py), the destination rectangle as a byte mask
     const int d2 = px * W + py;
-    for (int c = x.tid; c < x.nch; c += x.NT) {
+    BIG_EACH_CHUNK(x, c) {
       const Chunk bgc = ldg(bg, c);
       Chunk pv, qv;
       if (lift_delta >= 0) {
@@ -710,7 +741,7 @@ ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const 
     }
     return;
   }
-  for (int c = x.tid; c < x.nch; c += x.NT) {
+  BIG_EACH_CHUNK(x, c) {
     Chunk sel = zero_chunk();
     const Chunk bgc = ldg(bg, c);
     const Chunk cutc = cut ? ldg(cut, c) : zero_chunk();
@@ -732,20 +763,28 @@ ARCLE_BIG_DEV void place(const Ctx& x, const int8_t* r, const int8_t* bg, const 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // one step() of one env: O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step (arcenv.py:155-172) / RawARCEnv.step (arcenv.py:60-76)
 // ------------------------------------------------------------------------------------------------------------------------------------
-ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
-  const Ctx x(p, env, lds);
-  const int tid = x.tid, NT = x.NT, H = x.H, W = x.W, P = x.P, nch = x.nch;
+// X = CtxT<ONE, LEAN> (what the launch guarantees, see there); ING: -1 = the ingress form is p.ingress whatever it is, ING_T_MASKS = one of
+// the mask forms (int8 / bit-packed), ING_T_TUPLES = one of the tuple forms (bbox / point / bbox5) — the other family's code is not compiled.
+enum { ING_T_ANY = -1, ING_T_MASKS = 0, ING_T_TUPLES = 1 };
+template <class X, int ING>
+ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
+  const X x(p, env, lds);
+  const int tid = x.tid, H = x.H, W = x.W, P = x.P, nch = x.nch;
   Chunk rc = ldg(p.rec, env);
   int8_t* const r = rc.b;
   int cnt0 = p.cnt[2 * (size_t)env], cnt1 = p.cnt[2 * (size_t)env + 1];
-  const uint32_t flags = p.flags;
+  const uint32_t flags = X::LEAN ? (p.flags & (uint32_t)LEAN_FLAGS) : p.flags;
+  const bool mask_ingress = ING == ING_T_ANY ? (p.ingress == ING_MASK || p.ingress == ING_BITS) : ING == ING_T_MASKS;
+  const bool scratch_rows = !X::LEAN && p.res_rec != nullptr;  // arcle_transition_rows: the envs are scratch envs, one per row
+  const bool accounting = !X::LEAN && p.acct != nullptr;
   int reward = 0, submit_inc = 0;
   uint32_t st = 0;
   bool counted = false;  // the step happened: action_steps += 1
   int opi = 0;
   // ---- the action's scalars ----
   int pay[5] = {0, 0, 0, 0, 0};
-  if (p.ingress == ING_BBOX) {
+  if (mask_ingress) {
+  } else if (p.ingress == ING_BBOX) {
     for (int k = 0; k < 4; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[4 * (size_t)env + k];
   } else if (p.ingress == ING_POINT) {
     for (int k = 0; k < 2; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[2 * (size_t)env + k];
@@ -753,7 +792,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     for (int k = 0; k < 5; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[5 * (size_t)env + k];
   }
   // (workgroup-uniform by construction; telling the compiler so turns the dependent op-table read into a scalar load)
-  opi = bx::uniform(p.ingress == ING_BBOX5 ? pay[4] : p.op[env]);
+  opi = bx::uniform(!mask_ingress && p.ingress == ING_BBOX5 ? pay[4] : p.op[env]);
   if (tid == 0) {
     Red* q = x.red;
     q->any_nz = q->any_pos = q->sum = 0;
@@ -765,7 +804,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
   bx::sync();  // every thread holds the record / counters; the reduction block is clear
 
   do {
-    if (p.res_rec) {  // arcle_transition_rows: a row whose src_env names no resident env is passed through untouched
+    if (scratch_rows) {  // arcle_transition_rows: a row whose src_env names no resident env is passed through untouched
       const int src = p.src_env ? p.src_env[env] : env;
       if (src < 0 || src >= p.n_resident) {
         st |= ARCLE_ST_BAD_TASK;
@@ -809,9 +848,9 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     int staged = -1;  // the plane A holds (arcle_plane) once the ingest barrier has passed
     bool staged_obj = false;  // ... and B / C hold the stored object / object_sel
     {
-      const bool tuple = p.ingress != ING_MASK && p.ingress != ING_BITS;
+      const bool tuple = !mask_ingress;
       bool tuple_any = false;
-      if (p.ingress == ING_POINT) tuple_any = (uint32_t)pay[0] < (uint32_t)H && (uint32_t)pay[1] < (uint32_t)W;
+      if (tuple && p.ingress == ING_POINT) tuple_any = (uint32_t)pay[0] < (uint32_t)H && (uint32_t)pay[1] < (uint32_t)W;
       else if (tuple) tuple_any = (uint32_t)imin(pay[0], pay[2]) < (uint32_t)H && (uint32_t)imin(pay[1], pay[3]) < (uint32_t)W;
       const bool will_be_active = (oflags & ARCLE_OPF_RESET_SEL) ? false : r[ARCLE_REC_ACTIVE] != 0;
       switch (kind) {
@@ -840,16 +879,16 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     // ---- selection -> S (bytes in LDS) + its reductions -------------------------------------------------------------------------
     bool any_nz, any_pos;
     int ssum, x0, x1, y0, y1, amax_cell;
-    if (p.ingress == ING_MASK || p.ingress == ING_BITS) {
+    if (mask_ingress) {
       const bool packed = p.ingress == ING_BITS;  // boolean masks, bit f of the env's row of PS / 8 bytes = cell f
       const int8_t* const src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)env * (size_t)(packed ? x.PS >> 3 : P);
       const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
       int l_nz = 0, l_pos = 0, l_sum = 0, lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
       uint32_t l_amax = 0;
-      for (int c = tid; c < nch; c += NT) {
+      BIG_EACH_CHUNK(x, c) {
         Chunk v = zero_chunk();
         const int f0 = 16 * c;
-        x.io++;  // (the mask chunk: 16 bytes, or 2 of a bit row — counted as a chunk)
+        x.count();  // (the mask chunk: 16 bytes, or 2 of a bit row — counted as a chunk)
         if (packed) {
           const uint32_t m = (uint32_t)(uint8_t)src[2 * c] | ((uint32_t)(uint8_t)src[2 * c + 1] << 8);
 #pragma unroll
@@ -913,7 +952,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         // the O2ARC trace harness (tests/o2arc_check.py:169-170): an object op whose logged selection equals the env's current
         // `selected` plane continues the active object, i.e. is sent with an empty selection
         bool differs = false;
-        for (int c = tid; c < nch; c += NT) {
+        BIG_EACH_CHUNK(x, c) {
           const Chunk a = x.gl(ARCLE_PL_SELECTED, c), b = ldg(x.S, c);
           differs |= ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) != 0;
         }
@@ -948,15 +987,15 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         any = (uint32_t)xa < (uint32_t)H && (uint32_t)ya < (uint32_t)W;
         if (!any && (xa | ya) < 0) st |= ARCLE_ST_BAD_SELECTION;
       }
-      if (W >= 16) {
-        for (int c = tid; c < nch; c += NT) {
+      if (x.wide()) {
+        BIG_EACH_CHUNK(x, c) {
           Chunk m = any ? rect_mask16(c, W, xa, xb + 1, ya, yb + 1) : zero_chunk();
 #pragma unroll
           for (int q = 0; q < 4; q++) m.w[q] &= 0x01010101u;
           stg(x.S, c, m);
         }
       } else
-      for (int c = tid; c < nch; c += NT)
+      BIG_EACH_CHUNK(x, c)
         stg(x.S, c, build_chunk(c, W, P, [&](int, int i, int j) { return (any && i >= xa && i <= xb && j >= ya && j <= yb) ? 1 : 0; }));
       any_nz = any_pos = any;
       ssum = any ? (xb - xa + 1) * (yb - ya + 1) : 0;
@@ -1045,7 +1084,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
       case ARCLE_OP_COLOR: {  // color.py:70-74 — whole H x W plane, grid_dim ignored
         if (!any_nz) break;
-        for (int c = tid; c < nch; c += NT) {
+        BIG_EACH_CHUNK(x, c) {
           const Chunk s = ldg(x.S, c);
           if (!(s.w[0] | s.w[1] | s.w[2] | s.w[3])) continue;
           Chunk gr = x.gl(ARCLE_PL_GRID, c);
@@ -1073,7 +1112,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         int8_t *O = x.B, *Q = x.C;  // object / object_sel tiles
         bool bg_in_A = false;        // A holds the background itself (else: the grid, and the background is where(sel > 0, 0, grid))
         const bool transform = kind != ARCLE_OP_MOVE;
-        if (fresh && W >= 16) {
+        if (fresh && x.wide()) {
           // A fresh selection, whole chunks (object.py:67-99 fused with the op): the lifted object is the grid under the selection at the flat
           // shift delta = x0 * W + y0, so nothing is lifted into tiles first.  Move: the three object planes are formed straight from A / S
           // and place() reads A / S at the combined shift — ONE gather pass.  Rotate / Flip: the transformed tiles are gathered straight
@@ -1094,7 +1133,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             const int dy = (arg == 2) ? 1 : (arg == 3) ? -1 : 0;
             r[ARCLE_REC_OBJECT_POS] = (int8_t)i8w(x0 + dx);  // :238, int8 wrap
             r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)i8w(y0 + dy);
-            for (int c = tid; c < nch; c += NT) {
+            BIG_EACH_CHUNK(x, c) {
               const Chunk sv = shifted16(x.S, 16 * c + delta, x.PS), av = shifted16(x.A, 16 * c + delta, x.PS);
               const Chunk in = rect_mask16(c, W, 0, oh, 0, ow);
               Chunk ob, qs, gr = ldg(x.A, c);
@@ -1112,7 +1151,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             }
             place(x, r, x.A, x.S, nullptr, nullptr, delta);
           } else {
-            for (int c = tid; c < nch; c += NT) {
+            BIG_EACH_CHUNK(x, c) {
               const Chunk gs_ = gather_affine16(x.S, c, W, P, nh, nw, c0 + delta, ai, bj), ga = gather_affine16(x.A, c, W, P, nh, nw, c0 + delta, ai, bj);
               Chunk ob, qs;
 #pragma unroll
@@ -1132,7 +1171,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               r[ARCLE_REC_PARITY] = (int8_t)npar;
             }
             bx::sync();
-            for (int c = tid; c < nch; c += NT) {
+            BIG_EACH_CHUNK(x, c) {
               Chunk gr = ldg(x.A, c);
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
@@ -1151,7 +1190,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             x.stage_g(x.A, ARCLE_PL_GRID);
             bx::sync();
           }
-          for (int c = tid; c < nch; c += NT) {
+          BIG_EACH_CHUNK(x, c) {
             Chunk qs = zero_chunk();
             // (every gather below reads LDS UNCONDITIONALLY at a clamped index and selects afterwards: the 16 cells' reads are then
             // independent and issue back to back — reads under a branch wait for one another, profiles/round5_experiments.txt §15)
@@ -1189,7 +1228,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           r[ARCLE_REC_OBJECT_POS] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS] + dx);  // :238, int8 wrap
           r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)i8w(r[ARCLE_REC_OBJECT_POS + 1] + dy);
           if (fresh) {  // the lifted tiles and the background go out now, behind the last barrier (this thread's own chunks)
-            for (int c = tid; c < nch; c += NT) {
+            BIG_EACH_CHUNK(x, c) {
               x.gs(ARCLE_PL_OBJECT, c, ldg(x.B, c));
               x.gs(ARCLE_PL_OBJECT_SEL, c, ldg(x.C, c));
               Chunk gr = ldg(x.A, c);  // background = where(sel > 0, 0, grid)  :87-88; place() forms it again from A and S
@@ -1202,7 +1241,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         } else {
           // dst[:nh,:nw] = T(src[:h,:w]), rest 0 (_pad_assign, object.py:43-47): object B -> S, then object_sel C -> B.  A thread
           // overwrites S only at its OWN chunks, after it has formed the background of those chunks from them (fresh selections).
-          for (int c = tid; c < nch; c += NT) {
+          BIG_EACH_CHUNK(x, c) {
             if (fresh) {  // background = where(sel > 0, 0, grid)  :87-88, into A in place (the lift is done with the grid)
               Chunk gr = ldg(x.A, c);
               const Chunk sm = ldg(x.S, c);
@@ -1210,7 +1249,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
               for (int q = 0; q < 4; q++) gr.w[q] &= ~pos_bytes(sm.w[q]);
               stg(x.A, c, gr);
             }
-            const Chunk t = W >= 16 ? gather_affine16(x.B, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
+            const Chunk t = x.wide() ? gather_affine16(x.B, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int8_t v = x.B[in ? c0 + ai * i + bj * j : 0];
               return in ? v : (int8_t)0;
@@ -1219,8 +1258,8 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
           }
           bg_in_A = true;
           bx::sync();
-          for (int c = tid; c < nch; c += NT) {
-            const Chunk t = W >= 16 ? gather_affine16(x.C, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
+          BIG_EACH_CHUNK(x, c) {
+            const Chunk t = x.wide() ? gather_affine16(x.C, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int8_t v = x.C[in ? c0 + ai * i + bj * j : 0];
               return in ? v : (int8_t)0;
@@ -1237,7 +1276,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             r[ARCLE_REC_PARITY] = (int8_t)npar;
           }
           bx::sync();
-          for (int c = tid; c < nch; c += NT) {  // the transformed tiles (and a fresh background) go out behind the last barrier
+          BIG_EACH_CHUNK(x, c) {  // the transformed tiles (and a fresh background) go out behind the last barrier
             if (fresh) x.gs(ARCLE_PL_BACKGROUND, c, ldg(x.A, c));
             x.gs(ARCLE_PL_OBJECT, c, ldg(x.S, c));
             x.gs(ARCLE_PL_OBJECT_SEL, c, ldg(x.B, c));
@@ -1254,10 +1293,10 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         if (x1 > ss_h || y1 > ss_w) break;  // :301 (sic: > not >=)
         const int h = x1 - x0 + 1, w = y1 - y0 + 1;
         // (the source plane is in A)
-        if (W >= 16) {
-          for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_CLIP, c, cut_out16(x, c, x0, y0, h, w));  // :310-312 where=logical_and(src, sel)
+        if (x.wide()) {
+          BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_CLIP, c, cut_out16(x, c, x0, y0, h, w));  // :310-312 where=logical_and(src, sel)
         } else
-        for (int c = tid; c < nch; c += NT)
+        BIG_EACH_CHUNK(x, c)
           x.gs(ARCLE_PL_CLIP, c, build_chunk(c, W, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
                 const int s = in ? (x0 + i) * W + (y0 + j) : 0;
@@ -1275,9 +1314,10 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const int ex = imin(x0 + h, H), ey = imin(y0 + w, W);  // :340-341 clipped to H x W, not grid_dim
         // (the clip plane is in A)
         const int c_first = (x0 * W) >> 4, c_last = imin(nch - 1, (ex * W) >> 4);
-        if (W >= 16) {  // whole chunks: the clip read at the flat shift -(x0 * W + y0), the pasted rectangle as a byte mask
+        if (x.wide()) {  // whole chunks: the clip read at the flat shift -(x0 * W + y0), the pasted rectangle as a byte mask
           const int d2 = x0 * W + y0;
-          for (int c = c_first + tid; c <= c_last; c += NT) {
+          BIG_EACH_CHUNK(x, c) {
+            if (c < c_first || c > c_last) continue;
             Chunk gr = x.gl(ARCLE_PL_GRID, c);
             const Chunk pv = shifted16(x.A, 16 * c - d2, x.PS), in = rect_mask16(c, W, x0, ex, y0, ey);
 #pragma unroll
@@ -1288,7 +1328,8 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
             x.gs(ARCLE_PL_GRID, c, gr);
           }
         } else
-        for (int c = c_first + tid; c <= c_last; c += NT) {
+        BIG_EACH_CHUNK(x, c) {
+            if (c < c_first || c > c_last) continue;
           const Chunk gr = x.gl(ARCLE_PL_GRID, c);
           x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int f, int i, int j) {
                 const bool in = i >= x0 && i < ex && j >= y0 && j < ey;
@@ -1299,18 +1340,18 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         break;
       }
       case ARCLE_OP_COPY_FROM_INPUT: {  // critical.py:28-29
-        for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, x.gl(ARCLE_PL_INPUT, c));
+        BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_GRID, c, x.gl(ARCLE_PL_INPUT, c));
         r[ARCLE_REC_GRID_DIM] = r[ARCLE_REC_INPUT_DIM];
         r[ARCLE_REC_GRID_DIM + 1] = r[ARCLE_REC_INPUT_DIM + 1];
         break;
       }
       case ARCLE_OP_RESET_GRID: {  // critical.py:17
-        for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, zero_chunk());
+        BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_GRID, c, zero_chunk());
         break;
       }
       case ARCLE_OP_RESIZE_GRID: {  // critical.py:39-46
         if (!any_nz) break;
-        for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, zero_chunk());
+        BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_GRID, c, zero_chunk());
         r[ARCLE_REC_GRID_DIM] = (int8_t)(x1 - x0 + 1);
         r[ARCLE_REC_GRID_DIM + 1] = (int8_t)(y1 - y0 + 1);
         break;
@@ -1318,10 +1359,10 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       case ARCLE_OP_CROP_GRID: {  // critical.py:56-66
         if (!any_nz) break;
         const int h = x1 - x0 + 1, w = y1 - y0 + 1;  // (the grid is in A)
-        if (W >= 16) {
-          for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_GRID, c, cut_out16(x, c, x0, y0, h, w));
+        if (x.wide()) {
+          BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_GRID, c, cut_out16(x, c, x0, y0, h, w));
         } else
-        for (int c = tid; c < nch; c += NT)
+        BIG_EACH_CHUNK(x, c)
           x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
                 const int s = in ? (x0 + i) * W + (y0 + j) : 0;
@@ -1336,7 +1377,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         const int ah = r[ARCLE_REC_ANSWER_DIM], aw = r[ARCLE_REC_ANSWER_DIM + 1];
         r[ARCLE_REC_GRID_DIM] = (int8_t)ah;
         r[ARCLE_REC_GRID_DIM + 1] = (int8_t)aw;
-        for (int c = tid; c < nch; c += NT) {
+        BIG_EACH_CHUNK(x, c) {
           const Chunk gr = x.gl(ARCLE_PL_GRID, c);
           x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int f, int i, int j) { return (i < ah && j < aw) ? gr.b[f & 15] : (int8_t)0; }));
         }
@@ -1368,9 +1409,9 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
         break;
     }
     if (sel_pending == 2) {
-      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, ldg(x.S, c));
+      BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_SELECTED, c, ldg(x.S, c));
     } else if (sel_pending == 1) {
-      for (int c = tid; c < nch; c += NT) x.gs(ARCLE_PL_SELECTED, c, zero_chunk());
+      BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_SELECTED, c, zero_chunk());
     }
 
     // reward(): only the LAST op of the table can be rewarded (o2arcenv.py:121-128)
@@ -1401,7 +1442,8 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
       bx::sync();  // (also: every plane store of the step is visible to the workgroup)
       int mine = 0;
       const int lastc = imin(nch, (imax(mh, 0) * W + 15) >> 4);
-      for (int c = tid; c < lastc; c += NT) {
+      BIG_EACH_CHUNK(x, c) {
+        if (c >= lastc) break;
         const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
         int f = 16 * c;
         int i = f / W, j = f - i * W;
@@ -1428,7 +1470,7 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
   }
   const int term = r[ARCLE_REC_TERMINATED] != 0;
   const bool truncated = (flags & ARCLE_STEP_TRUNCATE) && cnt0 >= p.step_limit;
-  if (p.acct) {
+  if (accounting) {
     // byte accounting (arcle_enable_accounting): every 16-byte access of the step the threads counted, + the env's scalars (record in / out,
     // counters, action, outputs).  "issued" = those bytes; the other figure leaves the row padding out (chunks x 16 x P / PS).  Rows written
     // by the FLAT_OBS / PACK_OBS epilogue below are not in it (as in the one-wavefront kernels, where the host adds them per launch).
@@ -1456,6 +1498,9 @@ ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) {
     emit_rows(x, r, flags, reward, term, cnt0, cnt1, truncated, st);
   }
 }
+
+// the generic form: every run-time parameter honoured (tuning launches, transition_rows, accounting, the row epilogues, the emulator)
+ARCLE_BIG_DEV void step_env(const BigParams& p, const int env, int8_t* lds) { step_env_t<Ctx, ING_T_ANY>(p, env, lds); }
 
 // ---- reset kernels (one workgroup per env) ---------------------------------------------------------------------------------------------
 // mode 0: arcle_reset (init_state from PL_INPUT / REC_INPUT_DIM); 1: arcle_reset_from_table (task_idx); 2: arcle_reset_sampled
@@ -1515,7 +1560,7 @@ ARCLE_BIG_DEV void rows_env(const BigParams& p, int env, int mode, int8_t* lds) 
   if (mode == 2) {  // arcle_pack_mask_bits: int8 [N][P] masks (truthy = non-zero) -> bit rows of PS / 8 bytes (p.pack_out)
     const int8_t* const src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)env * (size_t)x.P;
     uint8_t* const dst = p.pack_out + (size_t)env * (size_t)(x.PS >> 3);
-    for (int c = x.tid; c < x.nch; c += x.NT) {
+    BIG_EACH_CHUNK(x, c) {
       uint32_t m = 0;
 #pragma unroll
       for (int k = 0; k < 16; k++)
@@ -1541,7 +1586,7 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
     int src = p.src_env ? p.src_env[env] : env;
     if (src < 0 || src >= p.n_resident) src = 0;  // (the step launch flags the row and skips it)
     rc = ldg(p.res_rec, src);
-    for (int c = x.tid; c < x.nch; c += x.NT) x.gs(ARCLE_PL_ANSWER, c, ldg(p.res_answer + (size_t)src * x.PS, c));
+    BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_ANSWER, c, ldg(p.res_answer + (size_t)src * x.PS, c));
     if (x.tid == 0) p.cnt[2 * (size_t)env] = p.cnt[2 * (size_t)env + 1] = 0;
   }
   if (x.tid == 0) {
@@ -1557,7 +1602,7 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
         for (int k = 0; k < sg.len; k++) x.sc[sg.soff + k] = row[sg.start + k];
     } else {
       const int8_t* const src = row + sg.start;
-      for (int c = x.tid; c < x.nch; c += x.NT) {
+      BIG_EACH_CHUNK(x, c) {
         Chunk v = zero_chunk();
         const int f0 = 16 * c;
         if (f0 + 16 <= x.P) {
@@ -1567,7 +1612,7 @@ ARCLE_BIG_DEV void set_rows_env(const BigParams& p, int env, int8_t* lds) {
           for (int k = 0; k < 16; k++)
             if (f0 + k < x.P) v.b[k] = src[f0 + k];
         }
-        x.io++;  // (the row bytes read)
+        x.count();  // (the row bytes read)
         x.gs(sg.plane, c, v);
       }
     }

@@ -41,6 +41,12 @@ extern __shared__ __attribute__((aligned(16))) int8_t arcle_big_lds[];
 __global__ __launch_bounds__(BIG_THREADS) void arcle_big_step_kernel(const BigParams p) {
   arcle_big::step_env(p, (int)blockIdx.x, arcle_big_lds);
 }
+// The LEAN instantiations (arcle_big.h CtxT): the launch's flag set lies within LEAN_FLAGS, W >= 16, no accounting, no scratch rows; ONE: at
+// least one thread per plane chunk.  What ARCVecEnv's plain step calls run; everything else takes the generic kernel above.
+template <bool ONE, int ING>
+__global__ __launch_bounds__(arcle_big::LEAN_THREADS) void arcle_big_step_lean(const BigParams p) {
+  arcle_big::step_env_t<arcle_big::CtxT<ONE, true>, ING>(p, (int)blockIdx.x, arcle_big_lds);
+}
 __global__ __launch_bounds__(BIG_THREADS) void arcle_big_reset_kernel(const BigParams p, int mode) {
   arcle_big::reset_env(p, (int)blockIdx.x, mode, arcle_big_lds);
 }
@@ -87,10 +93,36 @@ static unsigned threads_for(int PS) {
 
 int workgroup_threads(int PS) { return (int)threads_for(PS); }
 
+template <int ID, bool ONE, int ING>
+static int launch_lean(const BigParams& p, unsigned nt, int lds, void* stream) {
+  if (int rc = allow_lds<ID>(arcle_big_step_lean<ONE, ING>, lds)) return rc;
+  hipLaunchKernelGGL((arcle_big_step_lean<ONE, ING>), dim3((unsigned)p.n_envs), dim3(nt), (size_t)lds, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
+// ARCLE_BIG_GENERIC=1: every step launch takes the generic kernel (A/B runs)
+static bool lean_allowed() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("ARCLE_BIG_GENERIC");
+    v = (s && atoi(s)) ? 0 : 1;
+  }
+  return v != 0;
+}
+
 int launch_step(const BigParams& p, void* stream) {
   const int lds = lds_bytes(p.PS, p.H);
+  const unsigned nt = threads_for(p.PS);
+  const bool lean = lean_allowed() && !(p.flags & ~(uint32_t)LEAN_FLAGS) && p.W >= 16 && !p.res_rec && !p.acct && nt <= (unsigned)LEAN_THREADS;
+  if (lean) {
+    const bool one = (unsigned)(p.PS >> 4) <= nt;
+    const bool masks = p.ingress == ING_MASK || p.ingress == ING_BITS;
+    if (one) return masks ? launch_lean<4, true, ING_T_MASKS>(p, nt, lds, stream) : launch_lean<5, true, ING_T_TUPLES>(p, nt, lds, stream);
+    if (nt == (unsigned)LEAN_THREADS)
+      return masks ? launch_lean<6, false, ING_T_MASKS>(p, nt, lds, stream) : launch_lean<7, false, ING_T_TUPLES>(p, nt, lds, stream);
+  }
   if (int rc = allow_lds<0>(arcle_big_step_kernel, lds)) return rc;
-  hipLaunchKernelGGL(arcle_big_step_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(arcle_big_step_kernel, dim3((unsigned)p.n_envs), dim3(nt), (size_t)lds, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 int launch_reset(const BigParams& p, int mode, void* stream) {

@@ -462,6 +462,8 @@ class BigEmuBackend(EmuBackend):
     """arcle_big.h (one workgroup per env; H * W > 1024) on host threads.  Same surface as EmuBackend where the big path has the feature."""
     name = "bigemu"
     THREADS = 16  # the emulated workgroup (the product launches 128-512: every loop of the body is strided by the thread count)
+    LEAN, ONE = True, False
+    LEAN_FLAGS = 1 | 2 | 4 | 8 | 64  # arcle_big.h LEAN_FLAGS: AUTORESET | ELIDE_SELECTED | TRUNCATE | RESAMPLE | RESET_ON_SUBMIT
 
     def _params(self):
         p = _BigParams()
@@ -503,7 +505,7 @@ class BigEmuBackend(EmuBackend):
             p.flat_seq = int(getattr(self, "_flat_seq", 0))
 
     def _run(self, what, p, mode=0):
-        rc = big_emu_lib().big_emu_run(what, ctypes.byref(p), mode, self.THREADS)
+        rc = big_emu_lib().big_emu_run(what, ctypes.byref(p), mode, max(self.THREADS, (self.PS // 16 + 15) & ~15) if self.ONE else self.THREADS)
         assert rc == 0, f"big-grid emulator reported error {rc}"
 
     def reset(self, mask=None):
@@ -556,7 +558,14 @@ class BigEmuBackend(EmuBackend):
             pay = np.ascontiguousarray(payload, np.int32)
         opa = np.ascontiguousarray(op if op is not None else np.zeros(self.N), np.int32)
         p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
-        self._run(0, p)
+        # the instantiation the product's launcher would pick (arcle_big.hip launch_step): LEAN when the flag set, the plane width and
+        # the launch allow it — with ONE thread per chunk in BigEmuOneBackend —, the generic body otherwise
+        lean = self.LEAN and not (flags & ~self.LEAN_FLAGS) and self.W >= 16 and not getattr(self, "count_bytes", False)
+        self.lean_steps = getattr(self, "lean_steps", 0) + int(bool(lean))
+        if lean:
+            self._run(4, p, 1 if self.ONE else 0)
+        else:
+            self._run(0, p)
         return self.reward.copy(), self.term.copy()
 
     def pack_mask_bits(self, masks):
@@ -620,6 +629,19 @@ class BigEmuBackend(EmuBackend):
         p.flat_out, p.flat_stride, p.flat_filter, p.flat_tail = out.ctypes.data, out.shape[1], 0, int(tail)
         self._run(0, p)
         return out, reward, term
+
+
+class BigEmuGenericBackend(BigEmuBackend):
+    """... every step through the generic instantiation (what tuning launches, accounting and transition_rows run)."""
+    name = "bigemu_generic"
+    LEAN = False
+
+
+class BigEmuOneBackend(BigEmuBackend):
+    """... with at least one host thread per plane chunk: the one-chunk-per-thread LEAN instantiation (every plane of up to 8192 cells on
+    the GPU).  Hundreds of host threads behind a pthread barrier: small cases only."""
+    name = "bigemu_one"
+    ONE = True
 
 
 # ---- HIP (the product, through arcle_amd.engine -> libarcle_hip.so C ABI) ------------------------------
@@ -782,7 +804,7 @@ BACKENDS = {"oracle": OracleBackend, "emu": EmuBackend, "hip": HipBackend}
 # ---- golden fixtures ------------------------------------------------------------------------------------
 def fixture_names():
     """Trace fixtures of tests/golden/make_golden.py (research.npz has its own layout, tests/features.py)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "research.npz" and not f.startswith("big_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f not in ("research.npz", "api_edge.npz") and not f.startswith("big_"))
 
 
 def big_fixture_names():

@@ -11,6 +11,7 @@
 
 #define ARCLE_BIG_DEV inline
 #define ARCLE_BIG_HD
+#define ARCLE_BIG_LEAN_THREADS 16  // the LEAN instantiations with several chunks per thread take their workgroup size as a constant
 #define ARCLE_BIG_ROWS 8  // board rows per thread of the flood fill: 127 rows over the 16 threads of the emulated workgroup
 
 namespace bx {
@@ -56,9 +57,15 @@ using arcle_big::BigParams;
 extern "C" int big_emu_params_size(void) { return (int)sizeof(BigParams); }
 extern "C" int big_emu_lds_bytes(int PS, int H) { return arcle_big::lds_bytes(PS, H); }
 
-// what: 0 step, 1 reset (mode 0 / 1 / 2), 2 rows out (mode 0 flat / 1 packed), 3 state rows in
+// what: 0 step (generic instantiation), 1 reset (mode 0 / 1 / 2), 2 rows out (mode 0 flat / 1 packed), 3 state rows in,
+//       4 step, the LEAN instantiation the product launches for this ingress family (mode 1: the one-chunk-per-thread form)
 extern "C" int big_emu_run(int what, const BigParams* p, int mode, int nthreads) {
   if (nthreads < arcle_big::MIN_THREADS || p->PS > arcle_big::MAX_PS) return -1;
+  if (what == 4) {  // what the launcher checks before it picks a LEAN kernel (arcle_big.hip lean_ok)
+    if ((p->flags & ~(uint32_t)arcle_big::LEAN_FLAGS) || p->W < 16 || p->res_rec || p->acct) return -3;
+    if (mode == 1 ? (p->PS >> 4) > nthreads : nthreads != arcle_big::LEAN_THREADS) return -4;
+  }
+  const bool masks = p->ingress == arcle_big::ING_MASK || p->ingress == arcle_big::ING_BITS;
   void* lds = nullptr;
   if (posix_memalign(&lds, 64, (size_t)arcle_big::lds_bytes(p->PS, p->H))) return -2;
   memset(lds, 0x5a, (size_t)arcle_big::lds_bytes(p->PS, p->H));  // LDS is not zero at kernel start
@@ -71,6 +78,15 @@ extern "C" int big_emu_run(int what, const BigParams* p, int mode, int nthreads)
       for (int env = 0; env < p->n_envs; env++) {
         switch (what) {
           case 0: arcle_big::step_env(*p, env, (int8_t*)lds); break;
+          case 4:
+            if (mode == 1) {
+              if (masks) arcle_big::step_env_t<arcle_big::CtxT<true, true>, arcle_big::ING_T_MASKS>(*p, env, (int8_t*)lds);
+              else arcle_big::step_env_t<arcle_big::CtxT<true, true>, arcle_big::ING_T_TUPLES>(*p, env, (int8_t*)lds);
+            } else {
+              if (masks) arcle_big::step_env_t<arcle_big::CtxT<false, true>, arcle_big::ING_T_MASKS>(*p, env, (int8_t*)lds);
+              else arcle_big::step_env_t<arcle_big::CtxT<false, true>, arcle_big::ING_T_TUPLES>(*p, env, (int8_t*)lds);
+            }
+            break;
           case 1: arcle_big::reset_env(*p, env, mode, (int8_t*)lds); break;
           case 2: arcle_big::rows_env(*p, env, mode, (int8_t*)lds); break;
           default: arcle_big::set_rows_env(*p, env, (int8_t*)lds); break;

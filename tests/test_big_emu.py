@@ -35,6 +35,18 @@ def test_big_emulator_random_traces_vs_oracle(H, W, kind, flags, max_trial):
     assert not errs, "\n".join(errs[:10])
 
 
+@pytest.mark.parametrize("H,W,ingress_mix", [(33, 32, True), (40, 40, False)])
+def test_big_emulator_one_chunk_per_thread_instantiation(H, W, ingress_mix):
+    """the LEAN kernel the product launches for planes of up to 8192 cells: every "my chunks" loop is a single guarded body"""
+    errs = B.random_trace_compare(B.BigEmuOneBackend, "o2arc", O.o2arc_ops(), H, W, N=3, S=40, seed=H + W, flags=3, max_trial=3, bad_ops=True)
+    assert not errs, "\n".join(errs[:10])
+
+
+def test_big_emulator_generic_instantiation_still_agrees():
+    errs = B.random_trace_compare(B.BigEmuGenericBackend, "o2arc", O.o2arc_ops(), 40, 40, N=4, S=40, seed=77, flags=3, max_trial=3, bad_ops=True)
+    assert not errs, "\n".join(errs[:10])
+
+
 def test_big_emulator_127x127():
     errs = B.random_trace_compare(B.BigEmuBackend, "o2arc", O.o2arc_ops(), 127, 127, N=3, S=30, seed=9)
     assert not errs, "\n".join(errs[:10])
