@@ -77,11 +77,15 @@ ARCLE_BIG_DEV Chunk zero_chunk() {
 }
 
 // the chunk c of a plane built cell by cell: cell(f, i, j) for the cells f = i * W + j < P of the chunk, zero behind P (row padding)
+// f / W for a cell index 0 <= f < 127 * 128 of a plane: (f * wm) >> 21 with wm = 2^21 / W + 1 (BigParams::w_magic; exact: f * (wm - 2^21 / W)
+// <= f < 2^21 / W for every W <= 127) — one 24-bit multiply and a shift instead of the ~25-instruction division by a run-time value
+ARCLE_BIG_DEV int div_w(int f, uint32_t wm) { return (int)(bx::mul24((uint32_t)f, wm) >> 21); }
+
 template <class F>
-ARCLE_BIG_DEV Chunk build_chunk(int c, int W, int P, F&& cell) {
+ARCLE_BIG_DEV Chunk build_chunk(int c, int W, uint32_t wm, int P, F&& cell) {
   Chunk o;
   int f = 16 * c;
-  int i = f / W, j = f - i * W;
+  int i = div_w(f, wm), j = f - i * W;
 #pragma unroll
   for (int k = 0; k < 16; k++, f++) {
     o.b[k] = f < P ? (int8_t)cell(f, i, j) : (int8_t)0;
@@ -158,34 +162,50 @@ ARCLE_BIG_DEV B128 spread(B128 E, B128 S) {
 }
 
 struct Layout;
+// bytes [lo, hi) of a chunk = 0xff (0 <= lo, hi <= 16; empty when hi <= lo): per byte k, k >= lo and k < hi as the top bits of two packed
+// subtractions from (k | 0x80) — no borrow crosses a byte for subtrahends <= 128 — widened to whole bytes
+ARCLE_BIG_DEV Chunk range_mask16(int lo, int hi) {
+  const uint32_t l2 = (uint32_t)lo | ((uint32_t)lo << 8), h2 = (uint32_t)hi | ((uint32_t)hi << 8);
+  const uint32_t l = l2 | (l2 << 16), h = h2 | (h2 << 16);  // the bound in every byte (two shift-or each)
+  Chunk o;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t t = 0x83828180u + 0x04040404u * (uint32_t)q;
+    const uint32_t m = (((t - l) & ~(t - h)) & 0x80808080u) >> 7;
+    o.w[q] = (m << 8) - m;
+  }
+  return o;
+}
 // Flag bits the LEAN instantiations of the step kernel may see at run time (every other bit is known to be clear when the launcher picks
 // them, so the code behind it folds away): the flag sets ARCVecEnv steps with when no row epilogue, dense reward or trace rule is on.
 enum : uint32_t { LEAN_FLAGS = ARCLE_STEP_AUTORESET | ARCLE_STEP_ELIDE_SELECTED | ARCLE_STEP_RESAMPLE | ARCLE_STEP_TRUNCATE | ARCLE_STEP_RESET_ON_SUBMIT };
-#ifndef ARCLE_BIG_LEAN_THREADS
-#define ARCLE_BIG_LEAN_THREADS 512  // (the emulator runs its workgroups on 16 host threads)
-#endif
-enum { LEAN_THREADS = ARCLE_BIG_LEAN_THREADS };  // workgroup size of a LEAN launch whose planes have more chunks than that (ONE_ = false)
-
-// The per-workgroup context.  ONE_: the launch has at least one thread per 16-byte chunk of a plane (PS / 16 <= workgroup size: every
-// plane of up to 8192 cells with the workgroup sizes threads_for picks) — every "my chunks" loop is then a single guarded body, no
-// induction variable, no back edge.  LEAN_: compile-time knowledge of the launch — flags within LEAN_FLAGS, W >= 16, no byte accounting, no
-// transition_rows scratch envs (and, with ONE_ false, exactly LEAN_THREADS threads).  CtxT<false, false> is the generic form: every
-// run-time parameter honoured (the reset / row kernels, the emulator, tuning launches).
-template <bool ONE_, bool LEAN_>
+// The per-workgroup context.  CPT_ > 0: the launch has at most CPT_ 16-byte chunks of a plane per thread (PS / 16 <= CPT_ x workgroup size)
+// — every "my chunks" loop is then CPT_ guarded bodies in a row, no induction variable, no back edge; CPT_ = 0: a run-time loop.  LEAN_:
+// compile-time knowledge of the launch — flags within LEAN_FLAGS, W >= 16, no byte accounting, no transition_rows scratch envs.
+// CtxT<0, false> is the generic form: every run-time parameter honoured (the reset / row kernels, the emulator, tuning launches).
+// Why several chunks per thread at all: the step is one scalar program per env that EVERY wavefront of the workgroup executes (~280 scalar
+// instructions a wave) beside its share of the vector work, and a launch of these kernels takes about four cycles per instruction a SIMD
+// issues, of any kind (profiles/round6_experiments.txt §2) — a plane spread over half as many wavefronts runs a third fewer instructions
+// per env.
+template <int CPT_, bool LEAN_>
 struct CtxT {
-  static constexpr bool ONE = ONE_, LEAN = LEAN_;
+  static constexpr int CPT = CPT_;
+  static constexpr bool LEAN = LEAN_;
   const BigParams& p;
   int env, tid, NT, H, W, P, PS, nch;
+  uint32_t wm;  // BigParams::w_magic (div_w)
   int8_t *S, *A, *B, *C;
   Red* red;
   uint64_t *Eb, *Fb;
   int8_t* sc;   // 32 bytes of LDS: the scalar block of a row (record, reward, terminated) — indexed per byte, so not in registers
   Layout* lay;  // the row layout being written / read, in LDS for the same reason (dynamic indexing of a local array means scratch memory)
   size_t po;
+  bool sel01 = false;   // the selection tile S holds only 0 / 1 (tuple ingress: set by step_env_t; a compile-time fact of the instantiation)
   mutable uint32_t io;  // 16-byte global-memory accesses this thread issued (plane chunks, table chunks, mask chunks, row units): the
                         // byte accounting of arcle_enable_accounting — a register increment per access, summed per env when asked for
   ARCLE_BIG_DEV CtxT(const BigParams& p_, int env_, int8_t* lds)
-      : p(p_), env(env_), tid(bx::tid()), NT(LEAN_ && !ONE_ ? (int)LEAN_THREADS : bx::nt()), H(p_.H), W(p_.W), P(p_.P), PS(p_.PS), nch(p_.PS >> 4), io(0) {
+      : p(p_), env(env_), tid(bx::tid()), NT(bx::nt()), H(p_.H), W(p_.W), P(p_.P), PS(p_.PS), nch(p_.PS >> 4), wm(p_.w_magic), io(0) {
+    lds += LDS_GUARD;  // (shifted16 may read up to 16 bytes in front of a tile)
     S = lds;
     A = lds + PS;
     B = lds + 2 * PS;
@@ -206,6 +226,9 @@ struct CtxT {
     if (!LEAN_) io += k;
   }
   ARCLE_BIG_DEV bool wide() const { return LEAN_ || W >= 16; }  // whole-chunk (SWAR) forms of the geometric ops
+  // 0xff in every byte of a selection word that is > 0 / != 0 (pos_bytes / nz_bytes below; three instructions when the bytes are 0 / 1)
+  ARCLE_BIG_DEV uint32_t sel_pos(uint32_t v) const;
+  ARCLE_BIG_DEV uint32_t sel_nz(uint32_t v) const;
   ARCLE_BIG_DEV int8_t* g(int pl) const { return p.plane[pl] + po; }
   ARCLE_BIG_DEV bool has(int pl) const { return p.plane[pl] != nullptr; }
   // chunk c of a state plane of this env: load / store (counted)
@@ -218,20 +241,45 @@ struct CtxT {
     stg(p.plane[pl] + po, c, v);
   }
   // global plane -> LDS tile / fill
-  ARCLE_BIG_DEV void stage(int8_t* dst, const int8_t* src) const {
-    for (int c = tid, n_ = 0; c < nch && (!ONE_ || n_ == 0); c += NT, n_++) {
-      count();
-      stg(dst, c, ldg(src, c));
-    }
-  }
+  ARCLE_BIG_DEV void stage(int8_t* dst, const int8_t* src) const;
   ARCLE_BIG_DEV void stage_g(int8_t* dst, int pl) const { stage(dst, p.plane[pl] + po); }
-  ARCLE_BIG_DEV void fill(int8_t* dst, const Chunk& v) const {
-    for (int c = tid, n_ = 0; c < nch && (!ONE_ || n_ == 0); c += NT, n_++) stg(dst, c, v);
-  }
+  ARCLE_BIG_DEV void fill(int8_t* dst, const Chunk& v) const;
 };
-typedef CtxT<false, false> Ctx;
-// "for every chunk c of a plane that this thread owns" (c = tid, tid + NT, ...; with X::ONE at most the first)
-#define BIG_EACH_CHUNK(x, c) for (int c = (x).tid, n_##c = 0; c < (x).nch && (!(x).ONE || n_##c == 0); c += (x).NT, n_##c++)
+typedef CtxT<0, false> Ctx;
+// "for every chunk c of a plane that this thread owns" (c = tid, tid + NT, ...; with X::CPT > 0 at most that many: the loop unrolls fully.
+// Kept ROLLED — a loop of uniform trip count with the thread's guard inside — the two-chunk kernels spill fewer scalar registers but run
+// ~10 % more instructions per env and lose 3 %: profiles/round6_experiments.txt §2)
+#define BIG_EACH_CHUNK(x, c) \
+  _Pragma("unroll") for (int c = (x).tid, n_##c = 0; c < (x).nch && ((x).CPT == 0 || n_##c < (x).CPT); c += (x).NT, n_##c++)
+template <int CPT_, bool LEAN_>
+ARCLE_BIG_DEV void CtxT<CPT_, LEAN_>::stage(int8_t* dst, const int8_t* src) const {
+  // (all loads first, then the LDS writes: the chunks' round trips overlap)
+  if (CPT_ > 0) {
+    Chunk v[CPT_ > 0 ? CPT_ : 1];
+#pragma unroll
+    for (int k = 0; k < CPT_; k++) {
+      const int c = tid + k * NT;
+      if (c < nch) {
+        count();
+        v[k] = ldg(src, c);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CPT_; k++) {
+      const int c = tid + k * NT;
+      if (c < nch) stg(dst, c, v[k]);
+    }
+    return;
+  }
+  for (int c = tid; c < nch; c += NT) {
+    count();
+    stg(dst, c, ldg(src, c));
+  }
+}
+template <int CPT_, bool LEAN_>
+ARCLE_BIG_DEV void CtxT<CPT_, LEAN_>::fill(int8_t* dst, const Chunk& v) const {
+  BIG_EACH_CHUNK(*this, c) stg(dst, c, v);
+}
 
 // init_state (base.py:155-166 + o2arcenv.py:16-34 / arcenv.py:81-89): grid := input, the other state planes := 0, the record's state
 // fields; `src` = the input plane to copy (the env's own, or a task-table entry that is also written to PL_INPUT)
@@ -297,7 +345,7 @@ ARCLE_BIG_DEV bool load_task(const X& x, int8_t* r, int t, int rot_k, uint64_t p
       else if (rot_k == 3) { ai = 1; bj = -W; c0 = (h - 1) * W; nh = w; nw = h; }      // x[h-1-j, i]
       const int dpl = which ? ARCLE_PL_ANSWER : ARCLE_PL_INPUT;
       BIG_EACH_CHUNK(x, c)
-        x.gs(dpl, c, build_chunk(c, W, x.P, [&](int, int i, int j) {
+        x.gs(dpl, c, build_chunk(c, W, x.wm, x.P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int v = (uint8_t)src[in ? c0 + ai * i + bj * j : 0];
               const int pv = v < 16 ? (int)((perm >> (4 * v)) & 15u) : v;  // (cells beyond the palette keep their value)
@@ -329,7 +377,7 @@ ARCLE_BIG_DEV bool grid_equals_answer(const X& x, const int8_t* r) {
     const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
     if ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) {
       int f = 16 * c;
-      int i = f / x.W, j = f - i * x.W;
+      int i = div_w(f, x.wm), j = f - i * x.W;
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         if (i < gh && j < gw && a.b[k] != b.b[k]) differs = true;
@@ -602,7 +650,7 @@ ARCLE_BIG_DEV void flood_fill(const X& x, int gh, int gw, int sx, int sy, int co
   // the region takes the colour: chunks of the staged grid, rewritten where the board has a bit
   BIG_EACH_CHUNK(x, c) {
     bool any = false;
-    const Chunk o = build_chunk(c, W, x.P, [&](int f, int i, int j) {
+    const Chunk o = build_chunk(c, W, x.wm, x.P, [&](int f, int i, int j) {
       const B128 fr = F[i];
       const bool in = j < 64 ? ((fr.lo >> j) & 1ull) != 0 : ((fr.hi >> (j - 64)) & 1ull) != 0;
       any |= in;
@@ -620,31 +668,22 @@ ARCLE_BIG_DEV void flood_fill(const X& x, int gh, int gw, int sx, int sy, int co
 // (profiles/round5_experiments.txt §19-20).  W < 16 keeps the per-cell form.
 ARCLE_BIG_DEV Chunk shifted16(const int8_t* tile, int off, int PS) {  // bytes [off, off + 16) of the tile; bytes outside [0, PS) are unspecified
   const uint32_t* const t32 = reinterpret_cast<const uint32_t*>(tile);
-  const int d = off >> 2, sh = 8 * (off & 3), last = (PS >> 2) - 1;
+  // the five words d .. d + 4, d clamped to [-4, PS / 4]: a window with any byte inside the tile is read where it lies (its words outside the
+  // tile come from the 16 guard bytes in front of the first tile, a neighbouring tile or the block behind the last one — never from outside
+  // the workgroup's LDS), a window wholly outside is unspecified anyway.  ONE clamp and five consecutive words (paired reads).
+  const int d = imin(imax(off >> 2, -4), PS >> 2);
+  const uint32_t sh = 8u * (uint32_t)(off & 3);
   uint32_t w[5];
 #pragma unroll
-  for (int q = 0; q < 5; q++) w[q] = t32[imin(imax(d + q, 0), last)];
+  for (int q = 0; q < 5; q++) w[q] = t32[d + q];
   Chunk o;
 #pragma unroll
-  for (int q = 0; q < 4; q++) o.w[q] = (uint32_t)((((uint64_t)w[q + 1] << 32) | (uint64_t)w[q]) >> sh);
-  return o;
-}
-ARCLE_BIG_DEV uint64_t low_bytes(int n) { return n >= 8 ? ~0ull : (1ull << (8 * n)) - 1ull; }  // bytes [0, n) of a 64-bit word set, 0 <= n
-ARCLE_BIG_DEV Chunk range_mask16(int lo, int hi) {  // bytes [lo, hi) = 0xff (0 <= lo, hi <= 16; empty when hi <= lo)
-  Chunk o = zero_chunk();
-  if (hi > lo) {
-    const uint64_t a = low_bytes(hi) & ~low_bytes(lo);
-    const uint64_t b = low_bytes(imax(hi - 8, 0)) & ~low_bytes(imax(lo - 8, 0));
-    o.w[0] = (uint32_t)a;
-    o.w[1] = (uint32_t)(a >> 32);
-    o.w[2] = (uint32_t)b;
-    o.w[3] = (uint32_t)(b >> 32);
-  }
+  for (int q = 0; q < 4; q++) o.w[q] = bx::alignbit(w[q + 1], w[q], sh);  // (v_alignbit_b32: sh = 0 / 8 / 16 / 24)
   return o;
 }
 // byte mask of the cells of chunk c inside rows [r0, r1) x columns [c0, c1) (W >= 16; the rectangle lies inside the plane)
-ARCLE_BIG_DEV Chunk rect_mask16(int c, int W, int r0, int r1, int c0, int c1) {
-  const int f0 = 16 * c, i0 = f0 / W, j0 = f0 - i0 * W, n0 = imin(16, W - j0);
+ARCLE_BIG_DEV Chunk rect_mask16(int c, int W, uint32_t wm, int r0, int r1, int c0, int c1) {
+  const int f0 = 16 * c, i0 = div_w(f0, wm), j0 = f0 - i0 * W, n0 = imin(16, W - j0);
   Chunk m = zero_chunk();
   if (i0 >= r0 && i0 < r1) m = range_mask16(imin(imax(c0 - j0, 0), n0), imin(imax(c1 - j0, 0), n0));
   if (n0 < 16 && i0 + 1 >= r0 && i0 + 1 < r1) {
@@ -662,12 +701,23 @@ ARCLE_BIG_DEV uint32_t pos_bytes(uint32_t v) {  // 0xff in every byte of v that 
   const uint32_t t = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) & ~v) & 0x80808080u) >> 7;
   return (t << 8) - t;
 }
+template <int CPT_, bool LEAN_>
+ARCLE_BIG_DEV uint32_t CtxT<CPT_, LEAN_>::sel_pos(uint32_t v) const {
+  // (bit 0 of every byte first: a shifted window's bytes from outside the tile are anything, and must not borrow into their neighbours)
+  const uint32_t b = v & 0x01010101u;
+  return sel01 ? (b << 8) - b : pos_bytes(v);
+}
+template <int CPT_, bool LEAN_>
+ARCLE_BIG_DEV uint32_t CtxT<CPT_, LEAN_>::sel_nz(uint32_t v) const {
+  const uint32_t b = v & 0x01010101u;
+  return sel01 ? (b << 8) - b : nz_bytes(v);
+}
 
 // Rotate / Flip (W >= 16): chunk c of dst[:nh, :nw] = src[c0 + ai * i + bj * j] — a true gather (a column of the source becomes a row), but the
 // source index of consecutive cells advances by bj, restarts once where the chunk crosses into its second plane row, and the [:nh, :nw]
 // rectangle is applied as a byte mask afterwards: an add, a clamp (v_med3) and a byte read per cell instead of the compare chain
-ARCLE_BIG_DEV Chunk gather_affine16(const int8_t* tile, int c, int W, int P, int nh, int nw, int c0, int ai, int bj) {
-  const int f0 = 16 * c, i0 = f0 / W, j0 = f0 - i0 * W, n0 = imin(16, W - j0);
+ARCLE_BIG_DEV Chunk gather_affine16(const int8_t* tile, int c, int W, uint32_t wm, int P, int nh, int nw, int c0, int ai, int bj) {
+  const int f0 = 16 * c, i0 = div_w(f0, wm), j0 = f0 - i0 * W, n0 = imin(16, W - j0);
   const int ta = c0 + ai * i0 + bj * j0, tb = c0 + ai * (i0 + 1) - bj * n0;  // cell k: ta + bj * k in the first row, tb + bj * k in the second
   Chunk o;
 #pragma unroll
@@ -675,7 +725,7 @@ ARCLE_BIG_DEV Chunk gather_affine16(const int8_t* tile, int c, int W, int P, int
     const int t = (k < n0 ? ta : tb) + bj * k;
     o.b[k] = tile[imin(imax(t, 0), P - 1)];
   }
-  const Chunk in = rect_mask16(c, W, 0, nh, 0, nw);
+  const Chunk in = rect_mask16(c, W, wm, 0, nh, 0, nw);
 #pragma unroll
   for (int q = 0; q < 4; q++) o.w[q] &= in.w[q];
   return o;
@@ -686,10 +736,10 @@ template <class X>
 ARCLE_BIG_DEV Chunk cut_out16(const X& x, int c, int x0, int y0, int h, int w) {
   const int delta = x0 * x.W + y0;
   const Chunk sv = shifted16(x.S, 16 * c + delta, x.PS), av = shifted16(x.A, 16 * c + delta, x.PS);
-  const Chunk in = rect_mask16(c, x.W, 0, h, 0, w);
+  const Chunk in = rect_mask16(c, x.W, x.wm, 0, h, 0, w);
   Chunk o;
 #pragma unroll
-  for (int q = 0; q < 4; q++) o.w[q] = av.w[q] & in.w[q] & nz_bytes(sv.w[q]);
+  for (int q = 0; q < 4; q++) o.w[q] = av.w[q] & in.w[q] & x.sel_nz(sv.w[q]);
   return o;
 }
 
@@ -718,7 +768,7 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
         pv = shifted16(bg, 16 * c - d2 + lift_delta, x.PS);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const uint32_t m = pos_bytes(sv.w[q]);  // object.py:78 sel > 0
+          const uint32_t m = x.sel_pos(sv.w[q]);  // object.py:78 sel > 0
           pv.w[q] &= m;                           // :81
           qv.w[q] = 0x01010101u & m;              // :84
         }
@@ -726,12 +776,12 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
         pv = shifted16(O, 16 * c - d2, x.PS);
         qv = shifted16(Q, 16 * c - d2, x.PS);
       }
-      const Chunk in = draw ? rect_mask16(c, W, stx, edx, sty, edy) : zero_chunk();
+      const Chunk in = draw ? rect_mask16(c, W, x.wm, stx, edx, sty, edy) : zero_chunk();
       Chunk grid, sel;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         uint32_t b = bgc.w[q];
-        if (cut) b &= ~pos_bytes(reinterpret_cast<const uint32_t*>(cut)[4 * c + q]);  // background = where(sel > 0, 0, grid)
+        if (cut) b &= ~x.sel_pos(reinterpret_cast<const uint32_t*>(cut)[4 * c + q]);  // background = where(sel > 0, 0, grid)
         const uint32_t m = in.w[q] & pos_bytes(pv.w[q]);                                // :138 where=(p > 0)
         grid.w[q] = (pv.w[q] & m) | (b & ~m);
         sel.w[q] = qv.w[q] & in.w[q];                                                   // :165
@@ -745,7 +795,7 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
     Chunk sel = zero_chunk();
     const Chunk bgc = ldg(bg, c);
     const Chunk cutc = cut ? ldg(cut, c) : zero_chunk();
-    const Chunk grid = build_chunk(c, W, x.P, [&](int f, int i, int j) {
+    const Chunk grid = build_chunk(c, W, x.wm, x.P, [&](int f, int i, int j) {
       const int k = f & 15;
       const bool in = draw && i >= stx && i < edx && j >= sty && j < edy;
       const int t = in ? (i - px) * W + (j - py) : 0;
@@ -768,7 +818,8 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
 enum { ING_T_ANY = -1, ING_T_MASKS = 0, ING_T_TUPLES = 1 };
 template <class X, int ING>
 ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
-  const X x(p, env, lds);
+  X x(p, env, lds);
+  x.sel01 = ING == ING_T_TUPLES;  // (rectangles and points are written to S as 0 / 1)
   const int tid = x.tid, H = x.H, W = x.W, P = x.P, nch = x.nch;
   Chunk rc = ldg(p.rec, env);
   int8_t* const r = rc.b;
@@ -854,7 +905,10 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       else if (tuple) tuple_any = (uint32_t)imin(pay[0], pay[2]) < (uint32_t)H && (uint32_t)imin(pay[1], pay[3]) < (uint32_t)W;
       const bool will_be_active = (oflags & ARCLE_OPF_RESET_SEL) ? false : r[ARCLE_REC_ACTIVE] != 0;
       switch (kind) {
-        case ARCLE_OP_FLOODFILL:
+        case ARCLE_OP_FLOODFILL:  // (a tuple that is not a single cell fills nothing, color.py:92: no plane is needed)
+          if (!tuple || (tuple_any && (p.ingress == ING_POINT || (imin(imax(pay[0], pay[2]), H - 1) == imin(pay[0], pay[2]) && imin(imax(pay[1], pay[3]), W - 1) == imin(pay[1], pay[3])))))
+            staged = ARCLE_PL_GRID;
+          break;
         case ARCLE_OP_CROP_GRID: staged = ARCLE_PL_GRID; break;
         case ARCLE_OP_COPY: staged = arg ? ARCLE_PL_GRID : ARCLE_PL_INPUT; break;
         case ARCLE_OP_PASTE: staged = ARCLE_PL_CLIP; break;
@@ -903,7 +957,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
         }
         stg(x.S, c, v);
         if (v.w[0] | v.w[1] | v.w[2] | v.w[3]) {
-          int i = f0 / W, j = f0 - i * W;
+          int i = div_w(f0, x.wm), j = f0 - i * W;
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const int s = v.b[k];
@@ -989,14 +1043,14 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       }
       if (x.wide()) {
         BIG_EACH_CHUNK(x, c) {
-          Chunk m = any ? rect_mask16(c, W, xa, xb + 1, ya, yb + 1) : zero_chunk();
+          Chunk m = any ? rect_mask16(c, W, x.wm, xa, xb + 1, ya, yb + 1) : zero_chunk();
 #pragma unroll
           for (int q = 0; q < 4; q++) m.w[q] &= 0x01010101u;
           stg(x.S, c, m);
         }
       } else
       BIG_EACH_CHUNK(x, c)
-        stg(x.S, c, build_chunk(c, W, P, [&](int, int i, int j) { return (any && i >= xa && i <= xb && j >= ya && j <= yb) ? 1 : 0; }));
+        stg(x.S, c, build_chunk(c, W, x.wm, P, [&](int, int i, int j) { return (any && i >= xa && i <= xb && j >= ya && j <= yb) ? 1 : 0; }));
       any_nz = any_pos = any;
       ssum = any ? (xb - xa + 1) * (yb - ya + 1) : 0;
       x0 = xa;
@@ -1090,7 +1144,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
           Chunk gr = x.gl(ARCLE_PL_GRID, c);
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const uint32_t m = nz_bytes(s.w[q]);
+            const uint32_t m = x.sel_nz(s.w[q]);
             gr.w[q] = (gr.w[q] & ~m) | ((((uint32_t)arg & 0xffu) * 0x01010101u) & m);
           }
           x.gs(ARCLE_PL_GRID, c, gr);
@@ -1099,7 +1153,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       }
       case ARCLE_OP_FLOODFILL: {  // color.py:88-100
         if (ssum != 1) break;
-        const int sx = amax_cell / W, sy = amax_cell - sx * W;
+        const int sx = div_w(amax_cell, x.wm), sy = amax_cell - sx * W;
         const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1];
         if (sx >= gh || sy >= gw) break;
         flood_fill(x, gh, gw, sx, sy, arg);  // (the grid is in A)
@@ -1135,15 +1189,15 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
             r[ARCLE_REC_OBJECT_POS + 1] = (int8_t)i8w(y0 + dy);
             BIG_EACH_CHUNK(x, c) {
               const Chunk sv = shifted16(x.S, 16 * c + delta, x.PS), av = shifted16(x.A, 16 * c + delta, x.PS);
-              const Chunk in = rect_mask16(c, W, 0, oh, 0, ow);
+              const Chunk in = rect_mask16(c, W, x.wm, 0, oh, 0, ow);
               Chunk ob, qs, gr = ldg(x.A, c);
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
               for (int q = 0; q < 4; q++) {
-                const uint32_t m = in.w[q] & pos_bytes(sv.w[q]);  // :78 sel > 0
+                const uint32_t m = in.w[q] & x.sel_pos(sv.w[q]);  // :78 sel > 0
                 ob.w[q] = av.w[q] & m;                            // :81
                 qs.w[q] = 0x01010101u & m;                        // :84
-                gr.w[q] &= ~pos_bytes(sm.w[q]);                   // :87-88 background = where(sel > 0, 0, grid)
+                gr.w[q] &= ~x.sel_pos(sm.w[q]);                   // :87-88 background = where(sel > 0, 0, grid)
               }
               x.gs(ARCLE_PL_OBJECT, c, ob);
               x.gs(ARCLE_PL_OBJECT_SEL, c, qs);
@@ -1152,11 +1206,11 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
             place(x, r, x.A, x.S, nullptr, nullptr, delta);
           } else {
             BIG_EACH_CHUNK(x, c) {
-              const Chunk gs_ = gather_affine16(x.S, c, W, P, nh, nw, c0 + delta, ai, bj), ga = gather_affine16(x.A, c, W, P, nh, nw, c0 + delta, ai, bj);
+              const Chunk gs_ = gather_affine16(x.S, c, W, x.wm, P, nh, nw, c0 + delta, ai, bj), ga = gather_affine16(x.A, c, W, x.wm, P, nh, nw, c0 + delta, ai, bj);
               Chunk ob, qs;
 #pragma unroll
               for (int q = 0; q < 4; q++) {
-                const uint32_t m = pos_bytes(gs_.w[q]);
+                const uint32_t m = x.sel_pos(gs_.w[q]);
                 ob.w[q] = ga.w[q] & m;
                 qs.w[q] = 0x01010101u & m;
               }
@@ -1175,7 +1229,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
               Chunk gr = ldg(x.A, c);
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
-              for (int q = 0; q < 4; q++) gr.w[q] &= ~pos_bytes(sm.w[q]);
+              for (int q = 0; q < 4; q++) gr.w[q] &= ~x.sel_pos(sm.w[q]);
               x.gs(ARCLE_PL_BACKGROUND, c, gr);
               x.gs(ARCLE_PL_OBJECT, c, ldg(x.B, c));
               x.gs(ARCLE_PL_OBJECT_SEL, c, ldg(x.C, c));
@@ -1194,7 +1248,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
             Chunk qs = zero_chunk();
             // (every gather below reads LDS UNCONDITIONALLY at a clamped index and selects afterwards: the 16 cells' reads are then
             // independent and issue back to back — reads under a branch wait for one another, profiles/round5_experiments.txt §15)
-            const Chunk ob = build_chunk(c, W, P, [&](int f, int i, int j) {
+            const Chunk ob = build_chunk(c, W, x.wm, P, [&](int f, int i, int j) {
               const bool in = i < oh && j < ow;
               const int s = in ? (x0 + i) * W + (y0 + j) : 0;
               const int8_t sv = x.S[s], av = x.A[s];
@@ -1234,7 +1288,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
               Chunk gr = ldg(x.A, c);  // background = where(sel > 0, 0, grid)  :87-88; place() forms it again from A and S
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
-              for (int q = 0; q < 4; q++) gr.w[q] &= ~pos_bytes(sm.w[q]);
+              for (int q = 0; q < 4; q++) gr.w[q] &= ~x.sel_pos(sm.w[q]);
               x.gs(ARCLE_PL_BACKGROUND, c, gr);
             }
           }
@@ -1246,10 +1300,10 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
               Chunk gr = ldg(x.A, c);
               const Chunk sm = ldg(x.S, c);
 #pragma unroll
-              for (int q = 0; q < 4; q++) gr.w[q] &= ~pos_bytes(sm.w[q]);
+              for (int q = 0; q < 4; q++) gr.w[q] &= ~x.sel_pos(sm.w[q]);
               stg(x.A, c, gr);
             }
-            const Chunk t = x.wide() ? gather_affine16(x.B, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
+            const Chunk t = x.wide() ? gather_affine16(x.B, c, W, x.wm, P, nh, nw, c0, ai, bj) : build_chunk(c, W, x.wm, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int8_t v = x.B[in ? c0 + ai * i + bj * j : 0];
               return in ? v : (int8_t)0;
@@ -1259,7 +1313,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
           bg_in_A = true;
           bx::sync();
           BIG_EACH_CHUNK(x, c) {
-            const Chunk t = x.wide() ? gather_affine16(x.C, c, W, P, nh, nw, c0, ai, bj) : build_chunk(c, W, P, [&](int, int i, int j) {
+            const Chunk t = x.wide() ? gather_affine16(x.C, c, W, x.wm, P, nh, nw, c0, ai, bj) : build_chunk(c, W, x.wm, P, [&](int, int i, int j) {
               const bool in = i < nh && j < nw;
               const int8_t v = x.C[in ? c0 + ai * i + bj * j : 0];
               return in ? v : (int8_t)0;
@@ -1297,7 +1351,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
           BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_CLIP, c, cut_out16(x, c, x0, y0, h, w));  // :310-312 where=logical_and(src, sel)
         } else
         BIG_EACH_CHUNK(x, c)
-          x.gs(ARCLE_PL_CLIP, c, build_chunk(c, W, P, [&](int, int i, int j) {
+          x.gs(ARCLE_PL_CLIP, c, build_chunk(c, W, x.wm, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
                 const int s = in ? (x0 + i) * W + (y0 + j) : 0;
                 const int8_t sv = x.S[s], av = x.A[s];
@@ -1319,7 +1373,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
           BIG_EACH_CHUNK(x, c) {
             if (c < c_first || c > c_last) continue;
             Chunk gr = x.gl(ARCLE_PL_GRID, c);
-            const Chunk pv = shifted16(x.A, 16 * c - d2, x.PS), in = rect_mask16(c, W, x0, ex, y0, ey);
+            const Chunk pv = shifted16(x.A, 16 * c - d2, x.PS), in = rect_mask16(c, W, x.wm, x0, ex, y0, ey);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               const uint32_t m = arg ? in.w[q] : in.w[q] & pos_bytes(pv.w[q]);  // :345-348
@@ -1331,7 +1385,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
         BIG_EACH_CHUNK(x, c) {
             if (c < c_first || c > c_last) continue;
           const Chunk gr = x.gl(ARCLE_PL_GRID, c);
-          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int f, int i, int j) {
+          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, x.wm, P, [&](int f, int i, int j) {
                 const bool in = i >= x0 && i < ex && j >= y0 && j < ey;
                 const int8_t pv = x.A[in ? (i - x0) * W + (j - y0) : 0];
                 return (in && (arg || pv > 0)) ? pv : gr.b[f & 15];  // :345-348
@@ -1363,7 +1417,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
           BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_GRID, c, cut_out16(x, c, x0, y0, h, w));
         } else
         BIG_EACH_CHUNK(x, c)
-          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int, int i, int j) {
+          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, x.wm, P, [&](int, int i, int j) {
                 const bool in = i < h && j < w;
                 const int s = in ? (x0 + i) * W + (y0 + j) : 0;
                 const int8_t sv = x.S[s], av = x.A[s];
@@ -1379,7 +1433,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
         r[ARCLE_REC_GRID_DIM + 1] = (int8_t)aw;
         BIG_EACH_CHUNK(x, c) {
           const Chunk gr = x.gl(ARCLE_PL_GRID, c);
-          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, P, [&](int f, int i, int j) { return (i < ah && j < aw) ? gr.b[f & 15] : (int8_t)0; }));
+          x.gs(ARCLE_PL_GRID, c, build_chunk(c, W, x.wm, P, [&](int f, int i, int j) { return (i < ah && j < aw) ? gr.b[f & 15] : (int8_t)0; }));
         }
         break;
       }
@@ -1446,7 +1500,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
         if (c >= lastc) break;
         const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
         int f = 16 * c;
-        int i = f / W, j = f - i * W;
+        int i = div_w(f, x.wm), j = f - i * W;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           mine += (i < mh && j < mw && a.b[k] == b.b[k]) ? 1 : 0;

@@ -26,6 +26,8 @@ ARCLE_BIG_DEV void lds_max(int32_t* a, int v) { atomicMax(a, v); }
 ARCLE_BIG_DEV void lds_umax(uint32_t* a, uint32_t v) { atomicMax(a, v); }
 ARCLE_BIG_DEV void status_or(uint32_t* g, uint32_t v) { atomicOr(g, v); }
 ARCLE_BIG_DEV uint64_t brev64(uint64_t x) { return __brevll(x); }
+ARCLE_BIG_DEV uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }                                     // v_mul_u32_u24 (full rate)
+ARCLE_BIG_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }  // (hi:lo) >> sh, sh < 32
 ARCLE_BIG_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }  // a value every lane holds alike, moved to a scalar register
 ARCLE_BIG_DEV void release_store_system(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }  // namespace bx
@@ -41,11 +43,13 @@ extern __shared__ __attribute__((aligned(16))) int8_t arcle_big_lds[];
 __global__ __launch_bounds__(BIG_THREADS) void arcle_big_step_kernel(const BigParams p) {
   arcle_big::step_env(p, (int)blockIdx.x, arcle_big_lds);
 }
-// The LEAN instantiations (arcle_big.h CtxT): the launch's flag set lies within LEAN_FLAGS, W >= 16, no accounting, no scratch rows; ONE: at
-// least one thread per plane chunk.  What ARCVecEnv's plain step calls run; everything else takes the generic kernel above.
-template <bool ONE, int ING>
-__global__ __launch_bounds__(arcle_big::LEAN_THREADS) void arcle_big_step_lean(const BigParams p) {
-  arcle_big::step_env_t<arcle_big::CtxT<ONE, true>, ING>(p, (int)blockIdx.x, arcle_big_lds);
+// The LEAN instantiations (arcle_big.h CtxT): the launch's flag set lies within LEAN_FLAGS, W >= 16, no accounting, no scratch rows; CPT: at
+// most that many plane chunks per thread.  What ARCVecEnv's plain step calls run; everything else takes the generic kernel above.
+// (Instantiations compiled for 64-thread workgroups alone — one wavefront per env, the compiler drops the barriers — measured the same as
+// these launched with 64 threads: 25.7 / 25.6 us at 40 x 40 x 16 384, profiles/round6_experiments.txt §2.)
+template <int CPT, int ING>
+__global__ __launch_bounds__(arcle_big::LEAN_MAX_THREADS) void arcle_big_step_lean(const BigParams p) {
+  arcle_big::step_env_t<arcle_big::CtxT<CPT, true>, ING>(p, (int)blockIdx.x, arcle_big_lds);
 }
 __global__ __launch_bounds__(BIG_THREADS) void arcle_big_reset_kernel(const BigParams p, int mode) {
   arcle_big::reset_env(p, (int)blockIdx.x, mode, arcle_big_lds);
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(BIG_THREADS) void arcle_big_set_rows_kernel(const B
 
 namespace arcle_big {
 
-// the dynamic LDS of a launch: 65 344 bytes at 127 x 127; a plane stride that needs more than the 64 KB a kernel gets without asking
+// the dynamic LDS of a launch: 65 360 bytes at 127 x 127; a plane stride that needs more than the 64 KB a kernel gets without asking
 // (a caller-chosen stride with padding) asks for it
 template <int ID, class K>
 static int allow_lds(K kernel, int bytes) {
@@ -77,7 +81,8 @@ static int allow_lds(K kernel, int bytes) {
 // per-cell kernels and with the whole-chunk (SWAR) ones (profiles/round5_experiments.txt §15, §20: 40 x 40 x 16 384 envs 39 us with 128
 // threads, 61 with 256, 117 with 512; 127 x 127: 264 us with 512, 312 with 256, 443 with 128) — so: the chunk count rounded up to whole
 // wavefronts, at least 128 (the flood fill gives every board row its own thread) and at most 512 (128 threads at 40 x 40, 256 at 64 x 64,
-// 512 at 127 x 127).  ARCLE_BIG_THREADS overrides (tuning runs).
+// 512 at 127 x 127).  ARCLE_BIG_THREADS overrides (tuning runs).  (The generic kernel and the reset / row kernels; the LEAN step launches
+// size themselves, lean_threads_for below.)
 static unsigned threads_for(int PS) {
   static int forced = -1;
   if (forced < 0) {
@@ -92,52 +97,82 @@ static unsigned threads_for(int PS) {
 }
 
 int workgroup_threads(int PS) { return (int)threads_for(PS); }
+static bool lean_launch(const BigParams& p);
+static unsigned lean_threads_for(int PS, int H);
+int step_threads(const BigParams& p) { return lean_launch(p) ? (int)lean_threads_for(p.PS, p.H) : (int)threads_for(p.PS); }
 
-template <int ID, bool ONE, int ING>
+template <int ID, int CPT, int ING>
 static int launch_lean(const BigParams& p, unsigned nt, int lds, void* stream) {
-  if (int rc = allow_lds<ID>(arcle_big_step_lean<ONE, ING>, lds)) return rc;
-  hipLaunchKernelGGL((arcle_big_step_lean<ONE, ING>), dim3((unsigned)p.n_envs), dim3(nt), (size_t)lds, (hipStream_t)stream, p);
+  if (int rc = allow_lds<ID>(arcle_big_step_lean<CPT, ING>, lds)) return rc;
+  hipLaunchKernelGGL((arcle_big_step_lean<CPT, ING>), dim3((unsigned)p.n_envs), dim3(nt), (size_t)lds, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 
+static int env_int(const char* name) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : 0;
+}
 // ARCLE_BIG_GENERIC=1: every step launch takes the generic kernel (A/B runs)
 static bool lean_allowed() {
   static int v = -1;
-  if (v < 0) {
-    const char* s = getenv("ARCLE_BIG_GENERIC");
-    v = (s && atoi(s)) ? 0 : 1;
-  }
+  if (v < 0) v = env_int("ARCLE_BIG_GENERIC") ? 0 : 1;
   return v != 0;
 }
-
-int launch_step(const BigParams& p, void* stream) {
-  const int lds = lds_bytes(p.PS, p.H);
-  const unsigned nt = threads_for(p.PS);
-  const bool lean = lean_allowed() && !(p.flags & ~(uint32_t)LEAN_FLAGS) && p.W >= 16 && !p.res_rec && !p.acct && nt <= (unsigned)LEAN_THREADS;
-  if (lean) {
-    const bool one = (unsigned)(p.PS >> 4) <= nt;
-    const bool masks = p.ingress == ING_MASK || p.ingress == ING_BITS;
-    if (one) return masks ? launch_lean<4, true, ING_T_MASKS>(p, nt, lds, stream) : launch_lean<5, true, ING_T_TUPLES>(p, nt, lds, stream);
-    if (nt == (unsigned)LEAN_THREADS)
-      return masks ? launch_lean<6, false, ING_T_MASKS>(p, nt, lds, stream) : launch_lean<7, false, ING_T_TUPLES>(p, nt, lds, stream);
+// Threads per workgroup of a LEAN step launch: TWO chunks per thread — 64 threads (one wavefront per env) at 40 x 40, 128 at 64 x 64, 512 at
+// 127 x 127; at least one thread per plane row (the flood fill's boards).  Same library, same run, C3 mix, 16 384 envs: 40 x 40 29.7 us with
+// one chunk per thread, 27.1 with two; 64 x 64 50.9 / 46.3; four: no better at 40 x 40, 57 at 64 x 64 (profiles/round6_experiments.txt §2).
+// ARCLE_BIG_CPT = 1 / 2 picks the chunks per thread, ARCLE_BIG_THREADS the size itself (tuning runs).
+static unsigned lean_threads_for(int PS, int H) {
+  static int cpt = -1, forced = -1;
+  if (cpt < 0) {
+    const int v = env_int("ARCLE_BIG_CPT"), f = env_int("ARCLE_BIG_THREADS");
+    cpt = v == 1 ? 1 : 2;
+    forced = (f >= 64 && f <= LEAN_MAX_THREADS && (f & 63) == 0) ? f : 0;
   }
+  const int nch = PS >> 4, rows = (H + 63) & ~63;
+  int t = forced ? forced : (((nch + cpt - 1) / cpt) + 63) & ~63;
+  if (t < rows) t = rows;
+  return (unsigned)(t > LEAN_MAX_THREADS ? LEAN_MAX_THREADS : t);
+}
+
+// does a step launch with these parameters take a LEAN kernel?  (what they assume, arcle_big.h CtxT; a forced workgroup too small for two
+// chunks per thread falls back to the generic kernel)
+static bool lean_launch(const BigParams& p) {
+  if (!lean_allowed() || (p.flags & ~(uint32_t)LEAN_FLAGS) || p.W < 16 || p.res_rec || p.acct) return false;
+  return (unsigned)(p.PS >> 4) <= 2u * lean_threads_for(p.PS, p.H);
+}
+
+int launch_step(const BigParams& p0, void* stream) {
+  const BigParams p = with_magic(p0);
+  const int lds = lds_bytes(p.PS, p.H);
+  if (lean_launch(p)) {
+    const unsigned nt = lean_threads_for(p.PS, p.H);
+    const int need = (int)(((unsigned)(p.PS >> 4) + nt - 1) / nt);
+    const bool masks = p.ingress == ING_MASK || p.ingress == ING_BITS;
+    if (need <= 1) return masks ? launch_lean<4, 1, ING_T_MASKS>(p, nt, lds, stream) : launch_lean<5, 1, ING_T_TUPLES>(p, nt, lds, stream);
+    return masks ? launch_lean<6, 2, ING_T_MASKS>(p, nt, lds, stream) : launch_lean<7, 2, ING_T_TUPLES>(p, nt, lds, stream);
+  }
+  const unsigned nt = threads_for(p.PS);
   if (int rc = allow_lds<0>(arcle_big_step_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_step_kernel, dim3((unsigned)p.n_envs), dim3(nt), (size_t)lds, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
-int launch_reset(const BigParams& p, int mode, void* stream) {
+int launch_reset(const BigParams& p0, int mode, void* stream) {
+  const BigParams p = with_magic(p0);
   const int lds = lds_bytes(p.PS, p.H);
   if (int rc = allow_lds<1>(arcle_big_reset_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_reset_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p, mode);
   return (int)hipGetLastError();
 }
-int launch_rows(const BigParams& p, int mode, void* stream) {
+int launch_rows(const BigParams& p0, int mode, void* stream) {
+  const BigParams p = with_magic(p0);
   const int lds = lds_bytes(p.PS, p.H);
   if (int rc = allow_lds<2>(arcle_big_rows_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_rows_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p, mode);
   return (int)hipGetLastError();
 }
-int launch_set_rows(const BigParams& p, void* stream) {
+int launch_set_rows(const BigParams& p0, void* stream) {
+  const BigParams p = with_magic(p0);
   const int lds = lds_bytes(p.PS, p.H);
   if (int rc = allow_lds<3>(arcle_big_set_rows_kernel, lds)) return rc;
   hipLaunchKernelGGL(arcle_big_set_rows_kernel, dim3((unsigned)p.n_envs), dim3(threads_for(p.PS)), (size_t)lds, (hipStream_t)stream, p);

@@ -58,13 +58,20 @@ struct BigParams {
   const uint8_t* aug_perm;  // uint8 [n_envs][16]: perm[c] for colour c < 10
   uint32_t* acct;  // arcle_enable_accounting: uint32 [2][n_envs] — bytes without the row padding / bytes of every access issued, per env
   int32_t* dense;  // ARCLE_STEP_DENSE: int32 [n_envs][2] = (cells of the grid that match the answer inside the common rectangle, total cells)
+  uint32_t w_magic;  // 2^21 / W + 1: cell index -> row by a multiply and a shift (arcle_big.h div_w); filled in by the launchers (with_magic)
 };
+ARCLE_BIG_HD inline BigParams with_magic(const BigParams& p) {
+  BigParams q = p;
+  q.w_magic = (1u << 21) / (uint32_t)(p.W > 0 ? p.W : 1) + 1u;
+  return q;
+}
 
 // bytes of LDS one workgroup needs: four staging planes + the reduction block + two row boards of 128 x 128 bits + a row's scalars and layout
 // (the flood fill's two row boards, 16 bytes per plane row each, live in the B and C tiles — idle during a fill — whenever a tile holds them:
 // 16 * H <= PS, i.e. always for W >= 16; only narrow planes get 4 KB of their own)
 ARCLE_BIG_HD inline bool boards_in_tiles(int PS, int H) { return 16 * H <= PS; }
-ARCLE_BIG_HD inline int lds_bytes(int PS, int H) { return 4 * PS + 64 + 256 + (boards_in_tiles(PS, H) ? 0 : 2 * 128 * 16); }  // 65 344 at 127 x 127
+enum { LDS_GUARD = 16, LEAN_MAX_THREADS = 512 };  // bytes in front of the first tile (arcle_big.h shifted16 reads whole 5-word windows)
+ARCLE_BIG_HD inline int lds_bytes(int PS, int H) { return LDS_GUARD + 4 * PS + 64 + 256 + (boards_in_tiles(PS, H) ? 0 : 2 * 128 * 16); }  // 65 360 at 127 x 127
 
 ARCLE_BIG_HD inline int flat_len(int P, bool o2, bool clip, int filtered) {
   if (filtered) return 3 * P + 10;
@@ -77,6 +84,7 @@ int launch_step(const BigParams& p, void* stream);
 int launch_reset(const BigParams& p, int mode, void* stream);     // 0 arcle_reset, 1 arcle_reset_from_table, 2 arcle_reset_sampled
 int launch_rows(const BigParams& p, int mode, void* stream);      // 0 flat rows of the resident state, 1 packed rows
 int launch_set_rows(const BigParams& p, void* stream);
-int workgroup_threads(int PS);  // threads per workgroup the launches above use for a plane stride
+int workgroup_threads(int PS);  // threads per workgroup the reset / row launches (and the generic step kernel) use for a plane stride
+int step_threads(const BigParams& p);  // ... and a step launch with these parameters (flags, ingress, accounting)
 
 }  // namespace arcle_big

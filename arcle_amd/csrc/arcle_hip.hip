@@ -815,11 +815,6 @@ static int big_done(arcle_env* e, int hip_rc, const char* what) {
   }
   return ARCLE_OK;
 }
-#define BIG_REFUSE(e, what)                                                                                                      \
-  do {                                                                                                                           \
-    if ((e)->big) return fail((e), ARCLE_ERR_CONFIG, what " is not available for grids of more than ARCLE_MAX_CELLS (1024) cells"); \
-  } while (0)
-
 extern "C" int arcle_set_op_table(arcle_env* e, const uint32_t* descs, int32_t n_ops) {
   if (!e || !descs) return ARCLE_ERR_ARG;
   DeviceGuard guard(e->device);
@@ -1160,6 +1155,7 @@ static LaunchPlan plan_launch(const arcle_env* e, int ingress, const StepParams&
   if (pl.grouped) pl.policy = 0;
   else if (!(any_policy || (policy_a && pl.policy == 'A'))) pl.policy = 0;
   if (e->pf_next && pl.wpw != WAVES_PER_WG) pl.wpw = WAVES_PER_WG;  // (the record-prefetching launch is written for 8-wave workgroups)
+  if (pl.wpw & (pl.wpw - 1)) pl.grouped = 0;  // (a self-ordering launch rebuilds its slot from log2 of the workgroup's waves: powers of two only)
   return pl;
 }
 
@@ -1284,10 +1280,14 @@ static int launch_step(arcle_env* e, int ingress, const void* sel, const int32_t
 static size_t payload_bytes(const arcle_env* e, int ingress);
 
 extern "C" int arcle_launch_info(arcle_env* e, int ingress, uint32_t flags, int32_t* out4) {
-  if (e && out4 && e->big) {  // one workgroup of four wavefronts per env: no plan to choose
+  if (e && out4 && e->big) {  // one workgroup per env: no plan to choose; [2] = its wavefronts for this flag set / ingress form
+    arcle_big::BigParams q = big_params(e);
+    q.flags = flags;
+    q.ingress = ingress;
+    q.acct = e->d_acct;
     out4[0] = 0;
     out4[1] = 0;
-    out4[2] = arcle_big::workgroup_threads(e->base.PS) / 64;
+    out4[2] = arcle_big::step_threads(q) / 64;
     out4[3] = 0;
     return ARCLE_OK;
   }
@@ -1339,10 +1339,19 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, cons
   int8_t* save_rec = nullptr;
   int32_t *save_cnt = nullptr, *t_reward = nullptr;
   uint8_t* t_term = nullptr;
+  // (the caller's packed-row buffer and the sticky status word are part of "the handle as it was found": the timed launches write their
+  // rows to a scratch buffer, and the status word is saved and put back)
+  int8_t *t_pack = nullptr, *const caller_pack = e->pack_out;
+  uint32_t* save_status = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ok = hipMalloc((void**)&save_rec, n * ARCLE_REC_BYTES) == hipSuccess && hipMalloc((void**)&save_cnt, n * 8) == hipSuccess &&
             hipMalloc((void**)&t_reward, n * 4) == hipSuccess && hipMalloc((void**)&t_term, n) == hipSuccess &&
-            hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess;
+            hipMalloc((void**)&save_status, 8) == hipSuccess && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess;
+  if (ok && (flags & ARCLE_STEP_PACK_OBS) && caller_pack) {
+    ok = hipMalloc((void**)&t_pack, n * (size_t)arcle_packed_obs_size(e)) == hipSuccess;
+    if (ok) e->pack_out = t_pack;
+  }
+  ok = ok && hipMemcpyAsync(save_status, e->d_status, 8, hipMemcpyDeviceToDevice, st) == hipSuccess;
   for (int i = 0; ok && i < ARCLE_N_PLANES; i++)
     if (e->bufs.plane[i]) ok = hipMalloc((void**)&save_plane[i], pbytes) == hipSuccess;
   auto copy_state = [&](bool save) -> bool {
@@ -1394,10 +1403,14 @@ extern "C" int arcle_autotune(arcle_env* e, int ingress, int32_t n_batches, cons
           }
           e->forced = nullptr;
         }
-    if (!copy_state(false) || hipStreamSynchronize(st) != hipSuccess) rc = rc == ARCLE_OK ? ARCLE_ERR_HIP : rc;
+    if (!copy_state(false) || hipMemcpyAsync(e->d_status, save_status, 8, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      rc = rc == ARCLE_OK ? ARCLE_ERR_HIP : rc;
   } else {
     rc = ARCLE_ERR_HIP;
   }
+  e->pack_out = caller_pack;
+  if (t_pack) (void)hipFree(t_pack);
+  if (save_status) (void)hipFree(save_status);
   for (int i = 0; i < ARCLE_N_PLANES; i++)
     if (save_plane[i]) (void)hipFree(save_plane[i]);
   if (save_rec) (void)hipFree(save_rec);
@@ -1860,6 +1873,8 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
     // planes / records (+ the answer of resident env src_env[r]), one step() of the scratch envs with the fused row writer, i.e.
     // row r of rows_out = FlattenObservation of the stepped state (+ tail).  The resident envs are not touched.  The scratch (8 planes +
     // record + counters per row) is allocated — or grown — here: not inside a stream capture.
+    if (ingress != arcle::INGRESS_MASK && ingress != arcle::INGRESS_BBOX && ingress != arcle::INGRESS_POINT)  // (before any allocation or launch)
+      return fail(e, ARCLE_ERR_ARG, "arcle_transition_rows takes mask, bbox or point selections");
     const size_t PS = (size_t)e->base.PS, per_row = ARCLE_N_PLANES * PS + ARCLE_REC_BYTES + 8;
     if (n_rows > e->big_scratch_rows) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1901,8 +1916,6 @@ extern "C" int arcle_transition_rows(arcle_env* e, int32_t n_rows, const int8_t*
     q.flat_filter = 0;
     q.flat_tail = tail ? 1 : 0;
     q.flat_seq = tail ? e->flat_seq : 0;
-    if (ingress != arcle::INGRESS_MASK && ingress != arcle::INGRESS_BBOX && ingress != arcle::INGRESS_POINT)
-      return fail(e, ARCLE_ERR_ARG, "arcle_transition_rows takes mask, bbox or point selections");
     return big_done(e, arcle_big::launch_step(q, stream), "arcle_transition_rows");
   }
   StepParams p = e->base;

@@ -438,7 +438,8 @@ class _BigParams(ctypes.Structure):  # mirror of arcle_big::BigParams (arcle_amd
                 ("cur_task", ctypes.c_void_p), ("pair_off", ctypes.c_void_p), ("pair_cnt", ctypes.c_void_p),
                 ("n_problems", ctypes.c_int32), ("rows_in", ctypes.c_void_p), ("rows_in_stride", ctypes.c_int32),
                 ("n_resident", ctypes.c_int32), ("src_env", ctypes.c_void_p), ("res_answer", ctypes.c_void_p), ("res_rec", ctypes.c_void_p),
-                ("aug_flags", ctypes.c_uint32), ("aug_k", ctypes.c_void_p), ("aug_perm", ctypes.c_void_p), ("acct", ctypes.c_void_p), ("dense", ctypes.c_void_p)]
+                ("aug_flags", ctypes.c_uint32), ("aug_k", ctypes.c_void_p), ("aug_perm", ctypes.c_void_p), ("acct", ctypes.c_void_p), ("dense", ctypes.c_void_p),
+                ("w_magic", ctypes.c_uint32)]
 
 
 _big_emu = None
@@ -462,7 +463,7 @@ class BigEmuBackend(EmuBackend):
     """arcle_big.h (one workgroup per env; H * W > 1024) on host threads.  Same surface as EmuBackend where the big path has the feature."""
     name = "bigemu"
     THREADS = 16  # the emulated workgroup (the product launches 128-512: every loop of the body is strided by the thread count)
-    LEAN, ONE = True, False
+    LEAN, CPT = True, 0  # CPT: the LEAN instantiation's compile-time bound on the chunks per thread (0: the run-time loop, any plane on 16 threads)
     LEAN_FLAGS = 1 | 2 | 4 | 8 | 64  # arcle_big.h LEAN_FLAGS: AUTORESET | ELIDE_SELECTED | TRUNCATE | RESAMPLE | RESET_ON_SUBMIT
 
     def _params(self):
@@ -505,7 +506,9 @@ class BigEmuBackend(EmuBackend):
             p.flat_seq = int(getattr(self, "_flat_seq", 0))
 
     def _run(self, what, p, mode=0):
-        rc = big_emu_lib().big_emu_run(what, ctypes.byref(p), mode, max(self.THREADS, (self.PS // 16 + 15) & ~15) if self.ONE else self.THREADS)
+        nch = self.PS // 16
+        nthreads = max(self.THREADS, ((nch + self.CPT - 1) // self.CPT + 15) & ~15) if self.CPT else self.THREADS
+        rc = big_emu_lib().big_emu_run(what, ctypes.byref(p), mode, nthreads)
         assert rc == 0, f"big-grid emulator reported error {rc}"
 
     def reset(self, mask=None):
@@ -559,11 +562,11 @@ class BigEmuBackend(EmuBackend):
         opa = np.ascontiguousarray(op if op is not None else np.zeros(self.N), np.int32)
         p.sel, p.op, p.ingress, p.flags = pay.ctypes.data, opa.ctypes.data, self.INGRESS[ingress], flags
         # the instantiation the product's launcher would pick (arcle_big.hip launch_step): LEAN when the flag set, the plane width and
-        # the launch allow it — with ONE thread per chunk in BigEmuOneBackend —, the generic body otherwise
+        # the launch allow it — with the product's one / two / four chunks per thread in the BigEmuOne / Two / FourBackend —, the generic body otherwise
         lean = self.LEAN and not (flags & ~self.LEAN_FLAGS) and self.W >= 16 and not getattr(self, "count_bytes", False)
         self.lean_steps = getattr(self, "lean_steps", 0) + int(bool(lean))
         if lean:
-            self._run(4, p, 1 if self.ONE else 0)
+            self._run(4, p, self.CPT)
         else:
             self._run(0, p)
         return self.reward.copy(), self.term.copy()
@@ -641,7 +644,20 @@ class BigEmuOneBackend(BigEmuBackend):
     """... with at least one host thread per plane chunk: the one-chunk-per-thread LEAN instantiation (every plane of up to 8192 cells on
     the GPU).  Hundreds of host threads behind a pthread barrier: small cases only."""
     name = "bigemu_one"
-    ONE = True
+    CPT = 1
+
+
+class BigEmuTwoBackend(BigEmuBackend):
+    """... with one host thread per TWO plane chunks: the instantiation the product's launcher picks by default (64 threads at 40 x 40,
+    128 at 64 x 64, 512 at 127 x 127)."""
+    name = "bigemu_two"
+    CPT = 2
+
+
+class BigEmuFourBackend(BigEmuBackend):
+    """... four chunks per thread (ARCLE_BIG_CPT=4 / a forced small workgroup)."""
+    name = "bigemu_four"
+    CPT = 4
 
 
 # ---- HIP (the product, through arcle_amd.engine -> libarcle_hip.so C ABI) ------------------------------

@@ -11,7 +11,6 @@
 
 #define ARCLE_BIG_DEV inline
 #define ARCLE_BIG_HD
-#define ARCLE_BIG_LEAN_THREADS 16  // the LEAN instantiations with several chunks per thread take their workgroup size as a constant
 #define ARCLE_BIG_ROWS 8  // board rows per thread of the flood fill: 127 rows over the 16 threads of the emulated workgroup
 
 namespace bx {
@@ -48,6 +47,8 @@ inline uint64_t brev64(uint64_t x) {
 }
 inline void release_store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline int uniform(int v) { return v; }
+inline uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | (uint64_t)lo) >> (sh & 31u)); }
 }  // namespace bx
 
 #include "../../arcle_amd/csrc/arcle_big.h"
@@ -58,12 +59,16 @@ extern "C" int big_emu_params_size(void) { return (int)sizeof(BigParams); }
 extern "C" int big_emu_lds_bytes(int PS, int H) { return arcle_big::lds_bytes(PS, H); }
 
 // what: 0 step (generic instantiation), 1 reset (mode 0 / 1 / 2), 2 rows out (mode 0 flat / 1 packed), 3 state rows in,
-//       4 step, the LEAN instantiation the product launches for this ingress family (mode 1: the one-chunk-per-thread form)
-extern "C" int big_emu_run(int what, const BigParams* p, int mode, int nthreads) {
+//       4 step, a LEAN instantiation for this ingress family; mode = its compile-time bound on the chunks per thread (1 / 2 / 4: the forms
+//         the product launches — 2 by default; 0: the run-time loop, which lets 16 host threads walk a plane of any size)
+extern "C" int big_emu_run(int what, const BigParams* p_in, int mode, int nthreads) {
+  const BigParams filled = arcle_big::with_magic(*p_in);  // (what the product's launchers do, arcle_big.hip)
+  const BigParams* const p = &filled;
   if (nthreads < arcle_big::MIN_THREADS || p->PS > arcle_big::MAX_PS) return -1;
   if (what == 4) {  // what the launcher checks before it picks a LEAN kernel (arcle_big.hip lean_ok)
     if ((p->flags & ~(uint32_t)arcle_big::LEAN_FLAGS) || p->W < 16 || p->res_rec || p->acct) return -3;
-    if (mode == 1 ? (p->PS >> 4) > nthreads : nthreads != arcle_big::LEAN_THREADS) return -4;
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 4) return -4;
+    if (mode && (p->PS >> 4) > mode * nthreads) return -4;
   }
   const bool masks = p->ingress == arcle_big::ING_MASK || p->ingress == arcle_big::ING_BITS;
   void* lds = nullptr;
@@ -79,13 +84,13 @@ extern "C" int big_emu_run(int what, const BigParams* p, int mode, int nthreads)
         switch (what) {
           case 0: arcle_big::step_env(*p, env, (int8_t*)lds); break;
           case 4:
-            if (mode == 1) {
-              if (masks) arcle_big::step_env_t<arcle_big::CtxT<true, true>, arcle_big::ING_T_MASKS>(*p, env, (int8_t*)lds);
-              else arcle_big::step_env_t<arcle_big::CtxT<true, true>, arcle_big::ING_T_TUPLES>(*p, env, (int8_t*)lds);
-            } else {
-              if (masks) arcle_big::step_env_t<arcle_big::CtxT<false, true>, arcle_big::ING_T_MASKS>(*p, env, (int8_t*)lds);
-              else arcle_big::step_env_t<arcle_big::CtxT<false, true>, arcle_big::ING_T_TUPLES>(*p, env, (int8_t*)lds);
-            }
+#define BIG_EMU_LEAN(CPT)                                                                                                   \
+  if (masks) arcle_big::step_env_t<arcle_big::CtxT<CPT, true>, arcle_big::ING_T_MASKS>(*p, env, (int8_t*)lds);              \
+  else arcle_big::step_env_t<arcle_big::CtxT<CPT, true>, arcle_big::ING_T_TUPLES>(*p, env, (int8_t*)lds)
+            if (mode == 1) { BIG_EMU_LEAN(1); }
+            else if (mode == 2) { BIG_EMU_LEAN(2); }
+            else if (mode == 4) { BIG_EMU_LEAN(4); }
+            else { BIG_EMU_LEAN(0); }
             break;
           case 1: arcle_big::reset_env(*p, env, mode, (int8_t*)lds); break;
           case 2: arcle_big::rows_env(*p, env, mode, (int8_t*)lds); break;

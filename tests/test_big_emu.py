@@ -37,8 +37,29 @@ def test_big_emulator_random_traces_vs_oracle(H, W, kind, flags, max_trial):
 
 @pytest.mark.parametrize("H,W,ingress_mix", [(33, 32, True), (40, 40, False)])
 def test_big_emulator_one_chunk_per_thread_instantiation(H, W, ingress_mix):
-    """the LEAN kernel the product launches for planes of up to 8192 cells: every "my chunks" loop is a single guarded body"""
+    """a LEAN kernel of the product (ARCLE_BIG_CPT=1): every "my chunks" loop is a single guarded body"""
     errs = B.random_trace_compare(B.BigEmuOneBackend, "o2arc", O.o2arc_ops(), H, W, N=3, S=40, seed=H + W, flags=3, max_trial=3, bad_ops=True)
+    assert not errs, "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("H,W,kind,flags", [(40, 40, "o2arc", 3), (33, 48, "o2arc", 0), (64, 64, "o2arc", 3), (100, 20, "arc", 1), (127, 16, "o2arc", 3)])
+def test_big_emulator_two_chunks_per_thread_instantiation(H, W, kind, flags):
+    """the LEAN kernel the product's launcher picks by default: two guarded bodies per "my chunks" loop, a workgroup of half as many threads as
+    the plane has chunks (the last thread's second chunk may lie beyond the plane)"""
+    errs = B.random_trace_compare(B.BigEmuTwoBackend, kind, O.KIND_OPS[kind](), H, W, N=3, S=40, seed=2 * H + W, flags=flags, max_trial=3, bad_ops=True)
+    assert not errs, "\n".join(errs[:10])
+
+
+def test_big_emulator_two_chunks_per_thread_mask_forms_and_fill():
+    """... under the mask ingress forms (int8 and bit-packed rows) and through the flood fill's worst case"""
+    errs = B.random_trace_compare(B.BigEmuTwoBackend, "o2arc", O.o2arc_ops(), 40, 48, N=3, S=30, seed=5, max_trial=3, flags=3, new_forms=True)
+    assert not errs, "\n".join(errs[:10])
+    errs = B.floodfill_worst_case_compare(B.BigEmuTwoBackend, 40, 40)
+    assert not errs, "\n".join(errs[:10])
+
+
+def test_big_emulator_four_chunks_per_thread_instantiation():
+    errs = B.random_trace_compare(B.BigEmuFourBackend, "o2arc", O.o2arc_ops(), 64, 48, N=3, S=40, seed=31, flags=3, max_trial=3, bad_ops=True)
     assert not errs, "\n".join(errs[:10])
 
 

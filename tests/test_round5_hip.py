@@ -314,3 +314,41 @@ def test_grouped_launches_with_mask_ingress(form, n):
     for k in a.planes:
         assert torch.equal(a.planes[k], b.planes[k]), (form, n, k)
     assert torch.equal(a.rec, b.rec) and torch.equal(a.cnt, b.cnt) and a.status() == b.status()
+
+
+def test_autotune_leaves_packed_rows_and_status_alone():
+    """the 70-160 timed launches of arcle_autotune with ARCLE_STEP_PACK_OBS used to overwrite the caller's packed-row buffer
+    with tuning-run observations, and the sticky status word could pick up their ST_* bits.  Both are part of "the handle as found"."""
+    import torch
+    import bench
+    from arcle_amd.engine import STEP_PACK_OBS
+    dev, n, K = torch.device("cuda:0"), 4096, 8
+    bb_np, op_np = _streams(K, n, 77)
+    op_np[:, ::97] = 63  # (op indices beyond the table: every timed launch raises ARCLE_ST_BAD_OP)
+    bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)
+    b = bench.make_batch(dev, n, seed=9)
+    FL = b.elide_flag | 1 | STEP_PACK_OBS
+    packed = b.set_packed_output()
+    good = torch.from_numpy(np.where(op_np[0] == 63, 0, op_np[0])).to(dev)
+    b.step_bbox(bb[0], good, FL)
+    assert b.status(clear=True) == 0
+    rows_before = packed.clone()
+    rows = b.autotune("bbox", bb, op, FL)
+    assert rows
+    assert torch.equal(packed, rows_before), "the tuning launches wrote into the caller's packed rows"
+    assert b.status(clear=False) == 0, "the tuning launches left their status bits behind"
+    b.step_bbox(bb[1], op[1], FL)  # ... and the buffer is installed again afterwards
+    assert not torch.equal(packed, rows_before) and b.status() != 0
+
+
+def test_launch_info_reports_the_big_grid_workgroup():
+    """one workgroup per env beyond 1024 cells: two chunks per thread in the LEAN step launches (64 threads = one wavefront at 40 x 40), the
+    generic kernel's size when a flag outside their set is on"""
+    import torch
+    import bench
+    from arcle_amd.engine import STEP_FLAT_OBS
+    dev = torch.device("cuda:0")
+    for (H, W), lean_waves, generic_waves in (((40, 40), 1, 2), ((64, 64), 2, 4), ((127, 127), 8, 8)):
+        b = bench.make_batch(dev, 64, 3, "o2arc", H, W)
+        assert b.launch_info("bbox", b.elide_flag | 1)["waves_per_workgroup"] == lean_waves, (H, W)
+        assert b.launch_info("bbox", b.elide_flag | 1 | STEP_FLAT_OBS)["waves_per_workgroup"] == generic_waves, (H, W)

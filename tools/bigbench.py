@@ -29,6 +29,9 @@ def main():
             for n in (int(v) for v in a.envs.split(",")):
                 batch = BN.make_batch(dev, n, 1000, "o2arc", H, W)
                 bb, oo = BN.make_actions(a.steps, n, 2000, H, W)
+                if a.ops:
+                    lo, hi = (int(v) for v in a.ops.split("-"))
+                    oo = (lo + oo % (hi - lo + 1)).astype(np.int32)
                 bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
                 for i in range(a.steps):
                     batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), batch.elide_flag | 1, torch.cuda.current_stream(dev).cuda_stream)
