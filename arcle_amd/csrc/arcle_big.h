@@ -944,10 +944,11 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
         const int f0 = 16 * c;
         x.count();  // (the mask chunk: 16 bytes, or 2 of a bit row — counted as a chunk)
         if (packed) {
-          const uint32_t m = (uint32_t)(uint8_t)src[2 * c] | ((uint32_t)(uint8_t)src[2 * c + 1] << 8);
+          uint32_t m = (uint32_t)(uint8_t)src[2 * c] | ((uint32_t)(uint8_t)src[2 * c + 1] << 8);
+          m &= (1u << imin(imax(P - f0, 0), 16)) - 1u;  // (bits behind the plane's last cell are not the caller's to set)
 #pragma unroll
-          for (int k = 0; k < 16; k++)
-            if (f0 + k < P) v.b[k] = (int8_t)((m >> k) & 1u);
+          for (int q = 0; q < 4; q++)  // four bits -> four 0 / 1 bytes: bit i of the nibble lands on bit 8 i of n + (n << 7) + (n << 14) + (n << 21)
+            v.w[q] = bx::mul24((m >> (4 * q)) & 15u, 0x00204081u) & 0x01010101u;
         } else if (f0 + 16 <= P) {
           v = aligned ? ldg(src, c) : ldu(src + f0);
         } else {
@@ -956,7 +957,46 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
             if (f0 + k < P) v.b[k] = src[f0 + k];
         }
         stg(x.S, c, v);
-        if (v.w[0] | v.w[1] | v.w[2] | v.w[3]) {
+        const uint32_t any_bits = v.w[0] | v.w[1] | v.w[2] | v.w[3];
+        if (any_bits && x.wide()) {
+          // the chunk's share of the reductions on whole words (W >= 16: its cells lie in at most two plane rows): which bytes are non-zero as
+          // a 16-bit map (multiply-gather of the bytes' low bits), rows / first and last column of either part by count-zeros, the sum by
+          // a dot product with ones, the arg-max as "first 1" for a boolean chunk — the general chain (~12 instructions a cell) only
+          // for chunks that hold other values
+          uint32_t m16 = 0, posw = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            m16 |= ((bx::mul32(nz_bytes(v.w[q]) & 0x01010101u, 0x01020408u) >> 24) & 15u) << (4 * q);
+            posw |= pos_bytes(v.w[q]);
+            l_sum = bx::dot4_i8(v.w[q], l_sum);
+          }
+          const int i0 = div_w(f0, x.wm), j0 = f0 - i0 * W, n0 = imin(16, W - j0);
+          const uint32_t part0 = m16 & ((1u << n0) - 1u), part1 = m16 >> n0;
+          l_nz = 1;
+          l_pos |= posw != 0u;
+          if (part0) {
+            lx0 = imin(lx0, i0);
+            lx1 = imax(lx1, i0);
+            ly0 = imin(ly0, j0 + __builtin_ctz(part0));
+            ly1 = imax(ly1, j0 + 31 - __builtin_clz(part0));
+          }
+          if (part1) {
+            lx0 = imin(lx0, i0 + 1);
+            lx1 = imax(lx1, i0 + 1);
+            ly0 = imin(ly0, __builtin_ctz(part1));
+            ly1 = imax(ly1, 31 - __builtin_clz(part1));
+          }
+          if (!(any_bits & 0xfefefefeu)) {  // only 0 / 1: np.argmax = the first 1 (cells behind P hold 0)
+            const uint32_t key = (129u << 16) | (uint32_t)(0xffff - (f0 + __builtin_ctz(m16)));
+            if (key > l_amax) l_amax = key;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+              const uint32_t key = ((uint32_t)(v.b[k] + 128) << 16) | (uint32_t)(0xffff - (f0 + k));
+              if (f0 + k < P && key > l_amax) l_amax = key;
+            }
+          }
+        } else if (any_bits) {
           int i = div_w(f0, x.wm), j = f0 - i * W;
 #pragma unroll
           for (int k = 0; k < 16; k++) {

@@ -82,7 +82,7 @@ ARCLE_DEV uint32_t load32(const void* base, uint32_t off) {  // one dword per la
 }
 // 16 B plane store, write-through (`sc1`): the planes written by a step are only read again by the NEXT launch,
 // and per-XCD L2s are written back at every kernel boundary anyway; writing through lets that traffic overlap
-// the kernel instead of being flushed at its end (profiles/round1_store_policy_ab.txt: plain 11.46 us, nt 11.08,
+// the kernel instead of being flushed at its end (profiles/archive/round1_store_policy_ab.txt: plain 11.46 us, nt 11.08,
 // sc1 9.98 per launch of the C3 mix).  For state far beyond the 256 MiB Infinity Cache `nt` streams better
 // (tools/membench.hip, N = 131072: nt 43 us vs sc1 62 us), selectable at build time.
 // The trailing s_nop covers the ">64-bit VMEM store data" hazard: hipcc's hazard recogniser does not see into
@@ -1114,7 +1114,7 @@ static int stream_policy(const arcle_env* e, int n) {
 }
 
 // workgroups of 8 waves while the batch is one occupancy round or two (7.3 vs 7.7 us per launch at 8192 envs), 4 waves in the streaming
-// regime (76-79 vs 85-88 us at 131072 envs; in-box A/B, profiles/round2_experiments.txt) and for batches of at most two waves per SIMD
+// regime (76-79 vs 85-88 us at 131072 envs; in-box A/B, profiles/archive/round2_experiments.txt) and for batches of at most two waves per SIMD
 // (256-thread workgroups spread them over twice the CUs: c2 3.85 -> 3.69 us, profiles/round4_experiments.txt)
 static int launch_wpw(const arcle_env* e) {
   if (e->wpw_override) return e->wpw_override;

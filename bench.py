@@ -901,7 +901,7 @@ def other_configs_leg(dev, K=100):
         if name == "c2":
             rl.update({"bound": "launch-floor", "launch_floor_us": 2.5,
                        "note": "1024 envs = 1024 waves = 1/8 of one occupancy round of the chip: the launch cannot be shorter than the "
-                               "~2.5 us an EMPTY kernel of this shape takes (profiles/round2_membench.txt); the HBM fraction is reported "
+                               "~2.5 us an EMPTY kernel of this shape takes (profiles/archive/round2_membench.txt); the HBM fraction is reported "
                                "for completeness and is not the bound"})
         if name == "c5":
             seeds = [(int(bb[0, e, 0]), int(bb[0, e, 1])) for e in range(n) if 10 <= oo[0, e] < 20]
@@ -928,25 +928,40 @@ def _big_model_bytes(op, PS):
     return float(k.sum()) * PS / op.shape[0] + 56.0 * op.shape[1]  # + record in / out, counters, action, outputs per env
 
 
-def big_grid_case(dev, H, W, n, K=24, ops=None):
-    """One max_grid_size beyond 1024 cells: K graph-replayed step launches of the C3 action mix (one workgroup per env)."""
+def big_grid_case(dev, H, W, n, K=24, ops=None, ingress="bbox"):
+    """One max_grid_size beyond 1024 cells: K graph-replayed step launches of the C3 action mix (one workgroup per env).  `ingress`: "bbox"
+    tuples (the headline's form), or the same rectangles as full int8 masks ("mask") / bit-packed boolean masks ("bits")."""
     batch = make_batch(dev, n, 1000, "o2arc", H, W)
     bb, oo = make_actions(K, n, 2000, H, W)
     if ops is not None:  # (tools/bigbench.py: one class of operations only)
         oo = (ops[0] + oo % (ops[1] - ops[0] + 1)).astype(np.int32)
     bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
     FL = batch.elide_flag | STEP_AUTORESET
+    if ingress == "bbox":
+        def enqueue(sh):
+            for i in range(K):
+                batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), FL, sh)
+    else:
+        x1, x2 = torch.minimum(bbd[..., 0], bbd[..., 2]), torch.maximum(bbd[..., 0], bbd[..., 2])
+        y1, y2 = torch.minimum(bbd[..., 1], bbd[..., 3]), torch.maximum(bbd[..., 1], bbd[..., 3])
+        ii, jj = torch.arange(H, device=dev)[None, :, None], torch.arange(W, device=dev)[None, None, :]
+        pay = []
+        for i in range(K):  # (one step's masks at a time: 16 384 x 127 x 127 int8 = 264 MB)
+            m = ((ii >= x1[i, :, None, None]) & (ii <= x2[i, :, None, None]) & (jj >= y1[i, :, None, None]) & (jj <= y2[i, :, None, None])).to(torch.int8).contiguous()
+            pay.append(batch.pack_mask_bits(m) if ingress == "bits" else m)
+        fn = batch.L.arcle_step_bits if ingress == "bits" else batch.L.arcle_step_mask
 
-    def enqueue(sh):
-        for i in range(K):
-            batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), FL, sh)
+        def enqueue(sh):
+            for i in range(K):
+                rc = fn(batch._h, pay[i].data_ptr(), ood[i].data_ptr(), batch._reward_ptr, batch._term_ptr, FL, sh)
+                assert rc == 0
     alg, issued, _ = counted_bytes(batch, enqueue, K, dev)
     sec, _ = graph_time(dev, enqueue, K)
-    rl = roofline_block("arcle_big_step_kernel", sec, alg, issued, n, PS=batch.PS, planes=len(batch.planes),
-                        note="bytes counted by the kernel in this run (every 16-byte access a thread issues; `algorithmic` = the same without "
-                             "the row padding); bound: a thread's per-chunk instruction chain x the op's dependent phases, not HBM")
+    rl = roofline_block("arcle_big_step_lean<2, tuples>" if ingress == "bbox" else "arcle_big_step_lean<2, masks>", sec, alg, issued, n, PS=batch.PS, planes=len(batch.planes),
+                        note="bytes counted by the generic kernel replaying the same launches in this run (every 16-byte access a thread issues; "
+                             "`algorithmic` = the same without the row padding); bound: instructions issued per env (DESIGN.md §3), not HBM")
     rl["modelled_bytes_per_launch"] = _big_model_bytes(oo, batch.PS)  # (the per-op-kind model the first measurements of this path used)
-    return {"workload": f"O2ARCv2Env {H}x{W}, {n} envs, C3 action mix (max_grid_size beyond one wavefront: one workgroup per env)", "envs": n,
+    return {"workload": f"O2ARCv2Env {H}x{W}, {n} envs, C3 action mix, {ingress} ingress (max_grid_size beyond one wavefront: one workgroup per env)", "envs": n,
             "plane_stride": batch.PS, "us_per_step_batch": sec * 1e6, "value": n / sec, "unit": "env-steps/s", "roofline": rl}
 
 

@@ -655,7 +655,8 @@ class BigEmuTwoBackend(BigEmuBackend):
 
 
 class BigEmuFourBackend(BigEmuBackend):
-    """... four chunks per thread (ARCLE_BIG_CPT=4 / a forced small workgroup)."""
+    """... four chunks per thread: the template's general form (the product launches one or two, arcle_big.hip launch_step: four lost on
+    MI355X, profiles/round6_experiments.txt §2d)."""
     name = "bigemu_four"
     CPT = 4
 
@@ -892,10 +893,13 @@ def replay_fixture(backend_cls, name, max_steps=None, flags=0):
 
 # ---- random differential traces (no reference needed: backend vs oracle) ---------------------------------
 def random_trace_compare(backend_cls, kind, ops, H, W, N, S, seed, max_trial=-1, flags=0, op_weights=None,
-                         bad_ops=False, new_forms=False):
+                         bad_ops=False, new_forms=False, int8_masks=False):
     """Steps `backend_cls` and the oracle side by side on seeded random tasks/actions; returns mismatches.
     new_forms: the backend under test receives bbox actions as 5-tuple records (bbox5) and masks bit-packed (bits; the masks are
-    boolean then) — the oracle gets the classic forms of the same actions."""
+    boolean then) — the oracle gets the classic forms of the same actions.
+    int8_masks: every action is a full mask of arbitrary int8 values (out of the Gym contract, but NumPy takes them: sel > 0 / != 0 / sum /
+    argmax differ then): sparse values in [-3, 3], one cell of 1 / 2 / -1 / 127 / -128, the pair {2, -1} (sum 1, arg-max at the 2), 0 / 1
+    noise with a few negatives, a block of ones holding one 5."""
     rng = np.random.default_rng(seed)
     be = backend_cls(N, H, W, max_trial, kind, ops)
     orc = OracleBackend(N, H, W, max_trial, kind, ops)
@@ -930,8 +934,26 @@ def random_trace_compare(backend_cls, kind, ops, H, W, N, S, seed, max_trial=-1,
         op = rng.choice(n_ops, size=N, p=w).astype(np.int32)
         if bad_ops and s % 7 == 3:
             op[rng.integers(0, N)] = n_ops + rng.integers(0, 3)
-        ing = ["bbox", "bbox", "point", "mask"][rng.integers(0, 4)]
-        if ing == "bbox":
+        ing = "mask" if int8_masks else ["bbox", "bbox", "point", "mask"][rng.integers(0, 4)]
+        if int8_masks:
+            pay = np.zeros((N, H, W), np.int8)
+            for n in range(N):
+                t = rng.integers(0, 6)
+                x, y = rng.integers(0, H), rng.integers(0, W)
+                if t == 1:
+                    pay[n] = rng.integers(-3, 4, (H, W)) * (rng.random((H, W)) < rng.random() * 0.1)
+                elif t == 2:
+                    pay[n, x, y] = [1, 2, -1, 127, -128][rng.integers(0, 5)]
+                elif t == 3:
+                    pay[n, x, y] = 2
+                    pay[n, rng.integers(0, H), rng.integers(0, W)] -= 1
+                elif t == 4:
+                    pay[n] = rng.random((H, W)) < rng.random() * 0.3
+                    pay[n][rng.random((H, W)) < 0.01] = -1
+                elif t == 5:
+                    pay[n, x:x + rng.integers(1, 6), y:y + rng.integers(1, 6)] = 1
+                    pay[n, x, y] = 5
+        elif ing == "bbox":
             pay = np.stack([rng.integers(0, H, N), rng.integers(0, W, N), rng.integers(0, H, N), rng.integers(0, W, N)], 1)
             small = rng.random(N) < 0.5
             pay[small, 2] = np.minimum(H - 1, pay[small, 0] + rng.integers(0, 4, small.sum()))

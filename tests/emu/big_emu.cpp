@@ -48,6 +48,8 @@ inline uint64_t brev64(uint64_t x) {
 inline void release_store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline int uniform(int v) { return v; }
 inline uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+inline uint32_t mul32(uint32_t a, uint32_t b) { return a * b; }
+inline int dot4_i8(uint32_t v, int acc) { return acc + (int8_t)(v & 0xff) + (int8_t)((v >> 8) & 0xff) + (int8_t)((v >> 16) & 0xff) + (int8_t)(v >> 24); }
 inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | (uint64_t)lo) >> (sh & 31u)); }
 }  // namespace bx
 
@@ -59,8 +61,9 @@ extern "C" int big_emu_params_size(void) { return (int)sizeof(BigParams); }
 extern "C" int big_emu_lds_bytes(int PS, int H) { return arcle_big::lds_bytes(PS, H); }
 
 // what: 0 step (generic instantiation), 1 reset (mode 0 / 1 / 2), 2 rows out (mode 0 flat / 1 packed), 3 state rows in,
-//       4 step, a LEAN instantiation for this ingress family; mode = its compile-time bound on the chunks per thread (1 / 2 / 4: the forms
-//         the product launches — 2 by default; 0: the run-time loop, which lets 16 host threads walk a plane of any size)
+//       4 step, a LEAN instantiation for this ingress family; mode = its compile-time bound on the chunks per thread (1 / 2: the forms the
+//         product launches — 2 by default; 4: the template's general form; 0: the run-time loop, which lets 16 host threads walk a plane of
+//         any size)
 extern "C" int big_emu_run(int what, const BigParams* p_in, int mode, int nthreads) {
   const BigParams filled = arcle_big::with_magic(*p_in);  // (what the product's launchers do, arcle_big.hip)
   const BigParams* const p = &filled;

@@ -58,6 +58,16 @@ def test_big_emulator_two_chunks_per_thread_mask_forms_and_fill():
     assert not errs, "\n".join(errs[:10])
 
 
+@pytest.mark.parametrize("backend", ["BigEmuBackend", "BigEmuTwoBackend", "BigEmuGenericBackend"])
+@pytest.mark.parametrize("H,W", [(40, 40), (33, 48), (100, 20), (127, 9)])
+def test_big_emulator_int8_masks_of_any_value(backend, H, W):
+    """masks of arbitrary int8 values: the whole-word reductions of the mask ingest (non-zero map, rows / columns by count-zeros, dot-product
+    sum, "first 1" arg-max with the per-cell chain behind it for chunks that hold other values) against the oracle's per-cell loops"""
+    w = [3] * 10 + [3] * 10 + [2] * 8 + [2] * 7  # (Color / FloodFill weighted up: they read sum and arg-max)
+    errs = B.random_trace_compare(getattr(B, backend), "o2arc", O.o2arc_ops(), H, W, N=4, S=40, seed=H + 3 * W, flags=3, max_trial=3, op_weights=w, int8_masks=True)
+    assert not errs, "\n".join(errs[:10])
+
+
 def test_big_emulator_four_chunks_per_thread_instantiation():
     errs = B.random_trace_compare(B.BigEmuFourBackend, "o2arc", O.o2arc_ops(), 64, 48, N=3, S=40, seed=31, flags=3, max_trial=3, bad_ops=True)
     assert not errs, "\n".join(errs[:10])

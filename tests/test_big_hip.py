@@ -52,6 +52,17 @@ def test_hip_big_record_and_bit_packed_forms(H, W):
     assert np.array_equal(be.pack_mask_bits(m), B.pack_bits(m))
 
 
+@pytest.mark.parametrize("H,W,flags", [(40, 40, 3), (33, 48, 3), (64, 64, 3), (100, 20, 3), (127, 127, 3), (127, 9, 3), (48, 40, 0)])
+def test_hip_big_int8_masks_of_any_value(H, W, flags):
+    """masks of arbitrary int8 values (negative, > 1, the {2, -1} pair whose sum is 1): the whole-word reductions of the mask ingest in the
+    LEAN kernels (one wavefront per env at 40 x 40, eight at 127 x 127) and the per-cell form at W < 16 — every field of every env against
+    the oracle"""
+    w = [3] * 10 + [3] * 10 + [2] * 8 + [2] * 7
+    errs = B.random_trace_compare(B.HipBackend, "o2arc", O.o2arc_ops(), H, W, N=48, S=40, seed=H + 3 * W + flags, flags=flags, max_trial=3, op_weights=w,
+                                  int8_masks=True)
+    assert not errs, "\n".join(errs[:10])
+
+
 @pytest.mark.parametrize("variant", ["o2arc_exotic", "o2arc_crop"])
 @pytest.mark.parametrize("size", [45, 127])
 def test_hip_big_exotic_tables(variant, size):

@@ -322,7 +322,7 @@ def test_autotune_leaves_packed_rows_and_status_alone():
     import torch
     import bench
     from arcle_amd.engine import STEP_PACK_OBS
-    dev, n, K = torch.device("cuda:0"), 4096, 8
+    dev, n, K = torch.device("cuda:0"), 4096, 12
     bb_np, op_np = _streams(K, n, 77)
     op_np[:, ::97] = 63  # (op indices beyond the table: every timed launch raises ARCLE_ST_BAD_OP)
     bb, op = torch.from_numpy(bb_np).to(dev), torch.from_numpy(op_np).to(dev)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarises the bench lines under gpurun_out/ (written by tools/gpu_bench_profiles.sh) into profiles/round2_bench_configs.txt."""
+"""Summarises the bench lines under gpurun_out/ (written by tools/gpu_bench_profiles.sh) into profiles/archive/round2_bench_configs.txt."""
 import glob, json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 names = ["bench.log", "bench_k20.log", "bench_c2.log", "bench_c4.log", "bench_c5.log", "bench_n32768.log", "bench_n131072.log",
