@@ -58,7 +58,11 @@ def build(force=False, verbose=False):
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]  # (run-time chunk loops carry an unroll request meant for the LEAN instantiations)
     objs = [os.path.join(_CSRC, os.path.basename(u)[:-4] + ".o") for u in UNITS]
     cmds = [common + ["-mllvm", "-amdgpu-kernarg-preload-count=13", "-c", UNITS[0], "-o", objs[0]],
-            common + ["-c", UNITS[1], "-o", objs[1]]]
+            # -amdgpu-atomic-optimizer-strategy=DPP: the big-grid kernels reduce a selection (any / sum / arg-max / bounding box) with LDS
+            # atomics on ONE address per value; the compiler's default rewrites each into a scalar loop over the active lanes (~8 scalar
+            # instructions a lane: 1280 instead of 350 scalar instructions a wave, mask-ingress steps twice as slow), DPP into a
+            # cross-lane reduction + one atomic per wave (profiles/round6_experiments.txt §2f)
+            common + ["-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP", "-c", UNITS[1], "-o", objs[1]]]
     if verbose:
         for c in cmds:
             print(" ".join(c))

@@ -34,8 +34,19 @@ def main():
                     lo, hi = (int(v) for v in a.ops.split("-"))
                     oo = (lo + oo % (hi - lo + 1)).astype(np.int32)
                 bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
+                if a.ingress != "bbox":  # the same rectangles as int8 masks / bit rows
+                    x1, x2 = torch.minimum(bbd[..., 0], bbd[..., 2]), torch.maximum(bbd[..., 0], bbd[..., 2])
+                    y1, y2 = torch.minimum(bbd[..., 1], bbd[..., 3]), torch.maximum(bbd[..., 1], bbd[..., 3])
+                    ii, jj = torch.arange(H, device=dev)[None, :, None], torch.arange(W, device=dev)[None, None, :]
                 for i in range(a.steps):
-                    batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), batch.elide_flag | 1, torch.cuda.current_stream(dev).cuda_stream)
+                    if a.ingress == "bbox":
+                        batch.step_bbox_ptr(bbd[i].data_ptr(), ood[i].data_ptr(), batch.elide_flag | 1, torch.cuda.current_stream(dev).cuda_stream)
+                    else:
+                        m = ((ii >= x1[i, :, None, None]) & (ii <= x2[i, :, None, None]) & (jj >= y1[i, :, None, None]) & (jj <= y2[i, :, None, None])).to(torch.int8).contiguous()
+                        if a.ingress == "bits":
+                            batch.step_bits(batch.pack_mask_bits(m), ood[i], batch.elide_flag | 1)
+                        else:
+                            batch.step_mask(m, ood[i], batch.elide_flag | 1)
                 torch.cuda.synchronize()
                 print(f"{H}x{W} envs {n}: {a.steps} eager steps", flush=True)
         return

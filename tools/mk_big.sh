@@ -4,6 +4,6 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd)
 name=$1; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $R/arcle_amd/csrc/arcle_big.hip -o /tmp/big_$name.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -mllvm -amdgpu-atomic-optimizer-strategy=DPP "$@" -c $R/arcle_amd/csrc/arcle_big.hip -o /tmp/big_$name.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o $R/gpurun_lib_$name.so /tmp/hip_main.o /tmp/big_$name.o
 ls -la $R/gpurun_lib_$name.so

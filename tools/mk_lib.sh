@@ -6,7 +6,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 name=$1; shift
 T=$(mktemp -d)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=13 "$@" -c $R/arcle_amd/csrc/arcle_hip.hip -o $T/a.o 2>/dev/null &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $R/arcle_amd/csrc/arcle_big.hip -o $T/b.o 2>/dev/null &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -mllvm -amdgpu-atomic-optimizer-strategy=DPP "$@" -c $R/arcle_amd/csrc/arcle_big.hip -o $T/b.o 2>/dev/null &
 wait
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o $R/gpurun_lib_$name.so $T/a.o $T/b.o
 rm -rf $T
