@@ -1174,10 +1174,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        import datetime
+        # (a bounded wait: a rank that dies between two collectives must not leave the others in RCCL's default 10-minute watchdog — every
+        # phase of an N > 1 run is seconds long; the CPU baseline and the extras legs run at N = 1 only)
+        tmo = datetime.timedelta(seconds=int(os.environ.get("ARCLE_BENCH_DIST_TIMEOUT", "300")))
         if shared_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
 
     from arcle_amd import actions
     from arcle_amd.engine import EnvBatch

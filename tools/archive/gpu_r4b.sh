@@ -8,5 +8,5 @@ for N in 256 512 1024 2048 4096 8192; do for W in 8 4; do
   echo -n "c2 N=$N wpw=$W: "; ARCLE_WPW=$W timeout 300 python bench.py --config c2 --envs-per-gpu $N --no-cpu-baseline --no-extras --steps 200 --warmup 20 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('%.2f us' % d['roofline']['avg_launch_us'])"
 done; done 2>&1 | tee $O/r4_c2_sweep.txt
-echo "== streaming A/B"; bash tools/gpu_r4_stream.sh
+echo "== streaming A/B"; bash tools/archive/gpu_r4_stream.sh
 echo "== bench"; timeout 900 python bench.py --no-cpu-baseline > $O/bench.log 2> $O/bench.err; echo "bench rc=$?"; tail -c 3500 $O/bench.log

@@ -14,4 +14,4 @@ for r in 1 2; do for N in 1024 2048 4096; do for S in 0 4096; do
   echo -n "r$r c3 N=$N spec_small_max=$S: "; ARCLE_SPEC_SMALL_MAX=$S timeout 300 python bench.py --envs-per-gpu $N --no-cpu-baseline --no-extras --no-ordered --steps 200 --warmup 20 2>/dev/null | q
 done; done; done
 } 2>&1 | tee $O/r4_small_spec.txt
-SIZES="16384 24576 32768 65536 131072 262144" bash tools/gpu_r4_stream.sh
+SIZES="16384 24576 32768 65536 131072 262144" bash tools/archive/gpu_r4_stream.sh
