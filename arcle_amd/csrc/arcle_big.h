@@ -816,6 +816,47 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
 // X = CtxT<ONE, LEAN> (what the launch guarantees, see there); ING: -1 = the ingress form is p.ingress whatever it is, ING_T_MASKS = one of
 // the mask forms (int8 / bit-packed), ING_T_TUPLES = one of the tuple forms (bbox / point / bbox5) — the other family's code is not compiled.
 enum { ING_T_ANY = -1, ING_T_MASKS = 0, ING_T_TUPLES = 1 };
+// diagnostic builds (-DARCLE_BIG_STOP_AT=k, tools/gpu_r6k.sh): the workgroup leaves after stage k of the step — 1 the env's scalars are in,
+// 2 the selection is built and the op's plane staged, 3 the geometry is known, 4 the op has run — so that PMC passes count the instructions
+// per stage (results are meaningless; never defined in the product build)
+// (-DARCLE_BIG_EXP_S=n / -DARCLE_BIG_EXP_V=n: n dependent scalar / vector adds injected into every wave — what one more instruction of
+// either kind costs a launch, profiles/round6_experiments.txt §2h)
+#if defined(ARCLE_BIG_EXP_S) || defined(ARCLE_BIG_EXP_V)
+#define BIG_INJECT()                                                                    \
+  do {                                                                                  \
+    int es_ = opi, ev_ = tid;                                                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < BIG_EXP_S_N; k_++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(es_)); \
+    _Pragma("unroll") for (int k_ = 0; k_ < BIG_EXP_V_N; k_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(ev_)); \
+    if (es_ == 0x7fffffff || ev_ == 0x7fffffff) st |= 1u << 31;                         \
+  } while (0)
+#ifdef ARCLE_BIG_EXP_S
+enum { BIG_EXP_S_N = ARCLE_BIG_EXP_S };
+#else
+enum { BIG_EXP_S_N = 0 };
+#endif
+#ifdef ARCLE_BIG_EXP_V
+enum { BIG_EXP_V_N = ARCLE_BIG_EXP_V };
+#else
+enum { BIG_EXP_V_N = 0 };
+#endif
+#else
+#define BIG_INJECT() \
+  do {               \
+  } while (0)
+#endif
+#ifdef ARCLE_BIG_STOP_AT
+#define BIG_STOP(k)                 \
+  do {                              \
+    if (ARCLE_BIG_STOP_AT == (k)) { \
+      if (tid == 0) p.reward[env] = (int)st + cnt0 + opi; \
+      return;                       \
+    }                               \
+  } while (0)
+#else
+#define BIG_STOP(k) \
+  do {              \
+  } while (0)
+#endif
 template <class X, int ING>
 ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
   X x(p, env, lds);
@@ -853,6 +894,8 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
     q->neq = 0;
   }
   bx::sync();  // every thread holds the record / counters; the reduction block is clear
+  BIG_INJECT();
+  BIG_STOP(1);
 
   do {
     if (scratch_rows) {  // arcle_transition_rows: a row whose src_env names no resident env is passed through untouched
@@ -1101,6 +1144,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       bx::sync();
     }
 
+    BIG_STOP(2);
     // ---- reset_sel / keep_sel (object.py:10-41): scalar part first — an object op reads `active` after the wrapper ran ----
     const int8_t active_before = r[ARCLE_REC_ACTIVE];
     if (oflags & ARCLE_OPF_RESET_SEL) r[ARCLE_REC_ACTIVE] = 0;
@@ -1173,6 +1217,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
     else if ((oflags & ARCLE_OPF_RESET_SEL) && !((flags & ARCLE_STEP_ELIDE_SELECTED) && active_before == 0)) sel_pending = 1;
     // (the only ops that recycle the S tile — Rotate / Flip that proceed — end in place(): a pending keep_sel never needs S after them)
 
+    BIG_STOP(3);
     int eq = -1;  // grid == answer, evaluated at most once
     bool grid_moved = true;  // (conservative: every op below that stores the grid plane ends with a barrier before the compare)
     switch (kind) {  // transition(): self.operations[op](state, action)   o2arcenv.py:149-151
@@ -1508,6 +1553,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       BIG_EACH_CHUNK(x, c) x.gs(ARCLE_PL_SELECTED, c, zero_chunk());
     }
 
+    BIG_STOP(4);
     // reward(): only the LAST op of the table can be rewarded (o2arcenv.py:121-128)
     if (opi == p.n_ops - 1) {
       if (eq < 0) {
