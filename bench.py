@@ -405,7 +405,9 @@ def emit(out, a):
                                  "single_env_step": us("single_env", "us_per_step"), "transition_rows": us("transition_rows", "us_per_step_batch"),
                                  "rollout": us("rollout", "us_per_step_batch"), "c2": us("other_configs", "c2", "us_per_step_batch"),
                                  "c4": us("other_configs", "c4", "us_per_step_batch"), "c5": us("other_configs", "c5", "us_per_step_batch"),
-                                 "big_64x64_4096": us("big_grid", "64x64_4096", "us_per_step_batch")}
+                                 "big_64x64_4096": us("big_grid", "64x64_4096", "us_per_step_batch"),
+                                 "big_40x40_16384": us("big_grid", "40x40_16384", "us_per_step_batch"),
+                                 "big_40x40_16384_bits": us("big_grid", "40x40_16384_bits", "us_per_step_batch")}
     cb = out.get("cpu_baseline")
     if cb:
         ns = cb["numpy_step"]
@@ -968,7 +970,8 @@ def big_grid_case(dev, H, W, n, K=24, ops=None, ingress="bbox"):
 def big_grid_leg(dev):
     """Grids of more than 1024 cells (the reference takes any max_grid_size, base.py:37-49): the workgroup-per-env kernels, timed like the
     other legs.  Not the headline and not ARC's regime (30 x 30) — the completeness path."""
-    return {"64x64_4096": big_grid_case(dev, 64, 64, 4096), "127x127_1024": big_grid_case(dev, 127, 127, 1024)}
+    return {"64x64_4096": big_grid_case(dev, 64, 64, 4096), "127x127_1024": big_grid_case(dev, 127, 127, 1024),
+            "40x40_16384": big_grid_case(dev, 40, 40, 16384), "40x40_16384_bits": big_grid_case(dev, 40, 40, 16384, K=12, ingress="bits")}
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -27,6 +27,11 @@ if BE is not getattr(B, "EmuBackend"):
         errs = B.random_trace_compare(BE, "o2arc", ops, H, W, N=max(N // SCALE, 2), S=max(S // 4, 8), seed=H * 131 + W + flags, max_trial=mt, flags=flags,
                                       bad_ops=True)
         print(f"{name:40s} N={N} S={max(S // 4, 8)}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
+    # round 6: the mask ingest on whole words — masks of arbitrary int8 values, and the record / bit-row forms — through the two-chunk kernels
+    for name, H, W, N, kw in (("40x40 big-grid int8 masks of any value", 40, 40, 256, dict(int8_masks=True)), ("64x48 big-grid int8 masks of any value", 64, 48, 128, dict(int8_masks=True)),
+                              ("127x127 big-grid int8 masks of any value", 127, 127, 32, dict(int8_masks=True)), ("50x50 big-grid bbox5 / bit rows", 50, 50, 128, dict(new_forms=True))):
+        errs = B.random_trace_compare(BE, "o2arc", ops, H, W, N=max(N // SCALE, 2), S=max(S // 4, 8), seed=H * 7 + W, max_trial=3, flags=3, **kw)
+        print(f"{name:40s} N={N} S={max(S // 4, 8)}: {'OK' if not errs else errs[:3]}  ({time.time() - t0:.0f} s)", flush=True)
     O.set_threads(1)
 if os.environ.get("SOAK_BACKEND") == "BigEmuBackend":
     sys.exit(0)
