@@ -154,7 +154,9 @@ def emu_lib():
         d = os.path.join(ROOT, "tests", "emu")
         so, src = os.path.join(d, "libwave_emu.so"), os.path.join(d, "wave_emu.cpp")
         hdr = os.path.join(ROOT, "arcle_amd", "csrc", "arcle_wave.h")
-        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        if os.environ.get("ARCLE_WAVE_EMU_LIB"):  # (tests/test_emu_sanitized.py: the ASan + UBSan build)
+            so = os.environ["ARCLE_WAVE_EMU_LIB"]
+        elif not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
         _emu = ctypes.CDLL(so)
         _emu.emu_run.argtypes = [ctypes.c_int, ctypes.POINTER(_StepParams)]
@@ -451,7 +453,9 @@ def big_emu_lib():
         d = os.path.join(ROOT, "tests", "emu")
         so, src = os.path.join(d, "libbig_emu.so"), os.path.join(d, "big_emu.cpp")
         hdr = os.path.join(ROOT, "arcle_amd", "csrc", "arcle_big.h")
-        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        if os.environ.get("ARCLE_BIG_EMU_LIB"):  # (tests/test_emu_sanitized.py: the ASan + UBSan build)
+            so = os.environ["ARCLE_BIG_EMU_LIB"]
+        elif not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-o", so, src])
         _big_emu = ctypes.CDLL(so)
         _big_emu.big_emu_run.argtypes = [ctypes.c_int, ctypes.POINTER(_BigParams), ctypes.c_int, ctypes.c_int]
