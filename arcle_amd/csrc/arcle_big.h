@@ -3,18 +3,26 @@
 // (/root/reference/arcle/envs/base.py:37-49); ARC itself never exceeds 30 x 30, so this is the completeness path, not the headline:
 // the 30 x 30 batch keeps its one-wavefront-per-env kernels (arcle_wave.h).
 //
-// Execution model — ONE WORKGROUP per env (128 … 512 threads: about one 16-byte chunk of a plane per thread):
+// Execution model — ONE WORKGROUP per env (64 … 512 threads: two 16-byte chunks of a plane per thread in the compile-time-specialised LEAN
+// launches — one wavefront per env at 40 x 40 —, one chunk per thread in the generic kernel):
 //   * a plane is PS = H*W rounded up to 128 bytes; thread t owns the 16-byte chunks t, t + NT, t + 2 NT ... of it: every global plane
 //     access is one aligned 16 B load / store per thread, consecutive threads on consecutive chunks (fully coalesced);
-//   * the selection and up to three planes are staged in the workgroup's LDS (4 x PS bytes + 320, dynamic: 7 KB at 40 x 40, 64 KB at
-//     127 x 127); the geometric ops work on whole chunks: object lift / place, Copy, Paste and Crop are FLAT SHIFTS of a plane (16
-//     consecutive tile bytes through five dword reads and funnel shifts, the op's rectangle as a byte mask of two column runs), Rotate /
-//     Flip gather cell by cell with an add + clamp + byte read and take the rectangle as a mask (W < 16 keeps per-cell forms);
-//   * reductions (any / sum / arg-max / bounding box of the selection, grid == answer) are LDS atomics + a workgroup barrier;
+//   * the selection and up to three planes are staged in the workgroup's LDS (16 guard bytes + 4 x PS bytes + 320, dynamic: 7 KB at 40 x 40,
+//     64 KB at 127 x 127); the geometric ops work on whole chunks: object lift / place, Copy, Paste and Crop are FLAT SHIFTS of a plane (16
+//     consecutive tile bytes through five consecutive dword reads behind one clamp and funnel shifts, the op's rectangle as a byte mask of
+//     two column runs built by packed subtractions), Rotate / Flip gather cell by cell with an add + clamp + byte read and take the
+//     rectangle as a mask (W < 16 keeps per-cell forms);
+//   * reductions (any / sum / arg-max / bounding box of a mask selection, grid == answer) are formed per chunk on whole words and combined
+//     by LDS atomics on one address per value + a workgroup barrier — compiled with -amdgpu-atomic-optimizer-strategy=DPP (arcle_amd/_lib.py):
+//     a cross-lane reduction in every wavefront and ONE atomic per wavefront (the compiler's default turns each into a scalar loop over
+//     the lanes; tuple selections need none: their reductions are arithmetic on the tuple);
 //   * FloodFill runs on 128-bit row boards (one thread per row): a pass pulls the fill from the rows above and below and spreads it along
 //     the row's eligible runs with the carry trick (E + F ripples through a run of ones), until no row changes;
-//   * per-env scalars (the 16-byte record, counters, op descriptor) are loaded by every thread — the same address, one broadcast
-//     request — and kept replicated in registers; thread 0 writes them back.
+//   * per-env scalars (the 16-byte record, counters, op descriptor) are loaded by every thread — the same address: the compiler proves it
+//     and issues scalar loads — and kept in scalar registers; thread 0 writes them back.
+// What a launch costs is the number of instructions its wavefronts issue (one per ~4 cycles and SIMD, of any kind; one scalar instruction
+// per cycle and CU) — and every wavefront of a workgroup runs the env's whole scalar program: hence few wavefronts per env, compile-time
+// flag sets and the instruction diet of the whole-chunk forms (profiles/round6_experiments.txt §1-2).
 // All control flow around barriers is workgroup-uniform (it depends only on the env's record, the op and the reduced selection).
 //
 // The same header is compiled by hipcc for gfx950 (arcle_big.hip) and by g++ for tests/emu/big_emu.cpp, which runs the body on host
