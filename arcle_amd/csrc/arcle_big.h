@@ -257,8 +257,11 @@ typedef CtxT<0, false> Ctx;
 // "for every chunk c of a plane that this thread owns" (c = tid, tid + NT, ...; with X::CPT > 0 at most that many: the loop unrolls fully.
 // Kept ROLLED — a loop of uniform trip count with the thread's guard inside — the two-chunk kernels spill fewer scalar registers but run
 // ~10 % more instructions per env and lose 3 %: profiles/round6_experiments.txt §2)
-#define BIG_EACH_CHUNK(x, c) \
-  _Pragma("unroll") for (int c = (x).tid, n_##c = 0; c < (x).nch && ((x).CPT == 0 || n_##c < (x).CPT); c += (x).NT, n_##c++)
+// (CPT >= 2: a launch that NEEDS its second chunk has fewer threads than the plane has chunks, so every thread's FIRST chunk exists — no
+// guard around it, three scalar instructions fewer per loop; the launchers pick CPT = ceil(chunks / threads) exactly)
+#define BIG_EACH_CHUNK(x, c)                                                                                                              \
+  _Pragma("unroll") for (int c = (x).tid, n_##c = 0; (((x).CPT >= 2 && n_##c == 0) || c < (x).nch) && ((x).CPT == 0 || n_##c < (x).CPT); \
+                         c += (x).NT, n_##c++)
 template <int CPT_, bool LEAN_>
 ARCLE_BIG_DEV void CtxT<CPT_, LEAN_>::stage(int8_t* dst, const int8_t* src) const {
   // (all loads first, then the LDS writes: the chunks' round trips overlap)
@@ -267,7 +270,7 @@ ARCLE_BIG_DEV void CtxT<CPT_, LEAN_>::stage(int8_t* dst, const int8_t* src) cons
 #pragma unroll
     for (int k = 0; k < CPT_; k++) {
       const int c = tid + k * NT;
-      if (c < nch) {
+      if ((CPT_ >= 2 && k == 0) || c < nch) {
         count();
         v[k] = ldg(src, c);
       }
@@ -275,7 +278,7 @@ ARCLE_BIG_DEV void CtxT<CPT_, LEAN_>::stage(int8_t* dst, const int8_t* src) cons
 #pragma unroll
     for (int k = 0; k < CPT_; k++) {
       const int c = tid + k * NT;
-      if (c < nch) stg(dst, c, v[k]);
+      if ((CPT_ >= 2 && k == 0) || c < nch) stg(dst, c, v[k]);
     }
     return;
   }
@@ -756,9 +759,10 @@ ARCLE_BIG_DEV Chunk cut_out16(const X& x, int c, int x0, int y0, int h, int w) {
 // `cut`: nullptr when `bg` is the background itself; else `bg` is the grid and the background is where(cut > 0, 0, grid) (object.py:87-88).
 // `lift_delta` >= 0 (W >= 16, a fresh selection that is only MOVED): there are no object tiles — the object is the grid `bg` under the
 // selection `cut`, read at the lift's flat shift on top of the placement's: one gather pass instead of lift + barrier + place.
-template <class X>
-ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q,
-                         int lift_delta = -1) {
+// CUT / LIFT: whether `cut` is given / the lift is fused — compile-time facts of every call site but one, so that the tests leave the
+// per-word loops (a uniform branch costs two scalar instructions every time it is reached).
+template <bool CUT, bool LIFT, class X>
+ARCLE_BIG_DEV void place_t(const X& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q, int lift_delta) {
   const int W = x.W;
   const int px = r[ARCLE_REC_OBJECT_POS], py = r[ARCLE_REC_OBJECT_POS + 1];
   const int h = r[ARCLE_REC_OBJECT_DIM], w = r[ARCLE_REC_OBJECT_DIM + 1];
@@ -771,7 +775,7 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
     BIG_EACH_CHUNK(x, c) {
       const Chunk bgc = ldg(bg, c);
       Chunk pv, qv;
-      if (lift_delta >= 0) {
+      if (LIFT) {
         const Chunk sv = shifted16(cut, 16 * c - d2 + lift_delta, x.PS);
         pv = shifted16(bg, 16 * c - d2 + lift_delta, x.PS);
 #pragma unroll
@@ -789,7 +793,7 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         uint32_t b = bgc.w[q];
-        if (cut) b &= ~x.sel_pos(reinterpret_cast<const uint32_t*>(cut)[4 * c + q]);  // background = where(sel > 0, 0, grid)
+        if (CUT) b &= ~x.sel_pos(reinterpret_cast<const uint32_t*>(cut)[4 * c + q]);  // background = where(sel > 0, 0, grid)
         const uint32_t m = in.w[q] & pos_bytes(pv.w[q]);                                // :138 where=(p > 0)
         grid.w[q] = (pv.w[q] & m) | (b & ~m);
         sel.w[q] = qv.w[q] & in.w[q];                                                   // :165
@@ -802,7 +806,7 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
   BIG_EACH_CHUNK(x, c) {
     Chunk sel = zero_chunk();
     const Chunk bgc = ldg(bg, c);
-    const Chunk cutc = cut ? ldg(cut, c) : zero_chunk();
+    const Chunk cutc = CUT ? ldg(cut, c) : zero_chunk();
     const Chunk grid = build_chunk(c, W, x.wm, x.P, [&](int f, int i, int j) {
       const int k = f & 15;
       const bool in = draw && i >= stx && i < edx && j >= sty && j < edy;
@@ -818,12 +822,19 @@ ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const in
   }
 }
 
+template <class X>
+ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q) {
+  if (cut) place_t<true, false>(x, r, bg, cut, O, Q, -1);
+  else place_t<false, false>(x, r, bg, nullptr, O, Q, -1);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 // one step() of one env: O2ARCv2Env.step (o2arcenv.py:130-147) / ARCEnv.step (arcenv.py:155-172) / RawARCEnv.step (arcenv.py:60-76)
 // ------------------------------------------------------------------------------------------------------------------------------------
-// X = CtxT<ONE, LEAN> (what the launch guarantees, see there); ING: -1 = the ingress form is p.ingress whatever it is, ING_T_MASKS = one of
-// the mask forms (int8 / bit-packed), ING_T_TUPLES = one of the tuple forms (bbox / point / bbox5) — the other family's code is not compiled.
-enum { ING_T_ANY = -1, ING_T_MASKS = 0, ING_T_TUPLES = 1 };
+// X = CtxT<CPT, LEAN> (what the launch guarantees, see there); ING: ING_T_ANY = the ingress form is p.ingress whatever it is, ING_T_MASKS =
+// one of the mask forms (int8 / bit-packed), ING_T_TUPLES = one of the tuple forms (bbox / point / bbox5) — the other family's code is not
+// compiled —, ING_T_EXACT + f = exactly the form f (enum arcle_ingress): the form's tests and the other forms' loads fold away too.
+enum { ING_T_ANY = -1, ING_T_MASKS = 0, ING_T_TUPLES = 1, ING_T_EXACT = 16 };
 // diagnostic builds (-DARCLE_BIG_STOP_AT=k, tools/gpu_r6k.sh): the workgroup leaves after stage k of the step — 1 the env's scalars are in,
 // 2 the selection is built and the op's plane staged, 3 the geometry is known, 4 the op has run — so that PMC passes count the instructions
 // per stage (results are meaningless; never defined in the product build)
@@ -865,16 +876,21 @@ enum { BIG_EXP_V_N = 0 };
   do {              \
   } while (0)
 #endif
-template <class X, int ING>
+// FL >= 0: the launch's flag set is exactly FL (the launcher checked): every flag test folds — FL = AUTORESET | ELIDE_SELECTED is what
+// ARCVecEnv(autoreset=True) and the benchmark step with.
+template <class X, int ING, int FL = -1>
 ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
   X x(p, env, lds);
-  x.sel01 = ING == ING_T_TUPLES;  // (rectangles and points are written to S as 0 / 1)
+  const int ingress = ING >= ING_T_EXACT ? ING - ING_T_EXACT : p.ingress;
+  constexpr bool TUPLES = ING == ING_T_TUPLES || ING == ING_T_EXACT + ING_BBOX || ING == ING_T_EXACT + ING_POINT || ING == ING_T_EXACT + ING_BBOX5;
+  constexpr bool MASKS = ING == ING_T_MASKS || ING == ING_T_EXACT + ING_MASK || ING == ING_T_EXACT + ING_BITS;
+  x.sel01 = TUPLES;  // (rectangles and points are written to S as 0 / 1)
   const int tid = x.tid, H = x.H, W = x.W, P = x.P, nch = x.nch;
   Chunk rc = ldg(p.rec, env);
   int8_t* const r = rc.b;
   int cnt0 = p.cnt[2 * (size_t)env], cnt1 = p.cnt[2 * (size_t)env + 1];
-  const uint32_t flags = X::LEAN ? (p.flags & (uint32_t)LEAN_FLAGS) : p.flags;
-  const bool mask_ingress = ING == ING_T_ANY ? (p.ingress == ING_MASK || p.ingress == ING_BITS) : ING == ING_T_MASKS;
+  const uint32_t flags = FL >= 0 ? (uint32_t)FL : X::LEAN ? (p.flags & (uint32_t)LEAN_FLAGS) : p.flags;
+  const bool mask_ingress = ING == ING_T_ANY ? (ingress == ING_MASK || ingress == ING_BITS) : MASKS;
   const bool scratch_rows = !X::LEAN && p.res_rec != nullptr;  // arcle_transition_rows: the envs are scratch envs, one per row
   const bool accounting = !X::LEAN && p.acct != nullptr;
   int reward = 0, submit_inc = 0;
@@ -884,16 +900,16 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
   // ---- the action's scalars ----
   int pay[5] = {0, 0, 0, 0, 0};
   if (mask_ingress) {
-  } else if (p.ingress == ING_BBOX) {
+  } else if (ingress == ING_BBOX) {
     for (int k = 0; k < 4; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[4 * (size_t)env + k];
-  } else if (p.ingress == ING_POINT) {
+  } else if (ingress == ING_POINT) {
     for (int k = 0; k < 2; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[2 * (size_t)env + k];
-  } else if (p.ingress == ING_BBOX5) {
+  } else if (ingress == ING_BBOX5) {
     for (int k = 0; k < 5; k++) pay[k] = reinterpret_cast<const int32_t*>(p.sel)[5 * (size_t)env + k];
   }
   // (workgroup-uniform by construction; telling the compiler so turns the dependent op-table read into a scalar load)
-  opi = bx::uniform(!mask_ingress && p.ingress == ING_BBOX5 ? pay[4] : p.op[env]);
-  if (tid == 0) {
+  opi = bx::uniform(!mask_ingress && ingress == ING_BBOX5 ? pay[4] : p.op[env]);
+  if (!TUPLES && tid == 0) {  // (tuple selections reduce by arithmetic; grid == answer, the fill and the dense pair clear their own slots)
     Red* q = x.red;
     q->any_nz = q->any_pos = q->sum = 0;
     q->amax = 0u;
@@ -952,12 +968,12 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
     {
       const bool tuple = !mask_ingress;
       bool tuple_any = false;
-      if (tuple && p.ingress == ING_POINT) tuple_any = (uint32_t)pay[0] < (uint32_t)H && (uint32_t)pay[1] < (uint32_t)W;
+      if (tuple && ingress == ING_POINT) tuple_any = (uint32_t)pay[0] < (uint32_t)H && (uint32_t)pay[1] < (uint32_t)W;
       else if (tuple) tuple_any = (uint32_t)imin(pay[0], pay[2]) < (uint32_t)H && (uint32_t)imin(pay[1], pay[3]) < (uint32_t)W;
       const bool will_be_active = (oflags & ARCLE_OPF_RESET_SEL) ? false : r[ARCLE_REC_ACTIVE] != 0;
       switch (kind) {
         case ARCLE_OP_FLOODFILL:  // (a tuple that is not a single cell fills nothing, color.py:92: no plane is needed)
-          if (!tuple || (tuple_any && (p.ingress == ING_POINT || (imin(imax(pay[0], pay[2]), H - 1) == imin(pay[0], pay[2]) && imin(imax(pay[1], pay[3]), W - 1) == imin(pay[1], pay[3])))))
+          if (!tuple || (tuple_any && (ingress == ING_POINT || (imin(imax(pay[0], pay[2]), H - 1) == imin(pay[0], pay[2]) && imin(imax(pay[1], pay[3]), W - 1) == imin(pay[1], pay[3])))))
             staged = ARCLE_PL_GRID;
           break;
         case ARCLE_OP_CROP_GRID: staged = ARCLE_PL_GRID; break;
@@ -985,7 +1001,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
     bool any_nz, any_pos;
     int ssum, x0, x1, y0, y1, amax_cell;
     if (mask_ingress) {
-      const bool packed = p.ingress == ING_BITS;  // boolean masks, bit f of the env's row of PS / 8 bytes = cell f
+      const bool packed = ingress == ING_BITS;  // boolean masks, bit f of the env's row of PS / 8 bytes = cell f
       const int8_t* const src = reinterpret_cast<const int8_t*>(p.sel) + (size_t)env * (size_t)(packed ? x.PS >> 3 : P);
       const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
       int l_nz = 0, l_pos = 0, l_sum = 0, lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
@@ -1119,7 +1135,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       // outside the wrappers' action space select nothing and raise ARCLE_ST_BAD_SELECTION.
       int xa, xb, ya, yb;
       bool any;
-      if (p.ingress == ING_POINT) {
+      if (ingress == ING_POINT) {
         xa = xb = pay[0];
         ya = yb = pay[1];
         any = (uint32_t)xa < (uint32_t)H && (uint32_t)ya < (uint32_t)W;
@@ -1296,7 +1312,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
               x.gs(ARCLE_PL_OBJECT_SEL, c, qs);
               x.gs(ARCLE_PL_BACKGROUND, c, gr);
             }
-            place(x, r, x.A, x.S, nullptr, nullptr, delta);
+            place_t<true, true>(x, r, x.A, x.S, nullptr, nullptr, delta);
           } else {
             BIG_EACH_CHUNK(x, c) {
               const Chunk gs_ = gather_affine16(x.S, c, W, x.wm, P, nh, nw, c0 + delta, ai, bj), ga = gather_affine16(x.A, c, W, x.wm, P, nh, nw, c0 + delta, ai, bj);
@@ -1327,7 +1343,7 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
               x.gs(ARCLE_PL_OBJECT, c, ldg(x.B, c));
               x.gs(ARCLE_PL_OBJECT_SEL, c, ldg(x.C, c));
             }
-            place(x, r, x.A, x.S, x.B, x.C);
+            place_t<true, false>(x, r, x.A, x.S, x.B, x.C, -1);
           }
           sel_pending = 0;  // (place() writes the whole `selected` plane)
           break;
@@ -1463,13 +1479,14 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
         const int c_first = (x0 * W) >> 4, c_last = imin(nch - 1, (ex * W) >> 4);
         if (x.wide()) {  // whole chunks: the clip read at the flat shift -(x0 * W + y0), the pasted rectangle as a byte mask
           const int d2 = x0 * W + y0;
+          const uint32_t blank = arg ? ~0u : 0u;
           BIG_EACH_CHUNK(x, c) {
             if (c < c_first || c > c_last) continue;
             Chunk gr = x.gl(ARCLE_PL_GRID, c);
             const Chunk pv = shifted16(x.A, 16 * c - d2, x.PS), in = rect_mask16(c, W, x.wm, x0, ex, y0, ey);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              const uint32_t m = arg ? in.w[q] : in.w[q] & pos_bytes(pv.w[q]);  // :345-348
+              const uint32_t m = in.w[q] & (pos_bytes(pv.w[q]) | blank);  // :345-348 (paste_blank: every cell of the rectangle)
               gr.w[q] = (pv.w[q] & m) | (gr.w[q] & ~m);
             }
             x.gs(ARCLE_PL_GRID, c, gr);

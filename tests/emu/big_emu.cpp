@@ -72,6 +72,7 @@ extern "C" int big_emu_run(int what, const BigParams* p_in, int mode, int nthrea
     if ((p->flags & ~(uint32_t)arcle_big::LEAN_FLAGS) || p->W < 16 || p->res_rec || p->acct) return -3;
     if (mode != 0 && mode != 1 && mode != 2 && mode != 4) return -4;
     if (mode && (p->PS >> 4) > mode * nthreads) return -4;
+    if (mode >= 2 && (p->PS >> 4) <= nthreads) return -4;  // (these instantiations take every thread's first chunk for granted)
   }
   const bool masks = p->ingress == arcle_big::ING_MASK || p->ingress == arcle_big::ING_BITS;
   void* lds = nullptr;
@@ -90,8 +91,19 @@ extern "C" int big_emu_run(int what, const BigParams* p_in, int mode, int nthrea
 #define BIG_EMU_LEAN(CPT)                                                                                                   \
   if (masks) arcle_big::step_env_t<arcle_big::CtxT<CPT, true>, arcle_big::ING_T_MASKS>(*p, env, (int8_t*)lds);              \
   else arcle_big::step_env_t<arcle_big::CtxT<CPT, true>, arcle_big::ING_T_TUPLES>(*p, env, (int8_t*)lds)
+#define BIG_EMU_EXACT(F)                                                                                                                \
+  if (p->flags == 3u) arcle_big::step_env_t<arcle_big::CtxT<2, true>, arcle_big::ING_T_EXACT + arcle_big::F, 3>(*p, env, (int8_t*)lds);  \
+  else arcle_big::step_env_t<arcle_big::CtxT<2, true>, arcle_big::ING_T_EXACT + arcle_big::F>(*p, env, (int8_t*)lds)
             if (mode == 1) { BIG_EMU_LEAN(1); }
-            else if (mode == 2) { BIG_EMU_LEAN(2); }
+            else if (mode == 2) {  // (what the product launches by default: the instantiation of the exact ingress form)
+              switch (p->ingress) {
+                case arcle_big::ING_MASK: BIG_EMU_EXACT(ING_MASK); break;
+                case arcle_big::ING_BITS: BIG_EMU_EXACT(ING_BITS); break;
+                case arcle_big::ING_BBOX: BIG_EMU_EXACT(ING_BBOX); break;
+                case arcle_big::ING_POINT: BIG_EMU_EXACT(ING_POINT); break;
+                default: BIG_EMU_EXACT(ING_BBOX5); break;
+              }
+            }
             else if (mode == 4) { BIG_EMU_LEAN(4); }
             else { BIG_EMU_LEAN(0); }
             break;
