@@ -30,7 +30,12 @@ ARCLE_BIG_DEV uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); } 
 ARCLE_BIG_DEV uint32_t mul32(uint32_t a, uint32_t b) { return a * b; }
 ARCLE_BIG_DEV int dot4_i8(uint32_t v, int acc) { return __builtin_amdgcn_sdot4((int)v, 0x01010101, acc, false); }  // acc + the four int8 of v (v_dot4_i32_i8)
 ARCLE_BIG_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }  // (hi:lo) >> sh, sh < 32
-ARCLE_BIG_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }  // a value every lane holds alike, moved to a scalar register
+ARCLE_BIG_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a dword of a table no kernel writes, at an index every lane holds alike: through the constant address space, i.e. a scalar load even
+// behind stores the compiler cannot tell apart from it
+ARCLE_BIG_DEV uint32_t sload32(const uint32_t* p, uint32_t i) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(p + i));
+}  // a value every lane holds alike, moved to a scalar register
 ARCLE_BIG_DEV void release_store_system(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }  // namespace bx
 

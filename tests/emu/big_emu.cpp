@@ -47,6 +47,7 @@ inline uint64_t brev64(uint64_t x) {
 }
 inline void release_store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline int uniform(int v) { return v; }
+inline uint32_t sload32(const uint32_t* p, uint32_t i) { return p[i]; }
 inline uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline uint32_t mul32(uint32_t a, uint32_t b) { return a * b; }
 inline int dot4_i8(uint32_t v, int acc) { return acc + (int8_t)(v & 0xff) + (int8_t)((v >> 8) & 0xff) + (int8_t)((v >> 16) & 0xff) + (int8_t)(v >> 24); }
