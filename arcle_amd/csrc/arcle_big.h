@@ -1090,25 +1090,82 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
         }
       }
       Red* q = x.red;
-      if (l_nz) {
-        bx::lds_or(&q->any_nz, 1);
-        if (l_pos) bx::lds_or(&q->any_pos, 1);
-        bx::lds_min(&q->x0, lx0);
-        bx::lds_max(&q->x1, lx1);
-        bx::lds_min(&q->y0, ly0);
-        bx::lds_max(&q->y1, ly1);
+      if (bx::HAS_WAVE_OPS) {
+        // Every wavefront reduces its lanes' shares across lanes — two ballots, six DPP reductions (row shifts 1 / 2 / 4 / 8, then the row
+        // broadcasts 15 and 31: lane 63 holds the result) — and lane 0 leaves the eight words in the wavefront's slot; ONE barrier (which
+        // also publishes the S tile and the staged plane), then every thread combines the slots of the workgroup's wavefronts (one: none
+        // to combine).  No LDS atomics: the compiler's rewrite of a same-address atomic costs ~25 instructions each (its default, a
+        // scalar loop over the lanes, ~8 per lane), profiles/round6_experiments.txt §2f / §2i.
+        uint32_t* const slots = reinterpret_cast<uint32_t*>(x.sc);  // (the row writers' scalar / layout area: idle until a step's epilogue)
+        const uint32_t w_fl = (bx::wave_any(l_nz != 0) ? 1u : 0u) | (bx::wave_any(l_pos != 0) ? 2u : 0u);
+        const int w_sum = bx::wave_add(l_sum), w_x0 = bx::wave_min(lx0), w_x1 = bx::wave_max(lx1), w_y0 = bx::wave_min(ly0), w_y1 = bx::wave_max(ly1);
+        const uint32_t w_amax = bx::wave_umax(l_amax);
+        const int nw = x.NT >> 6;
+        if (nw > 1 && (tid & 63) == 0) {
+          uint32_t* const sl = slots + 8 * (tid >> 6);
+          sl[0] = w_fl;
+          sl[1] = (uint32_t)w_sum;
+          sl[2] = (uint32_t)w_x0;
+          sl[3] = (uint32_t)w_x1;
+          sl[4] = (uint32_t)w_y0;
+          sl[5] = (uint32_t)w_y1;
+          sl[6] = w_amax;
+        }
+        bx::sync();
+        uint32_t fl = w_fl, am = w_amax;
+        ssum = w_sum;
+        x0 = w_x0;
+        x1 = w_x1;
+        y0 = w_y0;
+        y1 = w_y1;
+        if (nw > 1) {
+          fl = 0u;
+          am = 0u;
+          ssum = 0;
+          x0 = y0 = 1 << 20;
+          x1 = y1 = -1;
+          for (int w = 0; w < nw; w++) {
+            const uint32_t* const sl = slots + 8 * w;
+            fl |= sl[0];
+            ssum += (int)sl[1];
+            x0 = imin(x0, (int)sl[2]);
+            x1 = imax(x1, (int)sl[3]);
+            y0 = imin(y0, (int)sl[4]);
+            y1 = imax(y1, (int)sl[5]);
+            am = sl[6] > am ? sl[6] : am;
+          }
+          fl = (uint32_t)bx::uniform((int)fl);
+          am = (uint32_t)bx::uniform((int)am);
+          ssum = bx::uniform(ssum);
+          x0 = bx::uniform(x0);
+          x1 = bx::uniform(x1);
+          y0 = bx::uniform(y0);
+          y1 = bx::uniform(y1);
+        }
+        any_nz = (fl & 1u) != 0;
+        any_pos = (fl & 2u) != 0;
+        amax_cell = 0xffff - (int)(am & 0xffffu);
+      } else {  // (the CPU emulation of the workgroup: host threads are no wavefront — atomics on the reduction block)
+        if (l_nz) {
+          bx::lds_or(&q->any_nz, 1);
+          if (l_pos) bx::lds_or(&q->any_pos, 1);
+          bx::lds_min(&q->x0, lx0);
+          bx::lds_max(&q->x1, lx1);
+          bx::lds_min(&q->y0, ly0);
+          bx::lds_max(&q->y1, ly1);
+        }
+        if (l_sum) bx::lds_add(&q->sum, l_sum);
+        bx::lds_umax(&q->amax, l_amax);
+        bx::sync();
+        any_nz = q->any_nz != 0;
+        any_pos = q->any_pos != 0;
+        ssum = q->sum;
+        x0 = q->x0;
+        x1 = q->x1;
+        y0 = q->y0;
+        y1 = q->y1;
+        amax_cell = 0xffff - (int)(q->amax & 0xffffu);
       }
-      if (l_sum) bx::lds_add(&q->sum, l_sum);
-      bx::lds_umax(&q->amax, l_amax);
-      bx::sync();
-      any_nz = q->any_nz != 0;
-      any_pos = q->any_pos != 0;
-      ssum = q->sum;
-      x0 = q->x0;
-      x1 = q->x1;
-      y0 = q->y0;
-      y1 = q->y1;
-      amax_cell = 0xffff - (int)(q->amax & 0xffffu);
       if ((flags & ARCLE_STEP_CONTINUE_RULE) && (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP)) {
         // the O2ARC trace harness (tests/o2arc_check.py:169-170): an object op whose logged selection equals the env's current
         // `selected` plane continues the active object, i.e. is sent with an empty selection

@@ -31,6 +31,30 @@ ARCLE_BIG_DEV uint32_t mul32(uint32_t a, uint32_t b) { return a * b; }
 ARCLE_BIG_DEV int dot4_i8(uint32_t v, int acc) { return __builtin_amdgcn_sdot4((int)v, 0x01010101, acc, false); }  // acc + the four int8 of v (v_dot4_i32_i8)
 ARCLE_BIG_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }  // (hi:lo) >> sh, sh < 32
 ARCLE_BIG_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// ---- wavefront-wide reductions (every lane of the wavefront active) -----------------------------------------------------------------
+enum { HAS_WAVE_OPS = 1 };
+ARCLE_BIG_DEV bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+// v op= its neighbours 1, 2, 4 and 8 lanes below inside each row of 16 (lanes without such a neighbour take `id`), then row 0's / row 2's
+// lane 15 into rows 1 / 3 and lane 31 into rows 2 - 3: lane 63 holds the reduction of all 64 lanes
+#define BIG_WAVE_REDUCE(OP, ID)                                                                      \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(ID), v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */       \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(ID), v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */       \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(ID), v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */       \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(ID), v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */       \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(ID), v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 */    \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(ID), v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 */    \
+  return __builtin_amdgcn_readlane(v, 63)
+ARCLE_BIG_DEV int op_add(int a, int b) { return a + b; }
+ARCLE_BIG_DEV int op_min(int a, int b) { return a < b ? a : b; }
+ARCLE_BIG_DEV int op_max(int a, int b) { return a > b ? a : b; }
+ARCLE_BIG_DEV int op_umax(int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; }
+ARCLE_BIG_DEV int wave_add(int v) { BIG_WAVE_REDUCE(op_add, 0); }
+ARCLE_BIG_DEV int wave_min(int v) { BIG_WAVE_REDUCE(op_min, 0x7fffffff); }
+ARCLE_BIG_DEV int wave_max(int v) { BIG_WAVE_REDUCE(op_max, (int)0x80000000); }
+ARCLE_BIG_DEV uint32_t wave_umax(uint32_t u) {
+  int v = (int)u;
+  BIG_WAVE_REDUCE(op_umax, 0);
+}
 // a dword of a table no kernel writes, at an index every lane holds alike: through the constant address space, i.e. a scalar load even
 // behind stores the compiler cannot tell apart from it
 ARCLE_BIG_DEV uint32_t sload32(const uint32_t* p, uint32_t i) {

@@ -47,6 +47,13 @@ inline uint64_t brev64(uint64_t x) {
 }
 inline void release_store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline int uniform(int v) { return v; }
+// (host threads are no wavefront: the kernel body takes its atomic form, arcle_big.h; these only have to exist)
+enum { HAS_WAVE_OPS = 0 };
+inline bool wave_any(bool b) { return b; }
+inline int wave_add(int v) { return v; }
+inline int wave_min(int v) { return v; }
+inline int wave_max(int v) { return v; }
+inline uint32_t wave_umax(uint32_t v) { return v; }
 inline uint32_t sload32(const uint32_t* p, uint32_t i) { return p[i]; }
 inline uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline uint32_t mul32(uint32_t a, uint32_t b) { return a * b; }
