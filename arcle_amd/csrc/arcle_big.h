@@ -12,10 +12,11 @@
 //     consecutive tile bytes through five consecutive dword reads behind one clamp and funnel shifts, the op's rectangle as a byte mask of
 //     two column runs built by packed subtractions), Rotate / Flip gather cell by cell with an add + clamp + byte read and take the
 //     rectangle as a mask (W < 16 keeps per-cell forms);
-//   * reductions (any / sum / arg-max / bounding box of a mask selection, grid == answer) are formed per chunk on whole words and combined
-//     by LDS atomics on one address per value + a workgroup barrier — compiled with -amdgpu-atomic-optimizer-strategy=DPP (arcle_amd/_lib.py):
-//     a cross-lane reduction in every wavefront and ONE atomic per wavefront (the compiler's default turns each into a scalar loop over
-//     the lanes; tuple selections need none: their reductions are arithmetic on the tuple);
+//   * reductions of a mask selection (any / sum / arg-max / bounding box) are formed per chunk on whole words and combined by two ballots and
+//     six DPP reductions per wavefront, one LDS slot per wavefront and ONE workgroup barrier (tuple selections need none: arithmetic on the
+//     tuple); the few LDS atomics left (dense pair, byte accounting; the CPU emulation of this step) are compiled with
+//     -amdgpu-atomic-optimizer-strategy=DPP (arcle_amd/_lib.py): the compiler's default turns a same-address atomic into a scalar loop over
+//     the lanes;
 //   * FloodFill runs on 128-bit row boards (one thread per row): a pass pulls the fill from the rows above and below and spreads it along
 //     the row's eligible runs with the carry trick (E + F ripples through a run of ones), until no row changes;
 //   * per-env scalars (the 16-byte record, counters, op descriptor) are loaded by every thread — the same address: the compiler proves it
