@@ -310,7 +310,26 @@ ARCLE_BIG_DEV void init_planes(const X& x, const int8_t* src, bool write_input) 
     if (x.has(ARCLE_PL_BACKGROUND)) x.gs(ARCLE_PL_BACKGROUND, c, z);
   }
 }
-ARCLE_BIG_DEV void init_rec(int8_t* r, int max_trial) {
+// The 16-byte record of an env as the step kernel holds it: FOUR WORDS (scalar registers: the record arrives through a scalar load), a field
+// read is one bit-field extract and a write one insert into its word — kept apart as sixteen byte values the compiler re-assembles all four
+// words from their bytes before the store, ~30 scalar instructions at the end of every step.  Indexable like the byte array it replaces.
+struct Rec16 {
+  uint32_t w[4];
+  struct Ref {
+    uint32_t* p;
+    int sh;
+    ARCLE_BIG_DEV operator int8_t() const { return (int8_t)(uint8_t)(*p >> sh); }
+    ARCLE_BIG_DEV Ref& operator=(int8_t v) {
+      *p = (*p & ~(0xffu << sh)) | ((uint32_t)(uint8_t)v << sh);
+      return *this;
+    }
+    ARCLE_BIG_DEV Ref& operator=(const Ref& o) { return *this = (int8_t)o; }
+  };
+  ARCLE_BIG_DEV Ref operator[](int i) { return Ref{&w[i >> 2], 8 * (i & 3)}; }
+  ARCLE_BIG_DEV int8_t operator[](int i) const { return (int8_t)(uint8_t)(w[i >> 2] >> (8 * (i & 3))); }
+};
+template <class R>
+ARCLE_BIG_DEV void init_rec(R&& r, int max_trial) {
   r[ARCLE_REC_GRID_DIM] = r[ARCLE_REC_INPUT_DIM];
   r[ARCLE_REC_GRID_DIM + 1] = r[ARCLE_REC_INPUT_DIM + 1];
   r[ARCLE_REC_CLIP_DIM] = r[ARCLE_REC_CLIP_DIM + 1] = 0;
@@ -326,8 +345,8 @@ ARCLE_BIG_DEV void init_rec(int8_t* r, int max_trial) {
 // into the env's input and answer planes and the record's dims, then runs init_state's plane part.  Returns false (nothing written) when
 // a quarter turn does not fit the H x W plane; `soften`: such a turn is dropped (k &= 2) instead — device-drawn augmentations never fail
 // (the rule of arcle_wave.h load_task).  Workgroup-uniform; contains barriers when it augments.
-template <class X>
-ARCLE_BIG_DEV bool load_task(const X& x, int8_t* r, int t, int rot_k, uint64_t perm, bool soften) {
+template <class X, class R>
+ARCLE_BIG_DEV bool load_task(const X& x, R&& r, int t, int rot_k, uint64_t perm, bool soften) {
   const BigParams& p = x.p;
   int ih = p.tbl_in_dim[2 * (size_t)t], iw = p.tbl_in_dim[2 * (size_t)t + 1];
   int ah = p.tbl_ans_dim[2 * (size_t)t], aw = p.tbl_ans_dim[2 * (size_t)t + 1];
@@ -376,8 +395,8 @@ ARCLE_BIG_DEV bool load_task(const X& x, int8_t* r, int t, int rot_k, uint64_t p
 
 // answer.shape == grid_dim and grid[:h,:w] == answer (base.py:177, o2arcenv.py:124-127); workgroup-uniform result.
 // (two barriers; the caller has made the grid plane in global memory final and visible — a barrier since its last store)
-template <class X>
-ARCLE_BIG_DEV bool grid_equals_answer(const X& x, const int8_t* r) {
+template <class X, class R>
+ARCLE_BIG_DEV bool grid_equals_answer(const X& x, const R& r) {
   const int gh = r[ARCLE_REC_GRID_DIM], gw = r[ARCLE_REC_GRID_DIM + 1];
   if (gh != r[ARCLE_REC_ANSWER_DIM] || gw != r[ARCLE_REC_ANSWER_DIM + 1]) return false;
   if (x.tid == 0) x.red->neq = 0;
@@ -531,8 +550,8 @@ ARCLE_BIG_DEV void write_row(const X& x, const Layout& L, const int8_t* sc, int8
 }
 
 // the FLAT_OBS / PACK_OBS epilogue of a step (and the stand-alone flatten / pack kernels): rows of the env's CURRENT state
-template <class X>
-ARCLE_BIG_DEV void emit_rows(const X& x, const int8_t* r, uint32_t flags, int reward, int term, int cnt0, int cnt1, bool truncated,
+template <class X, class R>
+ARCLE_BIG_DEV void emit_rows(const X& x, const R& r, uint32_t flags, int reward, int term, int cnt0, int cnt1, bool truncated,
                              uint32_t st) {
   const BigParams& p = x.p;
   // (entered behind a barrier: nobody is still reading the LDS tail area)
@@ -762,8 +781,8 @@ ARCLE_BIG_DEV Chunk cut_out16(const X& x, int c, int x0, int y0, int h, int w) {
 // selection `cut`, read at the lift's flat shift on top of the placement's: one gather pass instead of lift + barrier + place.
 // CUT / LIFT: whether `cut` is given / the lift is fused — compile-time facts of every call site but one, so that the tests leave the
 // per-word loops (a uniform branch costs two scalar instructions every time it is reached).
-template <bool CUT, bool LIFT, class X>
-ARCLE_BIG_DEV void place_t(const X& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q, int lift_delta) {
+template <bool CUT, bool LIFT, class X, class R>
+ARCLE_BIG_DEV void place_t(const X& x, const R& r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q, int lift_delta) {
   const int W = x.W;
   const int px = r[ARCLE_REC_OBJECT_POS], py = r[ARCLE_REC_OBJECT_POS + 1];
   const int h = r[ARCLE_REC_OBJECT_DIM], w = r[ARCLE_REC_OBJECT_DIM + 1];
@@ -823,8 +842,8 @@ ARCLE_BIG_DEV void place_t(const X& x, const int8_t* r, const int8_t* bg, const 
   }
 }
 
-template <class X>
-ARCLE_BIG_DEV void place(const X& x, const int8_t* r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q) {
+template <class X, class R>
+ARCLE_BIG_DEV void place(const X& x, const R& r, const int8_t* bg, const int8_t* cut, const int8_t* O, const int8_t* Q) {
   if (cut) place_t<true, false>(x, r, bg, cut, O, Q, -1);
   else place_t<false, false>(x, r, bg, nullptr, O, Q, -1);
 }
@@ -887,8 +906,12 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
   constexpr bool MASKS = ING == ING_T_MASKS || ING == ING_T_EXACT + ING_MASK || ING == ING_T_EXACT + ING_BITS;
   x.sel01 = TUPLES;  // (rectangles and points are written to S as 0 / 1)
   const int tid = x.tid, H = x.H, W = x.W, P = x.P, nch = x.nch;
-  Chunk rc = ldg(p.rec, env);
-  int8_t* const r = rc.b;
+  Rec16 r;
+  {
+    const Chunk rc = ldg(p.rec, env);
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.w[k] = rc.w[k];
+  }
   int cnt0 = p.cnt[2 * (size_t)env], cnt1 = p.cnt[2 * (size_t)env + 1];
   const uint32_t flags = FL >= 0 ? (uint32_t)FL : X::LEAN ? (p.flags & (uint32_t)LEAN_FLAGS) : p.flags;
   const bool mask_ingress = ING == ING_T_ANY ? (ingress == ING_MASK || ingress == ING_BITS) : MASKS;
@@ -1708,6 +1731,9 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
     }
   }
   if (tid == 0) {
+    Chunk rc;
+#pragma unroll
+    for (int k = 0; k < 4; k++) rc.w[k] = r.w[k];
     stg(p.rec, env, rc);
     p.cnt[2 * (size_t)env] = cnt0;
     p.cnt[2 * (size_t)env + 1] = cnt1;
