@@ -995,24 +995,25 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       if (tuple && ingress == ING_POINT) tuple_any = (uint32_t)pay[0] < (uint32_t)H && (uint32_t)pay[1] < (uint32_t)W;
       else if (tuple) tuple_any = (uint32_t)imin(pay[0], pay[2]) < (uint32_t)H && (uint32_t)imin(pay[1], pay[3]) < (uint32_t)W;
       const bool will_be_active = (oflags & ARCLE_OPF_RESET_SEL) ? false : r[ARCLE_REC_ACTIVE] != 0;
-      // (one table look-up instead of a compare chain on the op kind: a nibble per kind = the plane it gathers from, 15 = none / decided below)
-      constexpr uint64_t STAGE_BY_KIND = ~0ull & ~(0xfull << (4 * ARCLE_OP_FLOODFILL)) & ~(0xfull << (4 * ARCLE_OP_CROP_GRID)) & ~(0xfull << (4 * ARCLE_OP_COPY)) &
-                                             ~(0xfull << (4 * ARCLE_OP_PASTE)) |
-                                         ((uint64_t)ARCLE_PL_GRID << (4 * ARCLE_OP_FLOODFILL)) | ((uint64_t)ARCLE_PL_GRID << (4 * ARCLE_OP_CROP_GRID)) |
-                                         ((uint64_t)ARCLE_PL_INPUT << (4 * ARCLE_OP_COPY)) | ((uint64_t)ARCLE_PL_CLIP << (4 * ARCLE_OP_PASTE));
-      const int by_kind = (int)((STAGE_BY_KIND >> (4 * kind)) & 15u);
-      if (by_kind != 15) staged = by_kind;
-      if (kind == ARCLE_OP_COPY && arg) staged = ARCLE_PL_GRID;
-      if (kind == ARCLE_OP_FLOODFILL && tuple) {  // (a tuple that is not a single cell fills nothing, color.py:92: no plane is needed)
-        const bool one_cell = tuple_any && (ingress == ING_POINT || (imin(imax(pay[0], pay[2]), H - 1) == imin(pay[0], pay[2]) && imin(imax(pay[1], pay[3]), W - 1) == imin(pay[1], pay[3])));
-        if (!one_cell) staged = -1;
-      }
-      if (kind == ARCLE_OP_MOVE || kind == ARCLE_OP_ROTATE || kind == ARCLE_OP_FLIP) {
-        if (!tuple || tuple_any) staged = ARCLE_PL_GRID;
-        else if (will_be_active) {
-          staged = ARCLE_PL_BACKGROUND;
-          staged_obj = true;
-        }
+      switch (kind) {  // (a compare tree the compiler keeps as BRANCHES: Color and the critical ops leave after two or three compares; written
+                       // as a table look-up + conditional assignments it became ~60 scalar selects for every op, round6 §2h)
+        case ARCLE_OP_FLOODFILL:  // (a tuple that is not a single cell fills nothing, color.py:92: no plane is needed)
+          if (!tuple || (tuple_any && (ingress == ING_POINT || (imin(imax(pay[0], pay[2]), H - 1) == imin(pay[0], pay[2]) && imin(imax(pay[1], pay[3]), W - 1) == imin(pay[1], pay[3])))))
+            staged = ARCLE_PL_GRID;
+          break;
+        case ARCLE_OP_CROP_GRID: staged = ARCLE_PL_GRID; break;
+        case ARCLE_OP_COPY: staged = arg ? ARCLE_PL_GRID : ARCLE_PL_INPUT; break;
+        case ARCLE_OP_PASTE: staged = ARCLE_PL_CLIP; break;
+        case ARCLE_OP_MOVE:
+        case ARCLE_OP_ROTATE:
+        case ARCLE_OP_FLIP:
+          if (!tuple || tuple_any) staged = ARCLE_PL_GRID;
+          else if (will_be_active) {
+            staged = ARCLE_PL_BACKGROUND;
+            staged_obj = true;
+          }
+          break;
+        default: break;
       }
       if (staged >= 0) x.stage_g(x.A, staged);
       if (staged_obj) {
