@@ -67,7 +67,7 @@ ARCLE_BIG_DEV void release_store_system(uint32_t* p, uint32_t v) { __hip_atomic_
 
 using arcle_big::BigParams;
 
-#define BIG_THREADS 1024  // the largest workgroup a launch may be given (ARCLE_BIG_THREADS; the library itself asks for at most 512)
+#define BIG_THREADS 512  // the largest workgroup a launch is ever given (threads_for / lean_threads_for; ARCLE_BIG_THREADS overrides up to it)
 
 extern __shared__ __attribute__((aligned(16))) int8_t arcle_big_lds[];
 
