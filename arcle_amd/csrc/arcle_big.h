@@ -596,101 +596,6 @@ ARCLE_BIG_DEV void emit_rows(const X& x, const R& r, uint32_t flags, int reward,
   }
 }
 
-// ---- FloodFill (color.py:88-100, dfs :8-30): 4-connected region of (sx, sy) among the cells of the gh x gw grid that hold its colour.
-// The grid is staged in A.  Iterative propagation is equivalent to the reference's DFS (the visited set does not depend on the order).
-template <class X>
-ARCLE_BIG_DEV void flood_fill(const X& x, int gh, int gw, int sx, int sy, int colour) {
-  const int W = x.W, H = x.H;
-  const int col = x.A[sx * W + sy];
-  B128* const E = reinterpret_cast<B128*>(x.Eb);
-  B128* const F = reinterpret_cast<B128*>(x.Fb);
-  for (int i = x.tid; i < H; i += x.NT) {
-    B128 e;
-    e.lo = e.hi = 0;
-    if (i < gh) {
-      const int8_t* row = x.A + i * W;
-      for (int j = 0; j < gw; j++)
-        if (row[j] == col) {
-          if (j < 64) e.lo |= 1ull << j;
-          else e.hi |= 1ull << (j - 64);
-        }
-    }
-    B128 f;
-    f.lo = f.hi = 0;
-    if (i == sx) {
-      if (sy < 64) f.lo = 1ull << sy;
-      else f.hi = 1ull << (sy - 64);
-      f = spread(e, f);
-    }
-    E[i] = e;
-    F[i] = f;
-  }
-  if (x.tid == 0) x.red->flag[0] = x.red->flag[1] = x.red->flag[2] = 0;
-  bx::sync();
-  // Chaotic relaxation: inside a pass a thread re-reads its neighbours' boards LIVE (volatile LDS reads, no barrier) FILL_INNER times
-  // and publishes its own row as soon as it grows — rows of one wavefront advance in lock-step, so the fill climbs FILL_INNER rows of a
-  // vertical corridor per pass instead of one (one barrier per pass instead of two per row).  Every intermediate board is a subset of
-  // the region (the update is monotone), so whatever the interleaving the fixpoint is the reference's region; a pass in which NO thread
-  // changed anything evaluated every row against boards that were constant throughout: the fixpoint.  Flag slots rotate over three
-  // passes: slot (k + 1) % 3 is cleared during pass k — last read at the end of pass k - 2, behind a barrier every thread has passed.
-  volatile uint64_t* const Fv = reinterpret_cast<volatile uint64_t*>(F);
-  // (a thread's rows are tid, tid + NT, ...: ARCLE_BIG_ROWS of them at most — 1 on the GPU, where a workgroup has at least 128 threads — in
-  // loops of constant trip count, so that the boards stay in registers)
-  B128 mine[ARCLE_BIG_ROWS], elig[ARCLE_BIG_ROWS];
-#pragma unroll
-  for (int k = 0; k < ARCLE_BIG_ROWS; k++) {
-    const int i = x.tid + k * x.NT;
-    if (i < H) {
-      mine[k] = F[i];
-      elig[k] = E[i];
-    }
-  }
-  for (int pass = 0;; pass++) {
-    bool changed = false;
-    for (int it = 0; it < FILL_INNER; it++) {
-#pragma unroll
-      for (int k = 0; k < ARCLE_BIG_ROWS; k++) {
-        const int i = x.tid + k * x.NT;
-        if (i >= H) continue;
-        const B128 cur = mine[k], e = elig[k];
-        B128 s = cur;
-        if (i > 0) {
-          s.lo |= Fv[2 * (i - 1)];
-          s.hi |= Fv[2 * (i - 1) + 1];
-        }
-        if (i + 1 < H) {
-          s.lo |= Fv[2 * (i + 1)];
-          s.hi |= Fv[2 * (i + 1) + 1];
-        }
-        s.lo &= e.lo;
-        s.hi &= e.hi;
-        if (s.lo != cur.lo || s.hi != cur.hi) {
-          const B128 n = spread(e, s);
-          Fv[2 * i] = n.lo;
-          Fv[2 * i + 1] = n.hi;
-          mine[k] = n;
-          changed = true;
-        }
-      }
-    }
-    if (changed) x.red->flag[pass % 3] = 1;
-    if (x.tid == 0) x.red->flag[(pass + 1) % 3] = 0;
-    bx::sync();
-    if (!x.red->flag[pass % 3]) break;
-  }
-  // the region takes the colour: chunks of the staged grid, rewritten where the board has a bit
-  BIG_EACH_CHUNK(x, c) {
-    bool any = false;
-    const Chunk o = build_chunk(c, W, x.wm, x.P, [&](int f, int i, int j) {
-      const B128 fr = F[i];
-      const bool in = j < 64 ? ((fr.lo >> j) & 1ull) != 0 : ((fr.hi >> (j - 64)) & 1ull) != 0;
-      any |= in;
-      return in ? (int8_t)colour : x.A[f];
-    });
-    if (any) x.gs(ARCLE_PL_GRID, c, o);
-  }
-}
-
 // ---- whole-chunk (SWAR) forms of the gathers, for W >= 16 (a chunk then spans at most two plane rows) ------------------------------------
 // The object lift / place, Copy, Paste and Crop are FLAT SHIFTS of a plane: destination cell f reads source cell f + delta for one delta per
 // op (rows and columns move together in the row-major layout), valid wherever the destination lies inside the op's rectangle.  So a
@@ -772,6 +677,164 @@ ARCLE_BIG_DEV Chunk cut_out16(const X& x, int c, int x0, int y0, int h, int w) {
 #pragma unroll
   for (int q = 0; q < 4; q++) o.w[q] = av.w[q] & in.w[q] & x.sel_nz(sv.w[q]);
   return o;
+}
+
+// ---- FloodFill (color.py:88-100, dfs :8-30): 4-connected region of (sx, sy) among the cells of the gh x gw grid that hold its colour.
+// The grid is staged in A.  Iterative propagation is equivalent to the reference's DFS (the visited set does not depend on the order).
+template <class X>
+ARCLE_BIG_DEV void flood_fill(const X& x, int gh, int gw, int sx, int sy, int colour) {
+  const int W = x.W, H = x.H;
+  const int col = x.A[sx * W + sy];
+  B128* const E = reinterpret_cast<B128*>(x.Eb);
+  B128* const F = reinterpret_cast<B128*>(x.Fb);
+  if (x.wide()) {
+    // The eligibility boards E from whole chunks (W >= 16): a chunk's cells that hold the seed's colour inside the gh x gw grid as a 16-bit
+    // map (bytes equal <=> XOR is zero; the grid's rectangle as a byte mask; four multiply-gathers) OR-ed into the one or two rows it
+    // touches — ~60 vector instructions a chunk instead of ~6 per cell of a row in ONE thread (at 64 x 64 that loop was 400 instructions
+    // long on a wavefront most of whose lanes idled).
+    int32_t* const E32 = reinterpret_cast<int32_t*>(E);
+    for (int i = x.tid; i < H; i += x.NT) E[i].lo = E[i].hi = 0;
+    bx::sync();
+    const uint32_t colw = ((uint32_t)col & 0xffu) * 0x01010101u;
+    BIG_EACH_CHUNK(x, c) {
+      const Chunk v = ldg(x.A, c), in = rect_mask16(c, W, x.wm, 0, gh, 0, gw);
+      uint32_t m16 = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t eq = ~nz_bytes(v.w[q] ^ colw) & in.w[q] & 0x01010101u;
+        m16 |= ((bx::mul32(eq, 0x01020408u) >> 24) & 15u) << (4 * q);
+      }
+      if (m16) {
+        const int f0 = 16 * c, i0 = div_w(f0, x.wm), j0 = f0 - i0 * W, n0 = imin(16, W - j0);
+        const uint32_t part0 = m16 & ((1u << n0) - 1u), part1 = m16 >> n0;
+        if (part0) {  // columns j0 .. j0 + n0 - 1 of row i0: at most two words of the row's board
+          const int wi = j0 >> 5, sh = j0 & 31;
+          bx::lds_or(E32 + 4 * i0 + wi, (int)(part0 << sh));
+          if (sh > 16 && (part0 >> (32 - sh))) bx::lds_or(E32 + 4 * i0 + wi + 1, (int)(part0 >> (32 - sh)));
+        }
+        if (part1) bx::lds_or(E32 + 4 * (i0 + 1), (int)part1);  // columns 0 .. of row i0 + 1 (a row of the grid: part1 is empty behind the last)
+      }
+    }
+    bx::sync();
+    for (int i = x.tid; i < H; i += x.NT) {
+      B128 f;
+      f.lo = f.hi = 0;
+      if (i == sx) {
+        if (sy < 64) f.lo = 1ull << sy;
+        else f.hi = 1ull << (sy - 64);
+        f = spread(E[i], f);
+      }
+      F[i] = f;
+    }
+  } else
+  for (int i = x.tid; i < H; i += x.NT) {
+    B128 e;
+    e.lo = e.hi = 0;
+    if (i < gh) {
+      const int8_t* row = x.A + i * W;
+      for (int j = 0; j < gw; j++)
+        if (row[j] == col) {
+          if (j < 64) e.lo |= 1ull << j;
+          else e.hi |= 1ull << (j - 64);
+        }
+    }
+    B128 f;
+    f.lo = f.hi = 0;
+    if (i == sx) {
+      if (sy < 64) f.lo = 1ull << sy;
+      else f.hi = 1ull << (sy - 64);
+      f = spread(e, f);
+    }
+    E[i] = e;
+    F[i] = f;
+  }
+  if (x.tid == 0) x.red->flag[0] = x.red->flag[1] = x.red->flag[2] = 0;
+  bx::sync();
+  // Chaotic relaxation: inside a pass a thread re-reads its neighbours' boards LIVE (volatile LDS reads, no barrier) FILL_INNER times
+  // and publishes its own row as soon as it grows — rows of one wavefront advance in lock-step, so the fill climbs FILL_INNER rows of a
+  // vertical corridor per pass instead of one (one barrier per pass instead of two per row).  Every intermediate board is a subset of
+  // the region (the update is monotone), so whatever the interleaving the fixpoint is the reference's region; a pass in which NO thread
+  // changed anything evaluated every row against boards that were constant throughout: the fixpoint.  Flag slots rotate over three
+  // passes: slot (k + 1) % 3 is cleared during pass k — last read at the end of pass k - 2, behind a barrier every thread has passed.
+  volatile uint64_t* const Fv = reinterpret_cast<volatile uint64_t*>(F);
+  // (a thread's rows are tid, tid + NT, ...: ARCLE_BIG_ROWS of them at most — 1 on the GPU, where a workgroup has at least 128 threads — in
+  // loops of constant trip count, so that the boards stay in registers)
+  B128 mine[ARCLE_BIG_ROWS], elig[ARCLE_BIG_ROWS];
+#pragma unroll
+  for (int k = 0; k < ARCLE_BIG_ROWS; k++) {
+    const int i = x.tid + k * x.NT;
+    if (i < H) {
+      mine[k] = F[i];
+      elig[k] = E[i];
+    }
+  }
+  for (int pass = 0;; pass++) {
+    bool changed = false;
+    for (int it = 0; it < FILL_INNER; it++) {
+#pragma unroll
+      for (int k = 0; k < ARCLE_BIG_ROWS; k++) {
+        const int i = x.tid + k * x.NT;
+        if (i >= H) continue;
+        const B128 cur = mine[k], e = elig[k];
+        B128 s = cur;
+        if (i > 0) {
+          s.lo |= Fv[2 * (i - 1)];
+          s.hi |= Fv[2 * (i - 1) + 1];
+        }
+        if (i + 1 < H) {
+          s.lo |= Fv[2 * (i + 1)];
+          s.hi |= Fv[2 * (i + 1) + 1];
+        }
+        s.lo &= e.lo;
+        s.hi &= e.hi;
+        if (s.lo != cur.lo || s.hi != cur.hi) {
+          const B128 n = spread(e, s);
+          Fv[2 * i] = n.lo;
+          Fv[2 * i + 1] = n.hi;
+          mine[k] = n;
+          changed = true;
+        }
+      }
+    }
+    if (changed) x.red->flag[pass % 3] = 1;
+    if (x.tid == 0) x.red->flag[(pass + 1) % 3] = 0;
+    bx::sync();
+    if (!x.red->flag[pass % 3]) break;
+  }
+  // the region takes the colour: chunks of the staged grid, rewritten where the board has a bit
+  if (x.wide()) {  // (whole chunks: the chunk's 16 board bits out of its one or two rows, widened to bytes by a multiply per nibble)
+    const uint32_t* const F32 = reinterpret_cast<const uint32_t*>(F);
+    const uint32_t cw = ((uint32_t)colour & 0xffu) * 0x01010101u;
+    BIG_EACH_CHUNK(x, c) {
+      const int f0 = 16 * c, i0 = div_w(f0, x.wm), j0 = f0 - i0 * W, n0 = imin(16, W - j0);
+      uint32_t m16 = 0;
+      if (i0 < H) {
+        const int wi = j0 >> 5;
+        const uint32_t lo = F32[4 * i0 + wi], hi = wi < 3 ? F32[4 * i0 + wi + 1] : 0u;
+        m16 = bx::alignbit(hi, lo, (uint32_t)(j0 & 31)) & ((1u << n0) - 1u);
+      }
+      if (n0 < 16 && i0 + 1 < H) m16 |= (F32[4 * (i0 + 1)] & ((1u << (16 - n0)) - 1u)) << n0;
+      if (!m16) continue;
+      Chunk o = ldg(x.A, c);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t b = bx::mul24((m16 >> (4 * q)) & 15u, 0x00204081u) & 0x01010101u, m = (b << 8) - b;
+        o.w[q] = (o.w[q] & ~m) | (cw & m);
+      }
+      x.gs(ARCLE_PL_GRID, c, o);
+    }
+    return;
+  }
+  BIG_EACH_CHUNK(x, c) {
+    bool any = false;
+    const Chunk o = build_chunk(c, W, x.wm, x.P, [&](int f, int i, int j) {
+      const B128 fr = F[i];
+      const bool in = j < 64 ? ((fr.lo >> j) & 1ull) != 0 : ((fr.hi >> (j - 64)) & 1ull) != 0;
+      any |= in;
+      return in ? (int8_t)colour : x.A[f];
+    });
+    if (any) x.gs(ARCLE_PL_GRID, c, o);
+  }
 }
 
 // _apply_patch (object.py:113-138) + _apply_sel (object.py:140-165): grid := background, selected := 0, then the object tile `O`

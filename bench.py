@@ -930,13 +930,15 @@ def _big_model_bytes(op, PS):
     return float(k.sum()) * PS / op.shape[0] + 56.0 * op.shape[1]  # + record in / out, counters, action, outputs per env
 
 
-def big_grid_case(dev, H, W, n, K=24, ops=None, ingress="bbox"):
+def big_grid_case(dev, H, W, n, K=24, ops=None, ingress="bbox", point_seeds=False):
     """One max_grid_size beyond 1024 cells: K graph-replayed step launches of the C3 action mix (one workgroup per env).  `ingress`: "bbox"
     tuples (the headline's form), or the same rectangles as full int8 masks ("mask") / bit-packed boolean masks ("bits")."""
     batch = make_batch(dev, n, 1000, "o2arc", H, W)
     bb, oo = make_actions(K, n, 2000, H, W)
     if ops is not None:  # (tools/bigbench.py: one class of operations only)
         oo = (ops[0] + oo % (ops[1] - ops[0] + 1)).astype(np.int32)
+    if point_seeds:  # (tools/bigbench.py --point-seeds: every selection one cell — FloodFill really fills, as with c5's seeds)
+        bb[..., 2:] = bb[..., :2]
     bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
     FL = batch.elide_flag | STEP_AUTORESET
     if ingress == "bbox":

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--ops", default="", help="restrict the op indices drawn, e.g. 10-19 (FloodFill) or 20-23 (Move); default: all 35")
     ap.add_argument("--ingress", default="bbox", choices=["bbox", "mask", "bits"], help="the same rectangles as tuples / full int8 masks / bit-packed masks")
+    ap.add_argument("--point-seeds", action="store_true", help="every rectangle a single cell (FloodFill really fills)")
     ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replays (PMC passes: rocprofv3 counts no graph-launched kernels)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -33,6 +34,8 @@ def main():
                 if a.ops:
                     lo, hi = (int(v) for v in a.ops.split("-"))
                     oo = (lo + oo % (hi - lo + 1)).astype(np.int32)
+                if a.point_seeds:
+                    bb[..., 2:] = bb[..., :2]
                 bbd, ood = torch.from_numpy(bb).to(dev), torch.from_numpy(oo).to(dev)
                 if a.ingress != "bbox":  # the same rectangles as int8 masks / bit rows
                     x1, x2 = torch.minimum(bbd[..., 0], bbd[..., 2]), torch.maximum(bbd[..., 0], bbd[..., 2])
@@ -57,7 +60,7 @@ def main():
             if a.ops:
                 lo, hi = (int(v) for v in a.ops.split("-"))
                 ops = (lo, hi)
-            leg = BN.big_grid_case(dev, H, W, n, a.steps, ops=ops, ingress=a.ingress)
+            leg = BN.big_grid_case(dev, H, W, n, a.steps, ops=ops, ingress=a.ingress, point_seeds=a.point_seeds)
             rl = leg["roofline"]
             print(f"{H}x{W} envs {n}{' ops ' + a.ops if a.ops else ''}{' ' + a.ingress if a.ingress != 'bbox' else ''}: {leg['us_per_step_batch']:.1f} us per step = {leg['value'] / 1e6:.1f} M env-steps/s; kernel-counted "
                   f"{rl['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch ({rl['traffic'] / 1e6:.1f} issued) -> {rl['frac']:.3f} of 8 TB/s "
