@@ -393,6 +393,9 @@ ARCLE_BIG_DEV bool load_task(const X& x, R&& r, int t, int rot_k, uint64_t perm,
   return true;
 }
 
+ARCLE_BIG_DEV Chunk rect_mask16(int c, int W, uint32_t wm, int r0, int r1, int c0, int c1);  // (defined with the whole-chunk forms below)
+ARCLE_BIG_DEV uint32_t nz_bytes(uint32_t v);
+
 // answer.shape == grid_dim and grid[:h,:w] == answer (base.py:177, o2arcenv.py:124-127); workgroup-uniform result.
 // (two barriers; the caller has made the grid plane in global memory final and visible — a barrier since its last store)
 template <class X, class R>
@@ -407,14 +410,19 @@ ARCLE_BIG_DEV bool grid_equals_answer(const X& x, const R& r) {
     if (c >= lastc) break;
     const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
     if ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) {
-      int f = 16 * c;
-      int i = div_w(f, x.wm), j = f - i * x.W;
+      if (x.wide()) {  // (whole words: the differing bytes under the gh x gw rectangle's byte mask — no loop over the cells)
+        const Chunk in = rect_mask16(c, x.W, x.wm, 0, gh, 0, gw);
+        differs |= (((a.w[0] ^ b.w[0]) & in.w[0]) | ((a.w[1] ^ b.w[1]) & in.w[1]) | ((a.w[2] ^ b.w[2]) & in.w[2]) | ((a.w[3] ^ b.w[3]) & in.w[3])) != 0u;
+      } else {
+        int f = 16 * c;
+        int i = div_w(f, x.wm), j = f - i * x.W;
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        if (i < gh && j < gw && a.b[k] != b.b[k]) differs = true;
-        if (++j == x.W) {
-          j = 0;
-          ++i;
+        for (int k = 0; k < 16; k++) {
+          if (i < gh && j < gw && a.b[k] != b.b[k]) differs = true;
+          if (++j == x.W) {
+            j = 0;
+            ++i;
+          }
         }
       }
     }
@@ -1755,6 +1763,12 @@ ARCLE_BIG_DEV void step_env_t(const BigParams& p, const int env, int8_t* lds) {
       BIG_EACH_CHUNK(x, c) {
         if (c >= lastc) break;
         const Chunk a = x.gl(ARCLE_PL_GRID, c), b = x.gl(ARCLE_PL_ANSWER, c);
+        if (x.wide()) {  // (whole words: equal bytes under the common rectangle's mask, counted)
+          const Chunk in = rect_mask16(c, W, x.wm, 0, mh, 0, mw);
+#pragma unroll
+          for (int q = 0; q < 4; q++) mine += __builtin_popcount(~nz_bytes(a.w[q] ^ b.w[q]) & in.w[q] & 0x01010101u);
+          continue;
+        }
         int f = 16 * c;
         int i = div_w(f, x.wm), j = f - i * W;
 #pragma unroll
