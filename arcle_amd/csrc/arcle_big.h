@@ -17,8 +17,10 @@
 //     tuple); the few LDS atomics left (dense pair, byte accounting; the CPU emulation of this step) are compiled with
 //     -amdgpu-atomic-optimizer-strategy=DPP (arcle_amd/_lib.py): the compiler's default turns a same-address atomic into a scalar loop over
 //     the lanes;
-//   * FloodFill runs on 128-bit row boards (one thread per row): a pass pulls the fill from the rows above and below and spreads it along
-//     the row's eligible runs with the carry trick (E + F ripples through a run of ones), until no row changes;
+//   * FloodFill runs on 128-bit row boards: the eligibility boards are built on whole chunks (bytes equal to the seed's colour -> a 16-bit
+//     map OR-ed into the one or two rows a chunk touches), then one thread per row: a pass pulls the fill from the rows above and below and
+//     spreads it along the row's eligible runs with the carry trick (E + F ripples through a run of ones), until no row changes; the
+//     region is coloured chunk by chunk from 16 board bits;
 //   * per-env scalars (the 16-byte record, counters, op descriptor) are loaded by every thread — the same address: the compiler proves it
 //     and issues scalar loads — and kept in scalar registers; thread 0 writes them back.
 // What a launch costs is the number of instructions its wavefronts issue (one per ~4 cycles and SIMD, of any kind; one scalar instruction
